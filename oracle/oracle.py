@@ -1,0 +1,309 @@
+"""CPU oracle for the GPTQ-for-LLaMa QuantLinear hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product package (``gptq-for-llama_amd/``) never does.
+
+Two layers:
+
+* ``lib`` -- ctypes binding of ``libgptq_oracle.so`` (``gptq_oracle.c``), the C
+  restatement of the reference kernels (file:line citations live in the C header).
+* ``np_*`` -- a second, independent numpy restatement of the bit layout
+  (reference ``quant/quant_linear.py:103-128`` for unpack, ``:325-371`` for pack) used to
+  cross-check the C code.
+
+Parity pin: ``tests/golden/*.npz`` were produced by the reference's own Triton kernels run
+under ``TRITON_INTERPRET=1`` and by its own ``QuantLinear.pack`` (see
+``tests/golden/gen_golden.py``); ``tests/test_oracle_golden.py`` holds this oracle to them.
+bits == 3 is an extension the reference rejects (``quant_linear.py:308-309``): parity unpinned.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'libgptq_oracle.so')
+
+
+def build(force=False):
+    """(Re)build libgptq_oracle.so with the committed Makefile."""
+    src = os.path.join(_HERE, 'gptq_oracle.c')
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'libgptq_oracle.so'],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def _load():
+    build()
+    try:
+        return ctypes.CDLL(_SO)
+    except OSError:
+        build(force=True)
+        return ctypes.CDLL(_SO)
+
+
+lib = _load()
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u16p = ctypes.POINTER(ctypes.c_uint16)
+_f32p = ctypes.POINTER(ctypes.c_float)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _c(a, dtype):
+    return None if a is None else np.ascontiguousarray(np.asarray(a), dtype=dtype)
+
+
+def _h(a):
+    """fp16 array -> contiguous uint16 view."""
+    if a is None:
+        return None
+    a = np.ascontiguousarray(np.asarray(a))
+    if a.dtype != np.float16:
+        a = a.astype(np.float16)
+    return a.view(np.uint16)
+
+
+def num_threads():
+    return int(lib.oracle_num_threads())
+
+
+def n_groups(K, groupsize):
+    gs = K if groupsize == -1 else groupsize
+    return -(-K // gs)
+
+
+def trivial_g_idx(K, groupsize):
+    gs = K if groupsize == -1 else groupsize
+    return (np.arange(K) // gs).astype(np.int32)
+
+
+def dequant(qweight, qzeros, scales, g_idx, bits, faithful=True):
+    """W[K,N] float32. faithful=True rounds like the reference kernel (fp16 weight)."""
+    qweight = _c(qweight, np.int32)
+    qzeros = _c(qzeros, np.int32)
+    s = _h(scales)
+    g = _c(g_idx, np.int32)
+    K = g.shape[0]
+    N = qweight.shape[1]
+    G = s.shape[0]
+    W = np.empty((K, N), dtype=np.float32)
+    rc = lib.oracle_dequant(_p(qweight, _i32p), _p(qzeros, _i32p), _p(s, _u16p), _p(g, _i32p),
+                            K, N, G, bits, int(bool(faithful)), _p(W, _f32p))
+    if rc:
+        raise NotImplementedError('oracle: unsupported bits %r' % (bits,))
+    return W
+
+
+def matmul248(x, qweight, scales, qzeros, g_idx, bits, bias=None):
+    """Reference-faithful forward; argument order follows reference matmul248()
+    (quant/quant_linear.py:263).  x [M,K] fp16 -> y [M,N] fp16."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float16))
+    M, K = x.shape
+    qweight = _c(qweight, np.int32)
+    qzeros = _c(qzeros, np.int32)
+    s = _h(scales)
+    g = _c(g_idx, np.int32)[:K]
+    N = qweight.shape[1]
+    G = s.shape[0]
+    y = np.empty((M, N), dtype=np.float16)
+    b = _h(bias)
+    rc = lib.oracle_matmul248(_p(x.view(np.uint16), _u16p), ctypes.c_int64(K), _p(qweight, _i32p),
+                              _p(qzeros, _i32p), _p(s, _u16p), _p(g, _i32p), _p(b, _u16p),
+                              _p(y.view(np.uint16), _u16p), ctypes.c_int64(N), M, K, N, G, bits)
+    if rc:
+        raise NotImplementedError('oracle: unsupported bits %r' % (bits,))
+    return y
+
+
+def matmul248_exact(x, qweight, scales, qzeros, g_idx, bits):
+    """float64 result with the weight never rounded to fp16."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float16))
+    M, K = x.shape
+    qweight = _c(qweight, np.int32)
+    qzeros = _c(qzeros, np.int32)
+    s = _h(scales)
+    g = _c(g_idx, np.int32)[:K]
+    N = qweight.shape[1]
+    G = s.shape[0]
+    y = np.empty((M, N), dtype=np.float64)
+    rc = lib.oracle_matmul248_exact(_p(x.view(np.uint16), _u16p), ctypes.c_int64(K),
+                                    _p(qweight, _i32p), _p(qzeros, _i32p), _p(s, _u16p),
+                                    _p(g, _i32p), _p(y, _f64p), M, K, N, G, bits)
+    if rc:
+        raise NotImplementedError('oracle: unsupported bits %r' % (bits,))
+    return y
+
+
+def transpose_matmul248(dy, qweight, scales, qzeros, g_idx, bits):
+    """dX[M,K] = dY[M,N] . deq(B)^T (reference transpose_matmul248, quant_linear.py:272)."""
+    dy = np.ascontiguousarray(np.asarray(dy, dtype=np.float16))
+    M, N = dy.shape
+    qweight = _c(qweight, np.int32)
+    qzeros = _c(qzeros, np.int32)
+    s = _h(scales)
+    K = qweight.shape[0] * 32 // bits
+    g = _c(g_idx, np.int32)[:K]
+    G = s.shape[0]
+    dx = np.empty((M, K), dtype=np.float16)
+    rc = lib.oracle_transpose_matmul248(_p(dy.view(np.uint16), _u16p), ctypes.c_int64(N),
+                                        _p(qweight, _i32p), _p(qzeros, _i32p), _p(s, _u16p),
+                                        _p(g, _i32p), _p(dx.view(np.uint16), _u16p),
+                                        ctypes.c_int64(K), M, K, N, G, bits)
+    if rc:
+        raise NotImplementedError('oracle: unsupported bits %r' % (bits,))
+    return dx
+
+
+def fused_mlp(x, gate, up, bits):
+    """silu(x.Wg) * (x.Wu); gate/up = (qweight, scales, qzeros, g_idx) tuples
+    (reference fusedmatmul_248_kernel, quant/fused_mlp.py:84-168)."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float16))
+    M, K = x.shape
+    a = [_c(gate[0], np.int32), _h(gate[1]), _c(gate[2], np.int32), _c(gate[3], np.int32)[:K]]
+    b = [_c(up[0], np.int32), _h(up[1]), _c(up[2], np.int32), _c(up[3], np.int32)[:K]]
+    N = a[0].shape[1]
+    G = a[1].shape[0]
+    c = np.empty((M, N), dtype=np.float16)
+    rc = lib.oracle_fused_mlp(_p(x.view(np.uint16), _u16p), ctypes.c_int64(K),
+                              _p(a[0], _i32p), _p(a[2], _i32p), _p(a[1], _u16p), _p(a[3], _i32p),
+                              _p(b[0], _i32p), _p(b[2], _i32p), _p(b[1], _u16p), _p(b[3], _i32p),
+                              _p(c.view(np.uint16), _u16p), ctypes.c_int64(N), M, K, N, G, bits)
+    if rc:
+        raise NotImplementedError('oracle: unsupported bits %r' % (bits,))
+    return c
+
+
+def rmsnorm(x, weight, eps):
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float16))
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    M, N = x2.shape
+    w = _h(weight)
+    y = np.empty((M, N), dtype=np.float16)
+    lib.oracle_rmsnorm(_p(x2.view(np.uint16), _u16p), ctypes.c_int64(N), _p(w, _u16p),
+                       _p(y.view(np.uint16), _u16p), ctypes.c_int64(N), M, N, ctypes.c_float(eps))
+    return y.reshape(shape)
+
+
+def rope_(qk, position_ids, base=10000.0):
+    """In-place RoPE on qk [bsz, seq, 2, heads, head_dim] fp16 view whose (bsz,seq) rows are
+    `row_stride` apart (reference triton_rotate_half_, quant/fused_attn.py:61-93).
+    qk must be a numpy fp16 array whose last three dims are contiguous."""
+    bsz, seq, two, heads, hd = qk.shape
+    assert two == 2
+    assert qk.strides[4] == 2 and qk.strides[3] == 2 * hd and qk.strides[2] == 2 * hd * heads
+    assert qk.strides[0] == qk.strides[1] * seq
+    ld = qk.strides[1] // 2
+    pos = np.ascontiguousarray(np.asarray(position_ids, dtype=np.int64).reshape(bsz * seq))
+    ptr = ctypes.cast(qk.ctypes.data, _u16p)
+    lib.oracle_rope(ptr, ctypes.c_int64(ld), _p(pos, _i64p), bsz * seq, 2 * heads, hd,
+                    ctypes.c_float(base))
+    return qk
+
+
+def pack(weight, scales, zeros, g_idx, bits, groupsize):
+    """C restatement of QuantLinear.pack.  weight [N,K] fp32, scales/zeros [N,G] fp32."""
+    weight = _c(weight, np.float32)
+    N, K = weight.shape
+    G = n_groups(K, groupsize)
+    scales = _c(np.asarray(scales).reshape(N, G), np.float32)
+    zeros = _c(np.asarray(zeros).reshape(N, G), np.float32)
+    g = _c(g_idx if g_idx is not None else trivial_g_idx(K, groupsize), np.int32)
+    qweight = np.empty((K // 32 * bits, N), dtype=np.int32)
+    qzeros = np.empty((G, N // 32 * bits), dtype=np.int32)
+    s16 = np.empty((G, N), dtype=np.uint16)
+    rc = lib.oracle_pack(_p(weight, _f32p), _p(scales, _f32p), _p(zeros, _f32p), _p(g, _i32p),
+                         K, N, G, bits, _p(qweight, _i32p), _p(qzeros, _i32p), _p(s16, _u16p))
+    if rc:
+        raise NotImplementedError('oracle: unsupported bits %r' % (bits,))
+    return qweight, qzeros, s16.view(np.float16), g
+
+
+# --------------------------------------------------------------------------------------
+# independent numpy restatement of the bit layout (cross-check for the C code)
+# --------------------------------------------------------------------------------------
+
+def np_unpack_rows(qweight, bits):
+    """[K/32*bits, N] int32 -> integer fields [K, N] (unpack along rows, k axis)."""
+    qw = np.asarray(qweight).astype(np.int32).view(np.uint32)
+    R, N = qw.shape
+    if bits == 3:
+        blk = qw.reshape(R // 3, 3, N).astype(np.uint64)
+        stream_lo = blk[:, 0] | (blk[:, 1] << np.uint64(32))       # bits 0..63
+        stream_hi = blk[:, 2]                                       # bits 64..95
+        out = np.empty((R // 3, 32, N), dtype=np.int32)
+        for j in range(32):
+            b = 3 * j
+            if b + 3 <= 64:
+                v = (stream_lo >> np.uint64(b)) & np.uint64(7)
+            elif b >= 64:
+                v = (stream_hi >> np.uint64(b - 64)) & np.uint64(7)
+            else:  # straddles bit 64 (j == 21: bits 63..65)
+                v = ((stream_lo >> np.uint64(b)) | (stream_hi << np.uint64(64 - b))) & np.uint64(7)
+            out[:, j] = v.astype(np.int32)
+        return out.reshape(R // 3 * 32, N)
+    f = 32 // bits
+    sh = (np.arange(f, dtype=np.uint32) * bits)[None, :, None]
+    return ((qw[:, None, :] >> sh) & np.uint32((1 << bits) - 1)).astype(np.int32).reshape(R * f, N)
+
+
+def np_unpack_cols(qzeros, bits):
+    """[G, N/32*bits] int32 -> fields [G, N] (unpack along columns, n axis); raw, no +1."""
+    return np_unpack_rows(np.ascontiguousarray(np.asarray(qzeros).T), bits).T
+
+
+def np_dequant(qweight, qzeros, scales, g_idx, bits, faithful=True):
+    q = np_unpack_rows(qweight, bits)
+    z = np_unpack_cols(qzeros, bits) + 1
+    K = q.shape[0]
+    g = np.asarray(g_idx)[:K].astype(np.int64)
+    s = np.asarray(scales, dtype=np.float16)
+    d = (q - z[g])
+    if faithful:
+        return (d.astype(np.float16) * s[g]).astype(np.float32)
+    return d.astype(np.float32) * s[g].astype(np.float32)
+
+
+def np_pack_fields_rows(fields, bits):
+    """Inverse of np_unpack_rows for in-range fields [K,N] -> [K/32*bits, N] int32."""
+    fields = np.asarray(fields).astype(np.uint32)
+    K, N = fields.shape
+    if bits == 3:
+        out = np.zeros((K // 32, 3, N), dtype=np.uint64)
+        f3 = fields.reshape(K // 32, 32, N).astype(np.uint64) & np.uint64(7)
+        for j in range(32):
+            b = 3 * j
+            w, o = b // 32, b % 32
+            out[:, w] |= (f3[:, j] << np.uint64(o)) & np.uint64(0xFFFFFFFF)
+            if o + 3 > 32:
+                out[:, w + 1] |= f3[:, j] >> np.uint64(32 - o)
+        return out.astype(np.uint32).view(np.int32).reshape(K // 32 * 3, N)
+    f = 32 // bits
+    out = np.zeros((K // f, N), dtype=np.uint32)
+    ff = fields.reshape(K // f, f, N)
+    for j in range(f):
+        out |= ff[:, j] << np.uint32(bits * j)
+    return out.view(np.int32)
+
+
+def np_pack_fields_cols(fields, bits):
+    return np.ascontiguousarray(np_pack_fields_rows(np.asarray(fields).T, bits).T)
+
+
+def algorithmic_bytes(M, K, N, bits, groupsize, act_order=False, bias=False):
+    """SURVEY.md section 8(d) / BASELINE.md section 3 byte model for one dequant-matmul."""
+    G = n_groups(K, groupsize)
+    b = 4 * (K * bits // 32) * N + 4 * G * (N * bits // 32) + 2 * G * N + 2 * M * K + 2 * M * N
+    if act_order:
+        b += 4 * K
+    if bias:
+        b += 2 * N
+    return b

@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: "int4 g128 matvec GB/s + decode tokens/s, LLaMA-7B 4-bit".
+
+One "step" = one batch-1 decode pass over ALL quantised linears of a LLaMA-7B-shaped model
+(32 layers x [fused qkv 4096x12288, o_proj 4096x4096, fused gate/up+SiLU 2 x 4096x11008,
+down_proj 11008x4096], 4-bit, groupsize 128; synthetic random-init packed weights),
+issued through the C ABI (include/gptq_mi355x.h) exactly as the drop-in modules issue it after
+make_quant_attn / make_fused_mlp: 4 launches per layer, 128 per step, 3.37 GB of distinct
+weights per step (> the 256 MiB Infinity Cache, so every step streams from HBM).
+The step is captured once into a hipGraph and replayed; inputs are resident in HBM.
+
+value      = algorithmic GB/s of the whole job (SURVEY 8(d) byte model), all ranks summed.
+roofline   = the GEMV kernel family against the 8 TB/s HBM3E spec peak.
+cpu_baseline = the C/OpenMP oracle (oracle/gptq_oracle.c, a port of the reference kernel
+             arithmetic) on the host cores, on a bounded sample of the same workload.
+--gpus N   = N data-parallel replicas (one process per GPU, no data-path collective; weak
+             scaling).  `--tp` additionally times the row-sharded variant (one RCCL all-reduce
+             per linear, BASELINE config 5) and reports it under "tp".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'gptq-for-llama_amd'))
+sys.path.insert(0, ROOT)
+
+import torch
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+HIDDEN, INTER, LAYERS, BITS, GS = 4096, 11008, 32, 4, 128
+
+
+def alg_bytes(M, K, N, bits=BITS, gs=GS, nsets=1):
+    """qweight + qzeros + scales per weight set, x once, y once."""
+    G = -(-K // gs)
+    per_set = 4 * (K * bits // 32) * N + 4 * G * (N * bits // 32) + 2 * G * N
+    return nsets * per_set + 2 * M * K + 2 * M * N
+
+
+class PackedSet:
+    """random packed weight set on the GPU (uniform bit patterns, scales ~ U(0.001, 0.011))."""
+
+    def __init__(self, K, N, dev, gen):
+        G = K // GS
+        self.K, self.N = K, N
+        self.qweight = torch.randint(-2**31, 2**31 - 1, (K * BITS // 32, N), dtype=torch.int32, device=dev, generator=gen)
+        self.qzeros = torch.randint(-2**31, 2**31 - 1, (G, N * BITS // 32), dtype=torch.int32, device=dev, generator=gen)
+        self.scales = (torch.rand((G, N), device=dev, generator=gen) * 0.01 + 0.001).half()
+
+
+class DecodeLinears:
+    """the 4 launches/layer x 32 layers of one decode token, as raw C-ABI calls."""
+
+    def __init__(self, dev, layers=LAYERS, seed=0):
+        from quant import _native
+        self.native = _native
+        self.lib = _native.lib()
+        self.dev = dev
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        self.layers = []
+        for _ in range(layers):
+            self.layers.append(dict(qkv=PackedSet(HIDDEN, 3 * HIDDEN, dev, gen), o=PackedSet(HIDDEN, HIDDEN, dev, gen),
+                                    gate=PackedSet(HIDDEN, INTER, dev, gen), up=PackedSet(HIDDEN, INTER, dev, gen),
+                                    down=PackedSet(INTER, HIDDEN, dev, gen)))
+        self.x_h = torch.randn((1, HIDDEN), device=dev, generator=gen).half()
+        self.x_i = (torch.randn((1, INTER), device=dev, generator=gen) * 0.5).half()
+        self.y_qkv = torch.empty((1, 3 * HIDDEN), dtype=torch.float16, device=dev)
+        self.y_h = torch.empty((1, HIDDEN), dtype=torch.float16, device=dev)
+        self.y_i = torch.empty((1, INTER), dtype=torch.float16, device=dev)
+        self.ws = _native.workspace(torch.device(dev))
+        self.bytes_per_step = layers * (alg_bytes(1, HIDDEN, 3 * HIDDEN) + alg_bytes(1, HIDDEN, HIDDEN) +
+                                        alg_bytes(1, HIDDEN, INTER, nsets=2) + alg_bytes(1, INTER, HIDDEN))
+        self.launches_per_step = 4 * layers
+
+    def _mm(self, x, w, y, stream):
+        rc = self.lib.gptq_matmul248_f16(x.data_ptr(), w.K, w.qweight.data_ptr(), w.scales.data_ptr(), w.qzeros.data_ptr(),
+                                         None, None, y.data_ptr(), w.N, 1, w.K, w.N, BITS, GS, self.ws.data_ptr(),
+                                         self.ws.numel(), stream)
+        self.native.check(rc, 'gptq_matmul248_f16')
+
+    def _mlp(self, x, g, u, y, stream):
+        rc = self.lib.gptq_fused_mlp_f16(x.data_ptr(), g.K, g.qweight.data_ptr(), g.scales.data_ptr(), g.qzeros.data_ptr(),
+                                         None, u.qweight.data_ptr(), u.scales.data_ptr(), u.qzeros.data_ptr(), None,
+                                         y.data_ptr(), g.N, 1, g.K, g.N, BITS, GS, self.ws.data_ptr(), self.ws.numel(), stream)
+        self.native.check(rc, 'gptq_fused_mlp_f16')
+
+    def step(self):
+        s = torch.cuda.current_stream().cuda_stream
+        for L in self.layers:
+            self._mm(self.x_h, L['qkv'], self.y_qkv, s)
+            self._mm(self.x_h, L['o'], self.y_h, s)
+            self._mlp(self.x_h, L['gate'], L['up'], self.y_i, s)
+            self._mm(self.x_i, L['down'], self.y_h, s)
+
+    def per_shape(self, reps=20):
+        """event-timed launches per shape, rotating over the 32 layers' distinct weights (cold)."""
+        out = {}
+        s = torch.cuda.current_stream().cuda_stream
+        legs = {
+            'qkv_4096x12288': (lambda L: self._mm(self.x_h, L['qkv'], self.y_qkv, s), alg_bytes(1, HIDDEN, 3 * HIDDEN)),
+            'o_4096x4096': (lambda L: self._mm(self.x_h, L['o'], self.y_h, s), alg_bytes(1, HIDDEN, HIDDEN)),
+            'gate_up_silu_2x4096x11008': (lambda L: self._mlp(self.x_h, L['gate'], L['up'], self.y_i, s),
+                                          alg_bytes(1, HIDDEN, INTER, nsets=2)),
+            'down_11008x4096': (lambda L: self._mm(self.x_i, L['down'], self.y_h, s), alg_bytes(1, INTER, HIDDEN)),
+        }
+        for name, (fn, nbytes) in legs.items():
+            g = torch.cuda.CUDAGraph()
+            for L in self.layers:
+                fn(L)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                for L in self.layers:
+                    fn(L)
+            g.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / (reps * len(self.layers))
+            out[name] = {'us_per_launch': round(us, 3), 'GBps': round(nbytes / us / 1e3, 1),
+                         'frac_of_8TBps': round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4)}
+        return out
+
+
+def cpu_baseline(budget_s=20.0):
+    """the oracle (port of the reference kernel arithmetic) on the host cores: one decoder layer's
+    five matvecs (qkv as one 4096x12288, o, gate, up, down), repeated until ~budget_s."""
+    import numpy as np
+    from oracle import oracle
+    rng = np.random.default_rng(0)
+
+    def rand_set(K, N):
+        G = K // GS
+        return (rng.integers(-2**31, 2**31, size=(K * BITS // 32, N), dtype=np.int64).astype(np.int32),
+                rng.uniform(0.001, 0.011, size=(G, N)).astype(np.float16),
+                rng.integers(-2**31, 2**31, size=(G, N * BITS // 32), dtype=np.int64).astype(np.int32),
+                oracle.trivial_g_idx(K, GS))
+
+    shapes = [(HIDDEN, 3 * HIDDEN), (HIDDEN, HIDDEN), (HIDDEN, INTER), (HIDDEN, INTER), (INTER, HIDDEN)]
+    sets = [rand_set(K, N) for K, N in shapes]
+    xs = {HIDDEN: rng.standard_normal((1, HIDDEN)).astype(np.float16), INTER: rng.standard_normal((1, INTER)).astype(np.float16)}
+    nbytes = sum(alg_bytes(1, K, N) for K, N in shapes)
+    t_total, n = 0.0, 0
+    while t_total < budget_s and n < 50:
+        t0 = time.perf_counter()
+        for (K, N), (qw, sc, qz, gi) in zip(shapes, sets):
+            oracle.matmul248(xs[K], qw, sc, qz, gi, BITS)
+        t_total += time.perf_counter() - t0
+        n += 1
+    return {'value': round(nbytes * n / t_total / 1e9, 3), 'unit': 'GB/s', 'cores': oracle.num_threads(), 'kind': 'port',
+            'sample': '%d x one LLaMA-7B decoder layer (5 matvecs, %.1f MB algorithmic) by oracle/gptq_oracle.c (OpenMP)' %
+                      (n, nbytes / 1e6), 'seconds': round(t_total, 2)}
+
+
+def decode_tokens_per_s(dev, tokens=64):
+    """full decode step (norms, fused qkv + RoPE, KV cache, SDPA, o_proj, fused MLP, lm_head) on a
+    random-init LLaMA-7B-shaped model built from the drop-in modules; protocol of the reference's
+    benchmark() (llama.py:385-438): one token per step with KV cache, sync per step, median."""
+    try:
+        from quant.decode import build_random_llama, benchmark_decode
+    except Exception as e:  # pragma: no cover
+        return {'error': repr(e)}
+    model = build_random_llama(dev)
+    return benchmark_decode(model, tokens)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-decode', action='store_true')
+    ap.add_argument('--no-per-shape', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='time eager launches instead of hipGraph replay')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    import torch.distributed as dist
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = 'cuda:%d' % local_rank
+
+    work = DecodeLinears(dev, seed=rank)
+    for _ in range(2):
+        work.step()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.eager:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            work.step()
+    run = graph.replay if graph is not None else work.step
+
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if distributed:
+        dist.barrier()
+    ev_ms = e0.elapsed_time(e1)
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+
+    if rank == 0:
+        ms_per_step = wall_max * 1e3 / args.steps
+        total_bytes = work.bytes_per_step * world
+        value = total_bytes / (ms_per_step * 1e-3) / 1e9
+        us_per_launch = ev_ms * 1e3 / (args.steps * work.launches_per_step)
+        bytes_per_launch = work.bytes_per_step / work.launches_per_step
+        achieved = bytes_per_launch / us_per_launch / 1e3
+        out = {
+            'metric': 'int4 g128 matvec GB/s (LLaMA-7B 4-bit batch-1 decode pass over all quantised linears)',
+            'value': round(value, 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'int4 weights, fp16 activations, fp32 accumulate', 'data': 'synthetic',
+            'config': {'workload': 'LLaMA-7B-shaped 4-bit g128 matvec, batch=1 seq=1 (BASELINE configs[1]): 32 layers x '
+                                   '{qkv 4096x12288, o 4096x4096, gate/up+SiLU 2x4096x11008, down 11008x4096}',
+                       'launches_per_step': work.launches_per_step, 'algorithmic_bytes_per_step': work.bytes_per_step,
+                       'launch_mode': 'eager' if args.eager else 'hipGraph replay', 'parallelism': 'dp%d replicas' % world},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'kernel': 'gptq::gemv_fast_kernel<4,...> (all 128 launches/step)',
+                         'avg_launch_us': round(us_per_launch, 3), 'algorithmic_bytes_per_launch': int(bytes_per_launch)},
+        }
+        if not args.no_per_shape:
+            out['per_shape'] = work.per_shape()
+        if not args.no_decode:
+            out['decode'] = decode_tokens_per_s(dev)
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

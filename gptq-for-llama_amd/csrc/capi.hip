@@ -1,0 +1,353 @@
+// capi.hip -- extern "C" entry points of libgptq_mi355x.so (declared in include/gptq_mi355x.h)
+// and the static shape -> kernel dispatch that replaces the reference's Triton autotuner
+// (quant/custom_autotune.py:14-127, pruner :167-193) behind the same warm-up surface.
+#include <atomic>
+
+#include "gptq_internal.h"
+
+namespace gptq {
+
+static std::atomic<int> g_force_variant{-1};
+static std::atomic<int> g_force_split_k{-1};
+
+static bool aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+struct Problem {
+    const void *x;
+    int64_t ldx;
+    const int32_t *qw[2];
+    const void *sc[2];
+    const int32_t *qz[2];
+    const int32_t *gi[2];
+    const void *bias;
+    void *y;
+    int64_t ldy;
+    int M, K, N, bits, groupsize;
+    bool fused2;
+    void *ws;
+    size_t ws_bytes;
+};
+
+static int validate(const Problem &q) {
+    if (q.bits != 2 && q.bits != 3 && q.bits != 4 && q.bits != 8) return GPTQ_E_BITS;
+    if (q.M < 0 || q.K <= 0 || q.N <= 0 || q.groupsize <= 0) return GPTQ_E_SHAPE;
+    if (q.K % 32 != 0 || q.N % 32 != 0) return GPTQ_E_SHAPE;
+    const int ns = q.fused2 ? 2 : 1;
+    if (!q.x || !q.y) return GPTQ_E_NULL;
+    for (int s = 0; s < ns; s++)
+        if (!q.qw[s] || !q.sc[s] || !q.qz[s]) return GPTQ_E_NULL;
+    if (!aligned(q.x, 16) || q.ldx % 8 != 0 || !aligned(q.y, 8) || q.ldy % 4 != 0) return GPTQ_E_ALIGN;
+    for (int s = 0; s < ns; s++)
+        if (!aligned(q.qw[s], 16) || !aligned(q.sc[s], 8) || !aligned(q.qz[s], 4)) return GPTQ_E_ALIGN;
+    if (q.bias && !aligned(q.bias, 2)) return GPTQ_E_ALIGN;
+    return 0;
+}
+
+static int n_groups(int K, int gs) { return (K + gs - 1) / gs; }
+
+static bool fast_eligible(const Problem &q, int unit_k) {
+    if (q.bits == 3) return false;
+    if (q.gi[0] || (q.fused2 && q.gi[1])) return false;
+    return q.groupsize % unit_k == 0;
+}
+
+static void fill_params(const Problem &q, int m0, int mcount, GemvParams &p) {
+    p.x = (const half_t *)q.x + (size_t)m0 * q.ldx;
+    p.ldx = q.ldx;
+    for (int s = 0; s < 2; s++) {
+        p.qw[s] = (const uint32_t *)q.qw[s];
+        p.sc[s] = (const half_t *)q.sc[s];
+        p.qz[s] = q.qz[s];
+        p.gi[s] = q.gi[s];
+    }
+    p.bias = (const half_t *)q.bias;
+    p.y = (half_t *)q.y + (size_t)m0 * q.ldy;
+    p.ldy = q.ldy;
+    p.M = mcount;
+    p.K = q.K;
+    p.N = q.N;
+    p.G = n_groups(q.K, q.groupsize);
+    p.groupsize = q.groupsize;
+    p.counters = (unsigned *)q.ws;
+    p.ws = q.ws ? (float *)((char *)q.ws + (size_t)MAX_TILES * 4) : nullptr;
+}
+
+// Built-in table: which (NL, WAVES) tiling and K split the fast GEMV uses for a shape.
+// Filled from the MI355X sweep in profiles/ (see DESIGN.md "dispatch table").
+static void pick_gemv(int K, int N, bool fused2, int &variant, int &split_k) {
+    (void)K;
+    (void)fused2;
+    split_k = 1;
+    if (N >= 8192)
+        variant = 4;  // 32-col tiles x 512 threads
+    else
+        variant = 1;  // 16-col tiles x 512 threads
+}
+
+static int run_gemv(const Problem &q, hipStream_t s) {
+    const bool fast = fast_eligible(q, 32);
+    int variant, split_k;
+    pick_gemv(q.K, q.N, q.fused2, variant, split_k);
+    const int fv = g_force_variant.load();
+    if (fv >= 0) {
+        if (fv >= GEMV_NUM_VARIANTS) return GPTQ_E_VARIANT;
+        variant = fv;
+    }
+    const int fs = g_force_split_k.load();
+    if (fs >= 1) split_k = fs;
+    const int nchunks = q.K / 32;
+    if (split_k > nchunks) split_k = nchunks;
+    if (!fast) split_k = 1;
+    const int ns = q.fused2 ? 2 : 1;
+    const size_t ws_need = (size_t)MAX_TILES * 4 + (size_t)ns * GEMV_MAX_M * q.N * 4;
+    if (split_k > 1 && (!q.ws || q.ws_bytes < ws_need)) {
+        if (fs >= 1) return GPTQ_E_WORKSPACE;
+        split_k = 1;
+    }
+    int cps = (nchunks + split_k - 1) / split_k;
+    split_k = (nchunks + cps - 1) / cps;
+
+    for (int m0 = 0; m0 < q.M;) {
+        int mr = q.M - m0 >= 4 ? 4 : (q.M - m0 >= 2 ? 2 : 1);
+        if (q.fused2 && mr > 2) mr = 2;
+        GemvParams p;
+        int rc;
+        if (fast) {
+            while (mr > 1 && (size_t)mr * cps * 64 > 128 * 1024) mr >>= 1;
+            fill_params(q, m0, mr, p);
+            const int nl = g_gemv_variants[variant].nl;
+            p.ntiles = (q.N + 4 * nl - 1) / (4 * nl);
+            if (split_k > 1 && p.ntiles > MAX_TILES) return GPTQ_E_WORKSPACE;
+            p.split_k = split_k;
+            p.nchunks = nchunks;
+            p.chunks_per_slice = cps;
+            rc = gemv_fast_dispatch(q.bits, q.fused2, variant, p, s);
+        } else {
+            // LDS: x [mr][K] + g_idx + {s,z} table for the tile; narrow tiles when G is large
+            const int G = n_groups(q.K, q.groupsize);
+            int nl = 16;
+            auto need = [&](int mr_, int nl_) {
+                return (size_t)mr_ * q.K * 2 + (size_t)ns * q.K * 2 + 16 + (size_t)ns * G * 4 * nl_ * 4;
+            };
+            if (need(mr, nl) > 150 * 1024 || (q.N / 64) < 128) nl = 4;
+            while (mr > 1 && need(mr, nl) > 150 * 1024) mr >>= 1;
+            fill_params(q, m0, mr, p);
+            p.ntiles = (q.N + 4 * nl - 1) / (4 * nl);
+            p.split_k = 1;
+            p.nchunks = nchunks;
+            p.chunks_per_slice = nchunks;
+            rc = gemv_generic_dispatch(q.bits, q.fused2, nl, p, s);
+        }
+        if (rc) return rc;
+        m0 += mr;
+    }
+    return 0;
+}
+
+static int run_skinny(const Problem &q, hipStream_t s) {
+    const int unit_k = (q.bits == 2) ? 64 : 32;
+    if (!fast_eligible(q, unit_k)) return run_gemv(q, s);
+    const int ns = q.fused2 ? 2 : 1;
+    const int mmax = q.fused2 ? 32 : SKINNY_MAX_M;
+    for (int m0 = 0; m0 < q.M; m0 += mmax) {
+        const int mc = (q.M - m0 < mmax) ? (q.M - m0) : mmax;
+        GemvParams p;
+        fill_params(q, m0, mc, p);
+        p.ntiles = (q.N + 63) / 64;
+        const int nunits = q.K / unit_k;
+        // aim for >= 2 workgroups per CU; K slices must hold whole groups
+        int split_k = 1;
+        const int fs = g_force_split_k.load();
+        if (fs >= 1) {
+            split_k = fs;
+        } else {
+            while (p.ntiles * split_k < 512 && split_k * 2 * 4 <= nunits) split_k *= 2;
+        }
+        const size_t ws_need = (size_t)MAX_TILES * 4 + (size_t)ns * mc * q.N * 4;
+        if (split_k > 1 && (!q.ws || q.ws_bytes < ws_need || p.ntiles > MAX_TILES)) {
+            if (fs >= 1) return GPTQ_E_WORKSPACE;
+            split_k = 1;
+        }
+        // slices hold whole units; group boundaries are handled per unit inside the kernel
+        if (split_k > nunits) split_k = nunits;
+        const int ups = (nunits + split_k - 1) / split_k;
+        split_k = (nunits + ups - 1) / ups;
+        p.split_k = split_k;
+        p.nchunks = nunits;
+        p.chunks_per_slice = ups;
+        int rc = skinny_dispatch(q.bits, q.fused2, p, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+static int run_auto(const Problem &q, hipStream_t s) {
+    if (q.M == 0) return 0;
+    if (q.M <= GEMV_MAX_M) return run_gemv(q, s);
+    if (q.M <= SKINNY_MAX_M) return run_skinny(q, s);
+    const int unit_k = (q.bits == 2) ? 64 : 32;
+    if (!q.fused2 && fast_eligible(q, unit_k)) {
+        GemvParams p;
+        fill_params(q, 0, q.M, p);
+        int rc = gemm_dispatch(q.bits, false, p, s);
+        if (rc != GPTQ_E_VARIANT) return rc;
+    }
+    return run_skinny(q, s);
+}
+
+}  // namespace gptq
+
+using namespace gptq;
+
+extern "C" {
+
+int gptq_query(int what) {
+    switch (what) {
+        case GPTQ_Q_ABI_VERSION: return 1;
+        case GPTQ_Q_GEMV_MAX_M: return GEMV_MAX_M;
+        case GPTQ_Q_SKINNY_MAX_M: return SKINNY_MAX_M;
+        case GPTQ_Q_WORKSPACE_BYTES: return (int)(MAX_TILES * 4 + 2 * (size_t)SKINNY_MAX_M * 32768 * 4);
+        case GPTQ_Q_NUM_GEMV_VARIANTS: return GEMV_NUM_VARIANTS;
+    }
+    return -1;
+}
+
+const char *gptq_strerror(int code) {
+    switch (code) {
+        case GPTQ_OK: return "ok";
+        case GPTQ_E_BITS: return "Only 2,3,4,8 bits are supported.";
+        case GPTQ_E_SHAPE: return "bad shape: K and N must be positive multiples of 32, groupsize > 0";
+        case GPTQ_E_ALIGN: return "pointer or leading-dimension alignment";
+        case GPTQ_E_NULL: return "required pointer is NULL";
+        case GPTQ_E_WORKSPACE: return "workspace missing or too small for the requested split-K";
+        case GPTQ_E_VARIANT: return "unknown or inapplicable kernel variant";
+        case GPTQ_E_NORM_WIDTH: return "This layer norm doesn't support feature dim >= 64KB.";
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown error";
+}
+
+int gptq_set_gemv_variant(int variant) { return g_force_variant.exchange(variant); }
+int gptq_set_split_k(int split_k) { return g_force_split_k.exchange(split_k); }
+
+static Problem make_problem(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
+                            const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,
+                            int groupsize, void *ws, size_t ws_bytes) {
+    Problem q{};
+    q.x = x;
+    q.ldx = ldx;
+    q.qw[0] = qweight;
+    q.sc[0] = scales;
+    q.qz[0] = qzeros;
+    q.gi[0] = g_idx;
+    q.bias = bias;
+    q.y = y;
+    q.ldy = ldy;
+    q.M = M;
+    q.K = K;
+    q.N = N;
+    q.bits = bits;
+    q.groupsize = groupsize;
+    q.fused2 = false;
+    q.ws = ws;
+    q.ws_bytes = ws_bytes;
+    return q;
+}
+
+int gptq_matmul248_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
+                       const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,
+                       int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream) {
+    Problem q = make_problem(x, ldx, qweight, scales, qzeros, g_idx, bias, y, ldy, M, K, N, bits, groupsize, workspace,
+                             workspace_bytes);
+    if (int rc = validate(q)) return rc;
+    return run_auto(q, (hipStream_t)stream);
+}
+
+int gptq_gemv_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
+                  const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,
+                  int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream) {
+    Problem q = make_problem(x, ldx, qweight, scales, qzeros, g_idx, bias, y, ldy, M, K, N, bits, groupsize, workspace,
+                             workspace_bytes);
+    if (int rc = validate(q)) return rc;
+    return run_gemv(q, (hipStream_t)stream);
+}
+
+int gptq_skinny_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
+                    const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,
+                    int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream) {
+    Problem q = make_problem(x, ldx, qweight, scales, qzeros, g_idx, bias, y, ldy, M, K, N, bits, groupsize, workspace,
+                             workspace_bytes);
+    if (int rc = validate(q)) return rc;
+    return run_skinny(q, (hipStream_t)stream);
+}
+
+int gptq_gemm_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
+                  const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,
+                  int groupsize, gptq_stream_t stream) {
+    Problem q = make_problem(x, ldx, qweight, scales, qzeros, g_idx, bias, y, ldy, M, K, N, bits, groupsize, nullptr, 0);
+    if (int rc = validate(q)) return rc;
+    GemvParams p;
+    fill_params(q, 0, M, p);
+    return gemm_dispatch(bits, false, p, (hipStream_t)stream);
+}
+
+int gptq_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweight_gate, const void *scales_gate,
+                       const int32_t *qzeros_gate, const int32_t *g_idx_gate, const int32_t *qweight_up,
+                       const void *scales_up, const int32_t *qzeros_up, const int32_t *g_idx_up, void *c, int64_t ldc,
+                       int M, int K, int N, int bits, int groupsize, void *workspace, size_t workspace_bytes,
+                       gptq_stream_t stream) {
+    Problem q = make_problem(x, ldx, qweight_gate, scales_gate, qzeros_gate, g_idx_gate, nullptr, c, ldc, M, K, N, bits,
+                             groupsize, workspace, workspace_bytes);
+    q.fused2 = true;
+    q.qw[1] = qweight_up;
+    q.sc[1] = scales_up;
+    q.qz[1] = qzeros_up;
+    q.gi[1] = g_idx_up;
+    if (int rc = validate(q)) return rc;
+    return run_auto(q, (hipStream_t)stream);
+}
+
+int gptq_transpose_matmul248_f16(const void *dy, int64_t lddy, const int32_t *qweight, const void *scales,
+                                 const int32_t *qzeros, const int32_t *g_idx, void *dx, int64_t lddx, int M, int K,
+                                 int N, int bits, int groupsize, gptq_stream_t stream) {
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0) return GPTQ_E_SHAPE;
+    if (!dy || !dx || !qweight || !scales || !qzeros) return GPTQ_E_NULL;
+    if (!aligned(dy, 16) || lddy % 8 != 0 || !aligned(dx, 16) || lddx % 8 != 0 || !aligned(qweight, 16)) return GPTQ_E_ALIGN;
+    if (M == 0) return 0;
+    return transpose_dispatch(bits, (const half_t *)dy, lddy, (const uint32_t *)qweight, (const half_t *)scales, qzeros,
+                              g_idx, (half_t *)dx, lddx, M, K, N, n_groups(K, groupsize), groupsize, (hipStream_t)stream);
+}
+
+int gptq_rmsnorm_f16(const void *x, int64_t ldx, const void *weight, void *y, int64_t ldy, int M, int N, float eps,
+                     gptq_stream_t stream) {
+    if (!x || !weight || !y) return GPTQ_E_NULL;
+    if (M < 0 || N <= 0) return GPTQ_E_SHAPE;
+    if ((size_t)N * 2 > 65536) return GPTQ_E_NORM_WIDTH;
+    return rmsnorm_launch((const half_t *)x, ldx, (const half_t *)weight, (half_t *)y, ldy, M, N, eps, (hipStream_t)stream);
+}
+
+int gptq_rope_f16(void *qk, int64_t row_stride, const int64_t *position_ids, int64_t pos_batch_stride, int bsz, int seq,
+                  int heads, int head_dim, float base, gptq_stream_t stream) {
+    if (!qk || !position_ids) return GPTQ_E_NULL;
+    if (bsz < 0 || seq < 0 || heads <= 0 || head_dim <= 0 || head_dim % 2 != 0) return GPTQ_E_SHAPE;
+    return rope_launch((half_t *)qk, row_stride, position_ids, pos_batch_stride, bsz, seq, heads, head_dim, base,
+                       (hipStream_t)stream);
+}
+
+int gptq_pack_f32(const float *weight, const float *scales, const float *zeros, const int32_t *g_idx, int K, int N,
+                  int bits, int groupsize, int32_t *qweight, int32_t *qzeros, void *scales_f16, gptq_stream_t stream) {
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0) return GPTQ_E_SHAPE;
+    if (!weight || !scales || !zeros || !qweight || !qzeros || !scales_f16) return GPTQ_E_NULL;
+    return pack_launch(weight, scales, zeros, g_idx, K, N, n_groups(K, groupsize), bits, groupsize, qweight, qzeros,
+                       (half_t *)scales_f16, (hipStream_t)stream);
+}
+
+int gptq_g_idx_is_trivial(const int32_t *g_idx, int K, int groupsize, int32_t *out, gptq_stream_t stream) {
+    if (!g_idx || !out) return GPTQ_E_NULL;
+    if (K <= 0 || groupsize <= 0) return GPTQ_E_SHAPE;
+    return gidx_trivial_launch(g_idx, K, groupsize, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,273 @@
+// elementwise.hip -- the small fused LLaMA ops around QuantLinear, as plain HIP for gfx950:
+//   rmsnorm   reference quant/triton_norm.py:7-39  (rms_norm_fwd_fused)
+//   rope      reference quant/fused_attn.py:8-58,91 (rotate_half_kernel)
+//   pack      reference quant/quant_linear.py:325-371 (QuantLinear.pack, CPU upstream)
+//   g_idx triviality check (load-time helper, no reference counterpart)
+// All are bandwidth/latency bound: 16-byte vector accesses, wave shuffles + one LDS hop.
+#include "gptq_device.h"
+#include "gptq_internal.h"
+
+namespace gptq {
+
+// ------------------------------------------------------------------------------ RMSNorm
+// One workgroup per row; the row stays in registers between the two passes.
+template <int VPT>
+__global__ void __launch_bounds__(256) rmsnorm_kernel(const half_t *__restrict__ x, int64_t ldx,
+                                                      const half_t *__restrict__ w, half_t *__restrict__ y,
+                                                      int64_t ldy, int N, float eps) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const half_t *xr = x + (size_t)row * ldx;
+    half8_t v[VPT];
+    float ss = 0.f;
+    const int nv = N / 8;
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+        const int c = tid + i * 256;
+        v[i] = (half8_t)(half_t)0;
+        if (c < nv) v[i] = *(const half8_t *)(xr + (size_t)c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float f = (float)v[i][j];
+            ss += f * f;
+        }
+    }
+    ss = wave_sum_xor(ss, 1);
+    __shared__ float part[4];
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    const float var = (part[0] + part[1] + part[2] + part[3]) / (float)N;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    half_t *yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+        const int c = tid + i * 256;
+        if (c < nv) {
+            const half8_t wv = *(const half8_t *)(w + (size_t)c * 8);
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (half_t)((float)v[i][j] * rstd * (float)wv[j]);
+            *(half8_t *)(yr + (size_t)c * 8) = o;
+        }
+    }
+}
+
+// any N / alignment: two passes over global memory like the reference kernel.
+__global__ void __launch_bounds__(256) rmsnorm_scalar_kernel(const half_t *__restrict__ x, int64_t ldx,
+                                                             const half_t *__restrict__ w, half_t *__restrict__ y,
+                                                             int64_t ldy, int N, float eps) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const half_t *xr = x + (size_t)row * ldx;
+    float ss = 0.f;
+    for (int c = tid; c < N; c += 256) {
+        const float f = (float)xr[c];
+        ss += f * f;
+    }
+    ss = wave_sum_xor(ss, 1);
+    __shared__ float part[4];
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    const float var = (part[0] + part[1] + part[2] + part[3]) / (float)N;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    half_t *yr = y + (size_t)row * ldy;
+    for (int c = tid; c < N; c += 256) yr[c] = (half_t)((float)xr[c] * rstd * (float)w[c]);
+}
+
+int rmsnorm_launch(const half_t *x, int64_t ldx, const half_t *w, half_t *y, int64_t ldy, int M, int N,
+                   float eps, hipStream_t s) {
+    if (M == 0) return 0;
+    const bool vec = (N % 8 == 0) && (ldx % 8 == 0) && (ldy % 8 == 0) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w) % 16 == 0);
+    dim3 grid(M), block(256);
+    const int nv = N / 8;
+    if (!vec || nv > 16 * 256) {
+        hipLaunchKernelGGL(rmsnorm_scalar_kernel, grid, block, 0, s, x, ldx, w, y, ldy, N, eps);
+    } else if (nv <= 256) {
+        hipLaunchKernelGGL(rmsnorm_kernel<1>, grid, block, 0, s, x, ldx, w, y, ldy, N, eps);
+    } else if (nv <= 512) {
+        hipLaunchKernelGGL(rmsnorm_kernel<2>, grid, block, 0, s, x, ldx, w, y, ldy, N, eps);
+    } else if (nv <= 1024) {
+        hipLaunchKernelGGL(rmsnorm_kernel<4>, grid, block, 0, s, x, ldx, w, y, ldy, N, eps);
+    } else if (nv <= 2048) {
+        hipLaunchKernelGGL(rmsnorm_kernel<8>, grid, block, 0, s, x, ldx, w, y, ldy, N, eps);
+    } else {
+        hipLaunchKernelGGL(rmsnorm_kernel<16>, grid, block, 0, s, x, ldx, w, y, ldy, N, eps);
+    }
+    return (int)hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------- RoPE
+// One workgroup per (batch, position) row.  A thread owns VW adjacent rotary columns: it
+// computes their cos/sin once (fp32, accurate expf/cosf/sinf like the reference's libdevice
+// calls) and walks over the 2*heads head slots of q and k.
+template <int VW>
+__global__ void __launch_bounds__(256) rope_kernel(half_t *qk, int64_t row_stride, const int64_t *pos,
+                                                   int64_t pos_batch_stride, int seq, int nheads2, int head_dim,
+                                                   float inv_base) {
+    typedef half_t vec_t __attribute__((ext_vector_type(VW)));
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int half = head_dim / 2;
+    const int cv = half / VW;           // column vectors per head
+    const int hstep = 256 / cv;         // heads processed per pass (cv <= 256 checked on host)
+    const int c = (tid % cv) * VW, h0 = tid / cv;
+    if (h0 >= hstep) return;
+    const int b = row / seq, t = row % seq;
+    const float p = (float)pos[(size_t)b * pos_batch_stride + t];
+    float cs[VW], sn[VW];
+#pragma unroll
+    for (int j = 0; j < VW; j++) {
+        const float freq = expf((float)(c + j) * inv_base) * p;
+        cs[j] = cosf(freq);
+        sn[j] = sinf(freq);
+    }
+    half_t *base = qk + (size_t)row * row_stride + c;
+    for (int h = h0; h < nheads2; h += hstep) {
+        half_t *px = base + (size_t)h * head_dim;
+        vec_t xv = *(const vec_t *)px, yv = *(const vec_t *)(px + half), ox, oy;
+#pragma unroll
+        for (int j = 0; j < VW; j++) {
+            const float xf = (float)xv[j], yf = (float)yv[j];
+            ox[j] = (half_t)(xf * cs[j] - yf * sn[j]);
+            oy[j] = (half_t)(xf * sn[j] + yf * cs[j]);
+        }
+        *(vec_t *)px = ox;
+        *(vec_t *)(px + half) = oy;
+    }
+}
+
+int rope_launch(half_t *qk, int64_t row_stride, const int64_t *pos, int64_t pos_batch_stride, int bsz, int seq,
+                int heads, int head_dim, float base, hipStream_t s) {
+    const int rows = bsz * seq;
+    if (rows == 0) return 0;
+    const int half = head_dim / 2;
+    const float inv_base = -2.0f * logf(base) / (float)head_dim;
+    dim3 grid(rows), block(256);
+    const bool a16 = ((uintptr_t)qk % 16 == 0) && (row_stride % 8 == 0);
+    if (half % 8 == 0 && a16 && half / 8 <= 256) {
+        hipLaunchKernelGGL(rope_kernel<8>, grid, block, 0, s, qk, row_stride, pos, pos_batch_stride, seq, 2 * heads,
+                           head_dim, inv_base);
+    } else if (half % 2 == 0 && ((uintptr_t)qk % 4 == 0) && (row_stride % 2 == 0) && half / 2 <= 256) {
+        hipLaunchKernelGGL(rope_kernel<2>, grid, block, 0, s, qk, row_stride, pos, pos_batch_stride, seq, 2 * heads,
+                           head_dim, inv_base);
+    } else if (half <= 256) {
+        hipLaunchKernelGGL(rope_kernel<1>, grid, block, 0, s, qk, row_stride, pos, pos_batch_stride, seq, 2 * heads,
+                           head_dim, inv_base);
+    } else {
+        return GPTQ_E_SHAPE;
+    }
+    return (int)hipGetLastError();
+}
+
+// --------------------------------------------------------------------- g_idx triviality
+__global__ void __launch_bounds__(1024) gidx_trivial_kernel(const int32_t *g_idx, int K, int groupsize, int32_t *out) {
+    int ok = 1;
+    for (int k = threadIdx.x; k < K; k += 1024) ok &= (g_idx[k] == k / groupsize);
+    const int all = __syncthreads_and(ok);
+    if (threadIdx.x == 0) *out = all;
+}
+
+int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(gidx_trivial_kernel, dim3(1), dim3(1024), 0, s, g_idx, K, groupsize, out);
+    return (int)hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------- pack
+// Bit-exact restatement of QuantLinear.pack on the GPU.  The float ops are written with
+// explicit round-to-nearest intrinsics so that no FMA contraction changes the rounding:
+//   sz = z * s ; v = (W + sz) / fp16(s) ; iw = (int) rint(v) ; word |= (uint)iw << (bits*j)
+// (the OR is unmasked, exactly like the numpy code; 3-bit fields are masked -- extension).
+template <int BITS>
+__global__ void __launch_bounds__(256) pack_qweight_kernel(const float *__restrict__ weight, const float *__restrict__ scales,
+                                                           const float *__restrict__ zeros, const int32_t *__restrict__ g_idx,
+                                                           int K, int N, int G, int groupsize, uint32_t *__restrict__ qweight) {
+    // workgroup: one 32-k block x 64 columns.  LDS transposes the [n][k] weight tile.
+    __shared__ float tile[64][33];
+    const int blk = blockIdx.x, n_base = blockIdx.y * 64, tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 32; idx += 256) {
+        const int nn = idx / 32, kk = idx % 32;
+        const int n = n_base + nn;
+        tile[nn][kk] = (n < N) ? weight[(size_t)n * K + (size_t)blk * 32 + kk] : 0.f;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    const int n = n_base + tid;
+    if (n >= N) return;
+    uint32_t words[BITS];
+#pragma unroll
+    for (int i = 0; i < BITS; i++) words[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const int k = blk * 32 + j;
+        const int g = g_idx ? g_idx[k] : k / groupsize;
+        const float s = scales[(size_t)n * G + g], z = zeros[(size_t)n * G + g];
+        const float s16 = (float)(half_t)s;
+        const float v = __fdiv_rn(__fadd_rn(tile[tid][j], __fmul_rn(z, s)), s16);
+        const uint32_t u = (uint32_t)(int32_t)rintf(v);
+        if constexpr (BITS == 3) {
+            const int bit = 3 * j, wi = bit >> 5, o = bit & 31;
+            const uint64_t sh = (uint64_t)(u & 7u) << o;
+            words[wi] |= (uint32_t)sh;
+            if (wi < 2) words[wi + 1] |= (uint32_t)(sh >> 32);
+        } else {
+            constexpr int KPW = 32 / BITS;
+            words[j / KPW] |= u << (BITS * (j % KPW));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BITS; i++) qweight[((size_t)blk * BITS + i) * N + n] = words[i];
+}
+
+template <int BITS>
+__global__ void __launch_bounds__(256) pack_qzeros_kernel(const float *__restrict__ scales, const float *__restrict__ zeros,
+                                                          int N, int G, uint32_t *__restrict__ qzeros,
+                                                          half_t *__restrict__ scales16) {
+    // one thread per (g, 32-column block)
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int nb = N / 32;
+    if (idx >= G * nb) return;
+    const int g = idx / nb, b = idx % nb;
+    uint32_t words[BITS];
+#pragma unroll
+    for (int i = 0; i < BITS; i++) words[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const int n = b * 32 + j;
+        scales16[(size_t)g * N + n] = (half_t)scales[(size_t)n * G + g];
+        const float zf = __fadd_rn(zeros[(size_t)n * G + g], -1.0f);
+        const uint32_t u = (uint32_t)(int64_t)zf;  // -1.0 -> 0xFFFFFFFF like numpy's astype(uint32)
+        if constexpr (BITS == 3) {
+            const int bit = 3 * j, wi = bit >> 5, o = bit & 31;
+            const uint64_t sh = (uint64_t)(u & 7u) << o;
+            words[wi] |= (uint32_t)sh;
+            if (wi < 2) words[wi + 1] |= (uint32_t)(sh >> 32);
+        } else {
+            constexpr int KPW = 32 / BITS;
+            words[j / KPW] |= u << (BITS * (j % KPW));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BITS; i++) qzeros[(size_t)g * (nb * BITS) + (size_t)b * BITS + i] = words[i];
+}
+
+template <int BITS>
+static int pack_bits(const float *weight, const float *scales, const float *zeros, const int32_t *g_idx, int K, int N,
+                     int G, int groupsize, int32_t *qweight, int32_t *qzeros, half_t *scales16, hipStream_t s) {
+    dim3 grid(K / 32, (N + 63) / 64);
+    hipLaunchKernelGGL(pack_qweight_kernel<BITS>, grid, dim3(256), 0, s, weight, scales, zeros, g_idx, K, N, G, groupsize,
+                       (uint32_t *)qweight);
+    const int total = G * (N / 32);
+    hipLaunchKernelGGL(pack_qzeros_kernel<BITS>, dim3((total + 255) / 256), dim3(256), 0, s, scales, zeros, N, G,
+                       (uint32_t *)qzeros, scales16);
+    return (int)hipGetLastError();
+}
+
+int pack_launch(const float *weight, const float *scales, const float *zeros, const int32_t *g_idx, int K, int N, int G,
+                int bits, int groupsize, int32_t *qweight, int32_t *qzeros, half_t *scales16, hipStream_t s) {
+    switch (bits) {
+        case 2: return pack_bits<2>(weight, scales, zeros, g_idx, K, N, G, groupsize, qweight, qzeros, scales16, s);
+        case 3: return pack_bits<3>(weight, scales, zeros, g_idx, K, N, G, groupsize, qweight, qzeros, scales16, s);
+        case 4: return pack_bits<4>(weight, scales, zeros, g_idx, K, N, G, groupsize, qweight, qzeros, scales16, s);
+        case 8: return pack_bits<8>(weight, scales, zeros, g_idx, K, N, G, groupsize, qweight, qzeros, scales16, s);
+    }
+    return GPTQ_E_BITS;
+}
+
+}  // namespace gptq

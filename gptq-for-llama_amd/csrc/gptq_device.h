@@ -1,0 +1,125 @@
+// gptq_device.h -- shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define GPTQ_DEV static __device__ __forceinline__
+
+GPTQ_DEV half2_t as_half2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
+GPTQ_DEV uint32_t as_u32(half2_t h) { return __builtin_bit_cast(uint32_t, h); }
+
+// Number of XCDs on MI355X; block b is observed to run on XCD b % 8 (speed only, never
+// correctness).  Bijective remap that hands every XCD a contiguous range of logical ids so
+// neighbouring tiles (which share 128-B lines / x) hit the same L2.
+GPTQ_DEV int xcd_remap(int bid, int nwg) {
+    constexpr int NXCD = 8;
+    if (nwg < 2 * NXCD) return bid;
+    int xcd = bid % NXCD, idx = bid / NXCD;
+    int q = nwg / NXCD, r = nwg % NXCD;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// ---------------------------------------------------------------------------------------
+// Field extraction.  A packed word holds KPW = 32/BITS consecutive k of ONE column.
+// Unpack<BITS>::pairs() turns a word into NP = KPW/2 half2 values t[p] = {OFF + q_p,
+// OFF + q_{p+NP}} using the fp16 "magic exponent" trick: OR-ing the field into the mantissa
+// of a constant whose ulp equals the field's bit weight, so no int->float convert is needed.
+// The constant offset OFF is removed exactly (fp16 subtract) or folded into the zero point.
+// ---------------------------------------------------------------------------------------
+template <int BITS>
+struct Unpack;
+
+template <>
+struct Unpack<4> {
+    static constexpr int KPW = 8, NP = 4;
+    static constexpr float OFF = 64.0f;  // 0x5400 = 64.0, ulp 1/16: field at bits [7:4] -> +q
+    GPTQ_DEV void pairs(uint32_t w, half2_t (&t)[NP]) {
+        constexpr uint32_t MSK = 0x00F000F0u, MAG = 0x54005400u;
+        t[0] = as_half2(((w << 4) & MSK) | MAG);  // fields 0,4
+        t[1] = as_half2((w & MSK) | MAG);          // fields 1,5
+        t[2] = as_half2(((w >> 4) & MSK) | MAG);  // fields 2,6
+        t[3] = as_half2(((w >> 8) & MSK) | MAG);  // fields 3,7
+    }
+};
+
+template <>
+struct Unpack<2> {
+    static constexpr int KPW = 16, NP = 8;
+    static constexpr float OFF = 64.0f;  // field at bits [5:4] of 0x5400 -> +q
+    GPTQ_DEV void pairs(uint32_t w, half2_t (&t)[NP]) {
+        constexpr uint32_t MSK = 0x00300030u, MAG = 0x54005400u;
+        t[0] = as_half2(((w << 4) & MSK) | MAG);   // fields 0,8
+        t[1] = as_half2(((w << 2) & MSK) | MAG);   // 1,9
+        t[2] = as_half2((w & MSK) | MAG);           // 2,10
+        t[3] = as_half2(((w >> 2) & MSK) | MAG);   // 3,11
+        t[4] = as_half2(((w >> 4) & MSK) | MAG);   // 4,12
+        t[5] = as_half2(((w >> 6) & MSK) | MAG);   // 5,13
+        t[6] = as_half2(((w >> 8) & MSK) | MAG);   // 6,14
+        t[7] = as_half2(((w >> 10) & MSK) | MAG);  // 7,15
+    }
+};
+
+template <>
+struct Unpack<8> {
+    static constexpr int KPW = 4, NP = 2;
+    static constexpr float OFF = 256.0f;  // 0x5C00 = 256.0, ulp 1/4: byte at bits [9:2] -> +q
+    GPTQ_DEV void pairs(uint32_t w, half2_t (&t)[NP]) {
+        constexpr uint32_t MSK = 0x03FC03FCu, MAG = 0x5C005C00u;
+        t[0] = as_half2(((w << 2) & MSK) | MAG);  // bytes 0,2
+        t[1] = as_half2(((w >> 6) & MSK) | MAG);  // bytes 1,3
+    }
+};
+
+// Staged-x order for one word-row of KPW values: position 2p <- field p, 2p+1 <- field p+NP.
+template <int BITS>
+GPTQ_DEV int staged_pos(int field) {
+    constexpr int NP = Unpack<BITS>::NP;
+    return (field < NP) ? 2 * field : 2 * (field - NP) + 1;
+}
+
+// Generic integer field j (0..31) of a 32-k block for one column; rows w[0..CH) are the
+// BITS consecutive qweight rows of that block.  Used by the fallback kernels and by 3-bit.
+template <int BITS>
+GPTQ_DEV int field_of_block(const uint32_t *w, int j) {
+    if constexpr (BITS == 3) {
+        int bit = 3 * j, wi = bit >> 5, o = bit & 31;
+        uint64_t lo = w[wi];
+        uint64_t hi = (wi < 2) ? w[wi + 1] : 0;
+        return (int)(((lo | (hi << 32)) >> o) & 7u);
+    } else {
+        constexpr int KPW = 32 / BITS;
+        return (int)((w[j / KPW] >> (BITS * (j % KPW))) & ((1u << BITS) - 1u));
+    }
+}
+
+// zero point (stored + 1, not re-masked) of column n from a qzeros row pointer.
+template <int BITS>
+GPTQ_DEV int zero_of(const int32_t *zrow, int n) {
+    if constexpr (BITS == 3) {
+        const uint32_t *p = (const uint32_t *)zrow + 3 * (n >> 5);
+        int bit = 3 * (n & 31), wi = bit >> 5, o = bit & 31;
+        uint64_t lo = p[wi];
+        uint64_t hi = (wi < 2) ? p[wi + 1] : 0;
+        return (int)(((lo | (hi << 32)) >> o) & 7u) + 1;
+    } else {
+        constexpr int KPW = 32 / BITS;
+        uint32_t w = (uint32_t)zrow[n / KPW];
+        return (int)((w >> (BITS * (n % KPW))) & ((1u << BITS) - 1u)) + 1;
+    }
+}
+
+GPTQ_DEV float wave_sum_xor(float v, int from) {
+#pragma unroll
+    for (int off = from; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}

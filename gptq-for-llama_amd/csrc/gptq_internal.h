@@ -1,0 +1,62 @@
+// gptq_internal.h -- declarations shared by the kernel translation units and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/gptq_mi355x.h"
+#include "gptq_device.h"
+
+namespace gptq {
+
+constexpr int GEMV_MAX_M = 4;         // rows served by the wavefront-reduction GEMV
+constexpr int SKINNY_MAX_M = 64;      // rows served by the weight-streaming MFMA kernel
+constexpr int GEMV_NUM_VARIANTS = 8;
+constexpr int MAX_TILES = 8192;       // arrival counters in the workspace
+// workspace: [2][GEMV_MAX_M][N_max] fp32 partial sums + MAX_TILES counters
+constexpr size_t WS_MAX_N = 65536;
+constexpr size_t WS_SUM_BYTES = 2 * (size_t)SKINNY_MAX_M * WS_MAX_N * 4;
+constexpr size_t WS_BYTES = WS_SUM_BYTES + MAX_TILES * 4;
+
+struct GemvVariant {
+    int nl;     // column lanes per wave (tile = 4*nl columns)
+    int waves;  // waves per workgroup
+};
+extern const GemvVariant g_gemv_variants[GEMV_NUM_VARIANTS];
+
+struct GemvParams {
+    const half_t *x;
+    int64_t ldx;
+    const uint32_t *qw[2];
+    const half_t *sc[2];
+    const int32_t *qz[2];
+    const int32_t *gi[2];
+    const half_t *bias;
+    half_t *y;
+    int64_t ldy;
+    int M, K, N, G, groupsize;
+    int ntiles, split_k, nchunks, chunks_per_slice;
+    float *ws;
+    unsigned *counters;
+};
+
+int gemv_fast_dispatch(int bits, bool fused2, int variant, const GemvParams &p, hipStream_t s);
+int gemv_generic_dispatch(int bits, bool fused2, int nl, const GemvParams &p, hipStream_t s);
+
+// skinny MFMA (weight streaming, M <= 64) and tiled MFMA GEMM (prefill)
+int skinny_dispatch(int bits, bool fused2, const GemvParams &p, hipStream_t s);
+int gemm_dispatch(int bits, bool fused2, const GemvParams &p, hipStream_t s);
+int transpose_dispatch(int bits, const half_t *dy, int64_t lddy, const uint32_t *qw, const half_t *sc,
+                       const int32_t *qz, const int32_t *gi, half_t *dx, int64_t lddx, int M, int K, int N,
+                       int G, int groupsize, hipStream_t s);
+
+int rmsnorm_launch(const half_t *x, int64_t ldx, const half_t *w, half_t *y, int64_t ldy, int M, int N,
+                   float eps, hipStream_t s);
+int rope_launch(half_t *qk, int64_t row_stride, const int64_t *pos, int64_t pos_batch_stride, int bsz,
+                int seq, int heads, int head_dim, float base, hipStream_t s);
+int pack_launch(const float *weight, const float *scales, const float *zeros, const int32_t *g_idx, int K,
+                int N, int G, int bits, int groupsize, int32_t *qweight, int32_t *qzeros, half_t *scales16,
+                hipStream_t s);
+int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
+
+}  // namespace gptq

@@ -1,0 +1,113 @@
+"""ctypes binding of libgptq_mi355x.so (C ABI: include/gptq_mi355x.h).
+
+There is NO CPU fallback and no second backend: if the shared library is missing or a tensor
+is not on a ROCm device the call raises.  PyTorch is only the owner of device memory and
+streams here; every launch goes to ``torch.cuda.current_stream()`` of the input's device, so the
+ops are asynchronous and hipGraph-capturable like the reference's Triton launches
+(reference quant/quant_linear.py:263-269).
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, 'lib', 'libgptq_mi355x.so')
+CSRC_DIR = os.path.join(_PKG, 'csrc')
+
+_lib = None
+_lock = threading.Lock()
+
+c_void_p, c_int, c_int64, c_size_t, c_float = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                                ctypes.c_size_t, ctypes.c_float)
+
+# name -> argtypes; mirrors include/gptq_mi355x.h one to one
+_SIGNATURES = {
+    'gptq_query': [c_int],
+    'gptq_set_gemv_variant': [c_int],
+    'gptq_set_split_k': [c_int],
+    'gptq_matmul248_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                           c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
+    'gptq_gemv_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                      c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
+    'gptq_skinny_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                        c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
+    'gptq_gemm_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                      c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'gptq_fused_mlp_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
+                           c_void_p, c_size_t, c_void_p],
+    'gptq_transpose_matmul248_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'gptq_rmsnorm_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p],
+    'gptq_rope_f16': [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    'gptq_pack_f32': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                      c_void_p, c_void_p, c_void_p],
+    'gptq_g_idx_is_trivial': [c_void_p, c_int, c_int, c_void_p, c_void_p],
+}
+EXPORTS = sorted(list(_SIGNATURES) + ['gptq_strerror'])
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libgptq_mi355x.so once.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeLibraryMissing(
+                    'libgptq_mi355x.so not found at %s -- build it with `make -C %s` (or '
+                    '__graft_entry__.build()); there is no CPU/Triton fallback.' % (LIB_PATH, CSRC_DIR))
+            L = ctypes.CDLL(LIB_PATH)
+            for name, args in _SIGNATURES.items():
+                fn = getattr(L, name)
+                fn.argtypes = args
+                fn.restype = c_int
+            L.gptq_strerror.argtypes = [c_int]
+            L.gptq_strerror.restype = ctypes.c_char_p
+            _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    msg = lib().gptq_strerror(rc).decode()
+    if rc == -1:
+        raise NotImplementedError(msg)          # reference quant_linear.py:309
+    if rc == -7:
+        raise RuntimeError(msg)                 # reference triton_norm.py:60
+    raise RuntimeError('%s failed (%d): %s' % (what, rc, msg))
+
+
+def require_device(t, what):
+    if not t.is_cuda:
+        raise RuntimeError('%s: tensor is on %s -- the MI355X HIP path has no CPU fallback' % (what, t.device))
+
+
+def stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_workspaces = {}
+
+
+def workspace(device):
+    """Per-device zero-initialised scratch for the split-K kernels (they restore it to zero)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None:
+        nbytes = lib().gptq_query(3)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,303 @@
+"""MI355X-native ``QuantLinear``: drop-in for the reference ``quant/quant_linear.py``.
+
+Same module surface and checkpoint format as the reference --
+``QuantLinear(bits, groupsize, infeatures, outfeatures, bias)`` with buffers
+``qweight / qzeros / scales / g_idx [/ bias]`` (reference quant/quant_linear.py:306-323), ``pack``
+(:325-371), ``forward`` (:373-377), ``matmul248`` / ``transpose_matmul248`` (:263-279),
+``QuantLinearFunction`` (:282-301), ``make_quant_linear`` (:380-390) and
+``autotune_warmup_linear`` (:393-423) -- but the device code is hand-written HIP for gfx950
+behind the C ABI in ``include/gptq_mi355x.h`` (no Triton, no autotuner: a static shape ->
+kernel table, see csrc/capi.hip).  There is no CPU forward: a CPU tensor raises.
+
+Extension over the reference: ``bits == 3`` is accepted (dense 96-bit stream layout, see the
+header); the reference raises NotImplementedError for it (:308-309).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _native
+
+SUPPORTED_BITS = (2, 3, 4, 8)
+
+
+# ----------------------------------------------------------------------------------------------
+# g_idx bookkeeping: the fast kernels want to know whether g_idx is the trivial k // groupsize map
+# (always true unless the checkpoint was quantised with --act-order, reference gptq.py:210-216).
+# One device-side check per (buffer, version), cached; done during warm-up / first forward.
+# ----------------------------------------------------------------------------------------------
+_gidx_cache = {}
+
+
+def _infer_groupsize(K, G):
+    return K if G <= 1 else -(-K // G)
+
+
+def g_idx_is_trivial(g_idx, K, groupsize):
+    key = (g_idx.data_ptr(), g_idx._version, str(g_idx.device), K, groupsize)
+    hit = _gidx_cache.get(key)
+    if hit is not None:
+        return hit
+    g = g_idx[:K]
+    if g.is_cuda:
+        out = torch.empty(1, dtype=torch.int32, device=g.device)
+        gi = g if g.dtype == torch.int32 and g.is_contiguous() else g.to(torch.int32).contiguous()
+        rc = _native.lib().gptq_g_idx_is_trivial(gi.data_ptr(), K, groupsize, out.data_ptr(),
+                                                 _native.stream_ptr(g.device))
+        _native.check(rc, 'gptq_g_idx_is_trivial')
+        res = bool(out.item())
+    else:
+        res = bool(torch.equal(g.to(torch.int64), torch.arange(K, dtype=torch.int64) // groupsize))
+    if len(_gidx_cache) > 4096:
+        _gidx_cache.clear()
+    _gidx_cache[key] = res
+    return res
+
+
+def _as_rows(t):
+    """2-D fp16 view whose last dim is contiguous and whose rows are 16-byte aligned."""
+    if t.dtype != torch.float16:
+        t = t.half()
+    if t.stride(-1) != 1 or (t.shape[0] > 1 and t.stride(0) % 8 != 0) or t.data_ptr() % 16 != 0:
+        t = t.contiguous()
+        if t.data_ptr() % 16 != 0:
+            t = t.clone()
+    return t
+
+
+def _int32c(t):
+    return t if (t.dtype == torch.int32 and t.is_contiguous()) else t.to(torch.int32).contiguous()
+
+
+def _prep_weight(input, qweight, scales, qzeros, g_idx, bits):
+    _native.require_device(input, 'matmul248')
+    if bits not in SUPPORTED_BITS:
+        raise NotImplementedError('Only 2,3,4,8 bits are supported.')
+    K = qweight.shape[0] * 32 // bits
+    N = qweight.shape[1]
+    G = scales.shape[0]
+    groupsize = _infer_groupsize(K, G)
+    qweight, qzeros = _int32c(qweight), _int32c(qzeros)
+    scales = scales if (scales.dtype == torch.float16 and scales.is_contiguous()) else scales.half().contiguous()
+    gi = None
+    if g_idx is not None and not g_idx_is_trivial(g_idx, K, groupsize):
+        gi = _int32c(g_idx[:K])
+    return K, N, groupsize, qweight, scales, qzeros, gi
+
+
+def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None):
+    """``input [M,K] fp16 -> [M,N] fp16`` on the current stream of ``input.device``
+    (reference matmul248, quant/quant_linear.py:263-269; ``bias`` is an extension that fuses
+    the add of QuantLinear.forward, :376)."""
+    K, N, groupsize, qweight, scales, qzeros, gi = _prep_weight(input, qweight, scales, qzeros, g_idx, bits)
+    x = _as_rows(input)
+    if x.shape[1] != K:
+        raise RuntimeError('matmul248: input has %d features, weight expects %d' % (x.shape[1], K))
+    M = x.shape[0]
+    with torch.cuda.device(x.device):
+        out = torch.empty((M, N), device=x.device, dtype=torch.float16)
+        if M == 0:
+            return out
+        ws = _native.workspace(x.device)
+        rc = _native.lib().gptq_matmul248_f16(
+            x.data_ptr(), x.stride(0) if M > 1 else K, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
+            _native.ptr(gi), _native.ptr(bias), out.data_ptr(), N, M, K, N, bits, groupsize,
+            ws.data_ptr(), ws.numel(), _native.stream_ptr(x.device))
+    _native.check(rc, 'gptq_matmul248_f16')
+    return out
+
+
+def transpose_matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq):
+    """``input [M,N] fp16 -> [M,K] fp16`` = input . deq(B)^T (reference transpose_matmul248,
+    quant/quant_linear.py:272-279)."""
+    K, N, groupsize, qweight, scales, qzeros, gi = _prep_weight(input, qweight, scales, qzeros, g_idx, bits)
+    dy = _as_rows(input)
+    M = dy.shape[0]
+    with torch.cuda.device(dy.device):
+        out = torch.empty((M, K), device=dy.device, dtype=torch.float16)
+        if M == 0:
+            return out
+        rc = _native.lib().gptq_transpose_matmul248_f16(
+            dy.data_ptr(), dy.stride(0) if M > 1 else N, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
+            _native.ptr(gi), out.data_ptr(), K, M, K, N, bits, groupsize, _native.stream_ptr(dy.device))
+    _native.check(rc, 'gptq_transpose_matmul248_f16')
+    return out
+
+
+class QuantLinearFunction(torch.autograd.Function):
+    """autograd wrapper (reference quant/quant_linear.py:282-301): forward = matmul248,
+    backward = transpose_matmul248 for grad_input only (the packed weight is frozen)."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float16)
+    def forward(ctx, input, qweight, scales, qzeros, g_idx, bits, maxq):
+        output = matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq)
+        ctx.save_for_backward(qweight, scales, qzeros, g_idx)
+        ctx.bits, ctx.maxq = bits, maxq
+        return output
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, grad_output):
+        qweight, scales, qzeros, g_idx = ctx.saved_tensors
+        grad_input = None
+        if ctx.needs_input_grad[0]:
+            grad_input = transpose_matmul248(grad_output, qweight, scales, qzeros, g_idx, ctx.bits, ctx.maxq)
+        return grad_input, None, None, None, None, None, None
+
+
+def _pack_fields(fields_u32, bits, axis_rows=True):
+    """fields [R*f, C] uint32 (unmasked, as the reference ORs them) -> words [R*bits/…, C]."""
+    a = fields_u32 if axis_rows else fields_u32.T
+    total, C = a.shape
+    if bits == 3:
+        blk = a.reshape(total // 32, 32, C).astype(np.uint64) & np.uint64(7)
+        out = np.zeros((total // 32, 3, C), dtype=np.uint64)
+        for j in range(32):
+            bit = 3 * j
+            w, o = bit // 32, bit % 32
+            out[:, w] |= (blk[:, j] << np.uint64(o)) & np.uint64(0xFFFFFFFF)
+            if o + 3 > 32:
+                out[:, w + 1] |= blk[:, j] >> np.uint64(32 - o)
+        words = out.astype(np.uint32).reshape(total // 32 * 3, C)
+    else:
+        f = 32 // bits
+        words = np.zeros((total // f, C), dtype=np.uint32)
+        grouped = a.reshape(total // f, f, C)
+        for j in range(f):
+            words |= grouped[:, j] << np.uint32(bits * j)
+    words = words if axis_rows else np.ascontiguousarray(words.T)
+    return words.view(np.int32)
+
+
+class QuantLinear(nn.Module):
+
+    def __init__(self, bits, groupsize, infeatures, outfeatures, bias):
+        super().__init__()
+        if bits not in SUPPORTED_BITS:
+            raise NotImplementedError('Only 2,3,4,8 bits are supported.')
+        self.infeatures = infeatures
+        self.outfeatures = outfeatures
+        self.bits = bits
+        self.maxq = 2**self.bits - 1
+        self.groupsize = groupsize if groupsize != -1 else infeatures
+        groups = math.ceil(infeatures / self.groupsize)
+
+        self.register_buffer('qweight', torch.zeros((infeatures // 32 * self.bits, outfeatures), dtype=torch.int32))
+        self.register_buffer('qzeros', torch.zeros((groups, outfeatures // 32 * self.bits), dtype=torch.int32))
+        self.register_buffer('scales', torch.zeros((groups, outfeatures), dtype=torch.float16))
+        self.register_buffer('g_idx', (torch.arange(infeatures, dtype=torch.int64) // self.groupsize).to(torch.int32))
+        if bias:
+            self.register_buffer('bias', torch.zeros((outfeatures), dtype=torch.float16))
+        else:
+            self.bias = None
+
+    # ------------------------------------------------------------------------------------ pack
+    def pack(self, linear, scales, zeros, g_idx=None):
+        """Pack a grid-valued ``nn.Linear`` (``scales``/``zeros`` are ``[N, G]`` as produced by
+        gptq.py:226-228).  Same arithmetic and bit layout as the reference packer
+        (quant/quant_linear.py:325-371) -- incl. the division by the fp16-rounded scale, the
+        unmasked OR and ``zeros - 1`` -- vectorised on the host, or on the GPU
+        (``gptq_pack_f32``) when the layer lives there."""
+        self.g_idx = g_idx.clone() if g_idx is not None else self.g_idx
+        W = linear.weight.data
+        if linear.bias is not None:
+            self.bias = linear.bias.clone().half()
+        if W.is_cuda:
+            return self._pack_gpu(W, scales, zeros)
+
+        K, N, bits = self.infeatures, self.outfeatures, self.bits
+        g = self.g_idx.to(torch.int64).cpu()
+        st = scales.t().contiguous().float().cpu()              # [G, N]
+        zt = zeros.t().contiguous().float().cpu()
+        sz = zt * st
+        s16 = st.clone().half()
+        self.scales = s16
+        v = (W.float().cpu().t() + sz[g]) / s16[g]               # fp32 / fp16 -> fp32, like the reference
+        intweight = torch.round(v).to(torch.int32).numpy().astype(np.uint32)   # [K, N]
+        self.qweight = torch.from_numpy(_pack_fields(intweight, bits, axis_rows=True).copy())
+        zi = (zt - 1).numpy().astype(np.int64).astype(np.uint32)               # -1.0 -> 0xFFFFFFFF
+        self.qzeros = torch.from_numpy(_pack_fields(zi, bits, axis_rows=False).copy())
+
+    def _pack_gpu(self, W, scales, zeros):
+        K, N, bits = self.infeatures, self.outfeatures, self.bits
+        dev = W.device
+        G = math.ceil(K / self.groupsize)
+        Wf = W.float().contiguous()
+        sc = scales.to(dev).float().reshape(N, G).contiguous()
+        zr = zeros.to(dev).float().reshape(N, G).contiguous()
+        gi = _int32c(self.g_idx.to(dev))
+        with torch.cuda.device(dev):
+            qweight = torch.empty((K // 32 * bits, N), dtype=torch.int32, device=dev)
+            qzeros = torch.empty((G, N // 32 * bits), dtype=torch.int32, device=dev)
+            s16 = torch.empty((G, N), dtype=torch.float16, device=dev)
+            rc = _native.lib().gptq_pack_f32(Wf.data_ptr(), sc.data_ptr(), zr.data_ptr(), gi.data_ptr(), K, N, bits,
+                                             self.groupsize, qweight.data_ptr(), qzeros.data_ptr(), s16.data_ptr(),
+                                             _native.stream_ptr(dev))
+        _native.check(rc, 'gptq_pack_f32')
+        self.qweight, self.qzeros, self.scales = qweight, qzeros, s16
+        self.g_idx = gi
+
+    # --------------------------------------------------------------------------------- forward
+    def forward(self, x):
+        out_shape = x.shape[:-1] + (self.outfeatures, )
+        x2 = x.reshape(-1, x.shape[-1])
+        if torch.is_grad_enabled() and x2.requires_grad:
+            out = QuantLinearFunction.apply(x2, self.qweight, self.scales, self.qzeros, self.g_idx, self.bits, self.maxq)
+            out = out + self.bias if self.bias is not None else out
+        else:
+            # inference: bias add fused into the kernel epilogue (same rounding order as the
+            # reference's separate add: fp16(fp16(acc) + bias))
+            out = matmul248(x2, self.qweight, self.scales, self.qzeros, self.g_idx, self.bits, self.maxq, bias=self.bias)
+        return out.reshape(out_shape)
+
+
+def make_quant_linear(module, names, bits, groupsize, name=''):
+    """Replace every ``nn.Linear`` whose qualified name is in ``names`` by a ``QuantLinear``
+    (reference quant/quant_linear.py:380-390)."""
+    if isinstance(module, QuantLinear):
+        return
+    for attr in dir(module):
+        tmp = getattr(module, attr)
+        name1 = name + '.' + attr if name != '' else attr
+        if name1 in names:
+            delattr(module, attr)
+            setattr(module, attr, QuantLinear(bits, groupsize, tmp.in_features, tmp.out_features, tmp.bias is not None))
+    for name1, child in module.named_children():
+        make_quant_linear(child, names, bits, groupsize, name + '.' + name1 if name != '' else name1)
+
+
+def autotune_warmup_linear(model, transpose=False):
+    """Same call surface as the reference warm-up (quant/quant_linear.py:393-423).  There is no
+    autotuner to train: kernels are picked from a static shape table.  The warm-up still walks
+    every unique (K, N) at M = 1 .. 2048 so that the g_idx triviality checks, the workspace and
+    the kernels' code objects are resident before the first timed token."""
+    from tqdm import tqdm
+
+    kn_values = {}
+    for _, m in model.named_modules():
+        if not isinstance(m, QuantLinear):
+            continue
+        k, n = m.infeatures, m.outfeatures
+        if (k, n) not in kn_values:
+            kn_values[(k, n)] = (m.qweight.cuda(), m.scales.cuda(), m.qzeros.cuda(), m.g_idx.cuda(), m.bits, m.maxq)
+
+    print(f'Found {len(kn_values)} unique KN Linear values.')
+    print('Warming up autotune cache ...')
+    with torch.no_grad():
+        for m in tqdm(range(0, 12)):
+            m = 2**m  # [1, 2048]
+            for (k, n), (qweight, scales, qzeros, g_idx, bits, maxq) in kn_values.items():
+                a = torch.randn(m, k, dtype=torch.float16, device='cuda')
+                matmul248(a, qweight, scales, qzeros, g_idx, bits, maxq)
+                if transpose:
+                    a = torch.randn(m, n, dtype=torch.float16, device='cuda')
+                    transpose_matmul248(a, qweight, scales, qzeros, g_idx, bits, maxq)
+    del kn_values
+
+
+# old-cuda-branch spellings used by BASELINE.json's north_star
+make_quant = make_quant_linear
+autotune_warmup = autotune_warmup_linear

@@ -1,0 +1,154 @@
+/*
+ * gptq_mi355x.h -- C ABI of libgptq_mi355x.so: the MI355X (gfx950) native hot path behind
+ * GPTQ-for-LLaMa's `quant.QuantLinear` operator family.
+ *
+ * Every entry point is what a binding of the reference's operator interface for this path
+ * would call; the reference symbol each one stands in for is cited as
+ * `file:line` into qwopqwop200/GPTQ-for-LLaMa (triton branch).  There are no torch types in
+ * the signatures: plain device pointers, sizes, a HIP stream.  The caller owns every buffer;
+ * the library allocates nothing, never synchronises and never throws -- all launches go to
+ * `stream` and are hipGraph-capturable.
+ *
+ * Buffer conventions (identical to the reference checkpoint format, quant_linear.py:316-321):
+ *   x        fp16 [M, K]      row stride ldx (elements), last dim contiguous
+ *   qweight  int32 [K/32*bits, N]  row-major; bits in {2,4,8}: word r holds k = r*f .. r*f+f-1
+ *            (f = 32/bits) of one column, field j at bit bits*j (quant_linear.py:103,109,127).
+ *            bits == 3 (EXTENSION, the reference raises NotImplementedError,
+ *            quant_linear.py:308-309): 32 consecutive k of a column are a dense little-endian
+ *            96-bit stream over 3 consecutive rows.
+ *   qzeros   int32 [G, N/32*bits]   same packing along n; stored value is zero-1 and the
+ *            kernel adds 1 WITHOUT re-masking (quant_linear.py:120-121)
+ *   scales   fp16 [G, N]
+ *   g_idx    int32 [K] group of each k, or NULL meaning the trivial map k / groupsize
+ *   bias     fp16 [N] or NULL; added after the fp16 rounding of the product
+ *            (separate torch add in the reference, quant_linear.py:376)
+ *   y        fp16 [M, N]      row stride ldy
+ *   G = ceil(K / groupsize); groupsize == K for the reference's "-1".
+ *
+ * Return value: 0 on success; negative = GPTQ_E_* (bad argument, nothing launched);
+ * positive = hipError_t from a launch.
+ */
+#ifndef GPTQ_MI355X_H
+#define GPTQ_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *gptq_stream_t; /* hipStream_t */
+
+enum {
+    GPTQ_OK = 0,
+    GPTQ_E_BITS = -1,      /* bits not in {2,3,4,8}             (quant_linear.py:308-309)  */
+    GPTQ_E_SHAPE = -2,     /* K or N not a multiple of 32, M < 0, groupsize <= 0            */
+    GPTQ_E_ALIGN = -3,     /* pointer / leading dimension alignment                          */
+    GPTQ_E_NULL = -4,      /* required pointer is NULL                                       */
+    GPTQ_E_WORKSPACE = -5, /* workspace too small for the requested variant                  */
+    GPTQ_E_VARIANT = -6,   /* unknown / inapplicable kernel variant                          */
+    GPTQ_E_NORM_WIDTH = -7 /* RMSNorm row wider than 64 KiB (triton_norm.py:59-60)           */
+};
+
+/* gptq_query(what) */
+enum {
+    GPTQ_Q_ABI_VERSION = 0,
+    GPTQ_Q_GEMV_MAX_M = 1,        /* largest M served by the wavefront-reduction GEMV        */
+    GPTQ_Q_SKINNY_MAX_M = 2,      /* largest M served by the weight-streaming MFMA kernel    */
+    GPTQ_Q_WORKSPACE_BYTES = 3,   /* bytes of zero-initialised workspace split-K needs       */
+    GPTQ_Q_NUM_GEMV_VARIANTS = 4
+};
+
+int gptq_query(int what);
+const char *gptq_strerror(int code);
+
+/* Dispatch override used by autotune_warmup_* and the benchmarks: variant < 0 restores the
+ * built-in shape table.  Returns the previous value. */
+int gptq_set_gemv_variant(int variant);
+int gptq_set_split_k(int split_k);
+
+/*
+ * y = x . deq(B) (+ bias)  -- reference matmul248() + matmul_248_kernel + the bias add in
+ * QuantLinear.forward (quant/quant_linear.py:263-269, :72-137, :373-377).
+ * Chooses the GEMV (M small), the weight-streaming MFMA kernel (M <= 64) or the tiled MFMA
+ * GEMM (prefill).  workspace: >= gptq_query(GPTQ_Q_WORKSPACE_BYTES) bytes, zero on first use
+ * (the kernels restore it to zero); may be NULL, which disables split-K variants.
+ */
+int gptq_matmul248_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales,
+                       const int32_t *qzeros, const int32_t *g_idx, const void *bias, void *y,
+                       int64_t ldy, int M, int K, int N, int bits, int groupsize, void *workspace,
+                       size_t workspace_bytes, gptq_stream_t stream);
+
+/* Same contract, forcing one kernel family (tests and benchmarks). */
+int gptq_gemv_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales,
+                  const int32_t *qzeros, const int32_t *g_idx, const void *bias, void *y,
+                  int64_t ldy, int M, int K, int N, int bits, int groupsize, void *workspace,
+                  size_t workspace_bytes, gptq_stream_t stream);
+int gptq_skinny_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales,
+                    const int32_t *qzeros, const int32_t *g_idx, const void *bias, void *y,
+                    int64_t ldy, int M, int K, int N, int bits, int groupsize, void *workspace,
+                    size_t workspace_bytes, gptq_stream_t stream);
+int gptq_gemm_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales,
+                  const int32_t *qzeros, const int32_t *g_idx, const void *bias, void *y,
+                  int64_t ldy, int M, int K, int N, int bits, int groupsize, gptq_stream_t stream);
+
+/*
+ * c = silu(x . deq(B_gate)) * (x . deq(B_up))  -- reference QuantLlamaMLP.triton_llama_mlp +
+ * fusedmatmul_248_kernel (quant/fused_mlp.py:206-218, :84-168).  Both weight sets share
+ * K, N, bits, groupsize; each has its own scales / qzeros / g_idx.
+ */
+int gptq_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweight_gate,
+                       const void *scales_gate, const int32_t *qzeros_gate,
+                       const int32_t *g_idx_gate, const int32_t *qweight_up, const void *scales_up,
+                       const int32_t *qzeros_up, const int32_t *g_idx_up, void *c, int64_t ldc,
+                       int M, int K, int N, int bits, int groupsize, void *workspace,
+                       size_t workspace_bytes, gptq_stream_t stream);
+
+/*
+ * dx[M,K] = dy[M,N] . deq(B)^T -- reference transpose_matmul248() +
+ * transpose_matmul_248_kernel (quant/quant_linear.py:272-279, :191-258); the backward of
+ * QuantLinearFunction (:294-301).
+ */
+int gptq_transpose_matmul248_f16(const void *dy, int64_t lddy, const int32_t *qweight,
+                                 const void *scales, const int32_t *qzeros, const int32_t *g_idx,
+                                 void *dx, int64_t lddx, int M, int K, int N, int bits,
+                                 int groupsize, gptq_stream_t stream);
+
+/*
+ * y = x * rsqrt(mean(x^2) + eps) * w, fp32 math, one rounding to fp16 -- reference
+ * TritonLlamaRMSNorm.forward + rms_norm_fwd_fused (quant/triton_norm.py:50-67, :7-39).
+ * Rows wider than 64 KiB are rejected like the reference (:59-60).
+ */
+int gptq_rmsnorm_f16(const void *x, int64_t ldx, const void *weight, void *y, int64_t ldy, int M,
+                     int N, float eps, gptq_stream_t stream);
+
+/*
+ * In-place rotate-half RoPE on the q and k slices of a fused qkv activation -- reference
+ * triton_rotate_half_ + rotate_half_kernel (quant/fused_attn.py:61-93, :8-58).
+ * qk points at element [0,0,0,0,0] of a [bsz, seq, 2, heads, head_dim] fp16 view whose
+ * (bsz*seq) rows are row_stride elements apart; position_ids int64 [bsz, seq] with batch
+ * stride pos_batch_stride.  cos/sin are computed on the fly in fp32 with theta = base.
+ */
+int gptq_rope_f16(void *qk, int64_t row_stride, const int64_t *position_ids,
+                  int64_t pos_batch_stride, int bsz, int seq, int heads, int head_dim, float base,
+                  gptq_stream_t stream);
+
+/*
+ * GPU packer -- reference QuantLinear.pack (quant/quant_linear.py:325-371), which runs on the
+ * CPU upstream ("TODO: perform packing on GPU", llama.py:264).  weight fp32 [N, K] (nn.Linear
+ * layout, already grid-valued), scales/zeros fp32 [N, G] as produced by gptq.py:226-228.
+ * Bit-exact with the reference, including the unmasked OR and the zeros-1 wrap.
+ */
+int gptq_pack_f32(const float *weight, const float *scales, const float *zeros,
+                  const int32_t *g_idx, int K, int N, int bits, int groupsize, int32_t *qweight,
+                  int32_t *qzeros, void *scales_f16, gptq_stream_t stream);
+
+/* 1 iff g_idx[k] == k / groupsize for all k (device-side check, writes one int32 to `out`). */
+int gptq_g_idx_is_trivial(const int32_t *g_idx, int K, int groupsize, int32_t *out,
+                          gptq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPTQ_MI355X_H */

@@ -1,0 +1,324 @@
+"""GPU parity tests: the HIP path (through the drop-in Python surface -> C ABI) against
+(a) the golden fixtures recorded from the reference's own kernels, (b) the CPU oracle on seeded
+inputs, incl. the full LLaMA-7B shapes, and (c) size-independent properties.
+Tolerance (SURVEY 0.6 / BASELINE north_star): max|y - y_ref| / max|y_ref| < 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+import quant
+from quant import quant_linear as QL
+from quant import _native
+from oracle import oracle
+from util import TOL, golden_names, load_golden, make_random_layer, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def hip_forward(x, L, bias=None):
+    out = QL.matmul248(dev(x), dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), int(L['bits']),
+                       2**int(L['bits']) - 1, bias=None if bias is None else dev(bias))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def oracle_forward(x, L, bias=None):
+    return oracle.matmul248(x, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], int(L['bits']), bias=bias)
+
+
+def check_forward(x, L, bias=None):
+    y = hip_forward(x, L, bias)
+    ref = oracle_forward(x, L, bias)
+    assert y.shape == ref.shape
+    assert np.isfinite(y.astype(np.float32)).all()
+    assert rel_err(y, ref) < TOL, rel_err(y, ref)
+    return y, ref
+
+
+def test_native_library_loaded():
+    L = _native.lib()
+    assert L.gptq_query(0) == 1
+    assert torch.cuda.get_device_properties(0).gcnArchName.startswith('gfx950')
+
+
+@pytest.mark.parametrize('name', golden_names('pack_') + golden_names('fwd_'))
+def test_forward_vs_reference_kernel_golden(name):
+    f = load_golden(name)
+    y = hip_forward(f['x'], f)
+    assert rel_err(y, f['y']) < TOL
+    ye = oracle.matmul248_exact(f['x'], f['qweight'], f['scales'], f['qzeros'], f['g_idx'], int(f['bits']))
+    assert rel_err(y, ye) < TOL
+
+
+def test_bias_golden():
+    f = load_golden('pack_w4gall_sym_bias.npz')
+    y = hip_forward(f['x'], f, bias=f['bias'])
+    ref = oracle_forward(f['x'], f, bias=f['bias'])
+    assert rel_err(y, ref) < TOL
+
+
+@pytest.mark.parametrize('name', golden_names('mlp_'))
+def test_fused_mlp_vs_reference_kernel_golden(name):
+    f = load_golden(name)
+    bits = int(f['gate_bits'])
+    gs = int(f['gate_groupsize'])
+    K = f['x'].shape[1]
+    gs = K if gs == -1 else gs
+    gate = tuple(dev(f['gate_' + k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(f['up_' + k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c = quant.fused_mlp.fused_gate_up(dev(f['x']), gate, up, bits, gs).cpu().numpy()
+    assert rel_err(c, f['c']) < TOL
+
+
+@pytest.mark.parametrize('name', golden_names('bwd_'))
+def test_backward_vs_reference_kernel_golden(name):
+    f = load_golden(name)
+    bits = int(f['bits'])
+    dx = QL.transpose_matmul248(dev(f['dy']), dev(f['qweight']), dev(f['scales']), dev(f['qzeros']), dev(f['g_idx']), bits,
+                                2**bits - 1).cpu().numpy()
+    assert rel_err(dx, f['dx']) < TOL
+
+
+@pytest.mark.parametrize('name', golden_names('norm_'))
+def test_rmsnorm_vs_reference_kernel_golden(name):
+    f = load_golden(name)
+    y = quant.triton_norm.rms_norm(dev(f['x']), dev(f['w']), float(f['eps'])).cpu().numpy()
+    assert rel_err(y, f['y']) < TOL
+
+
+@pytest.mark.parametrize('name', golden_names('rope_'))
+def test_rope_vs_reference_kernel_golden(name):
+    f = load_golden(name)
+    qkv = dev(f['qkv_in'])
+    quant.fused_attn.hip_rotate_half_(qkv[:, :, :2], dev(f['pos']))
+    out = qkv.cpu().numpy()
+    assert np.array_equal(out[:, :, 2].view(np.uint16), f['qkv_out'][:, :, 2].view(np.uint16))
+    assert np.abs(out.astype(np.float32) - f['qkv_out'].astype(np.float32)).max() < 4e-3
+    assert rel_err(out, f['qkv_out']) < TOL
+
+
+@pytest.mark.parametrize('bits', [2, 4, 8])
+@pytest.mark.parametrize('variant', list(range(8)))
+@pytest.mark.parametrize('M', [1, 2, 3, 4])
+def test_gemv_every_variant(bits, variant, M):
+    """every (tile, threads) variant of the wavefront-reduction GEMV, forced through the ABI."""
+    L = make_random_layer(bits, 128, 1024, 512, seed=bits * 10 + variant)
+    x = np.random.default_rng(M).standard_normal((M, 1024)).astype(np.float16)
+    lib = _native.lib()
+    lib.gptq_set_gemv_variant(variant)
+    try:
+        check_forward(x, L)
+    finally:
+        lib.gptq_set_gemv_variant(-1)
+
+
+@pytest.mark.parametrize('split_k', [2, 3, 8])
+@pytest.mark.parametrize('variant', [0, 5, 7])
+def test_gemv_split_k(split_k, variant):
+    """K slices combined through the fp32 atomic workspace; run twice: the last arriver must
+    leave the workspace and the tickets zeroed for the next launch."""
+    L = make_random_layer(4, 128, 2048, 512, seed=7)
+    x = np.random.default_rng(3).standard_normal((2, 2048)).astype(np.float16)
+    lib = _native.lib()
+    lib.gptq_set_gemv_variant(variant)
+    lib.gptq_set_split_k(split_k)
+    try:
+        y1, _ = check_forward(x, L)
+        y2, _ = check_forward(x, L)
+        assert rel_err(y1, y2) < 1e-3
+    finally:
+        lib.gptq_set_gemv_variant(-1)
+        lib.gptq_set_split_k(-1)
+
+
+@pytest.mark.parametrize('bits,gs', [(4, 128), (4, 32), (4, -1), (2, 64), (2, 128), (8, 128), (8, 32)])
+@pytest.mark.parametrize('M', [5, 16, 17, 33, 64])
+def test_skinny_mfma(bits, gs, M):
+    L = make_random_layer(bits, gs, 1024, 256, seed=bits + M)
+    x = np.random.default_rng(M).standard_normal((M, 1024)).astype(np.float16)
+    check_forward(x, L)
+
+
+@pytest.mark.parametrize('split_k', [2, 4])
+def test_skinny_split_k(split_k):
+    L = make_random_layer(4, 128, 2048, 256, seed=11)
+    x = np.random.default_rng(5).standard_normal((24, 2048)).astype(np.float16)
+    lib = _native.lib()
+    lib.gptq_set_split_k(split_k)
+    try:
+        check_forward(x, L)
+        check_forward(x, L)
+    finally:
+        lib.gptq_set_split_k(-1)
+
+
+@pytest.mark.parametrize('M', [65, 130, 257])
+def test_large_m(M):
+    L = make_random_layer(4, 128, 512, 256, seed=M)
+    x = np.random.default_rng(M).standard_normal((M, 512)).astype(np.float16)
+    check_forward(x, L)
+
+
+@pytest.mark.parametrize('bits', [2, 3, 4, 8])
+@pytest.mark.parametrize('M', [1, 3, 9])
+def test_act_order_and_3bit(bits, M):
+    """non-trivial g_idx (act-order) for every width; 3-bit is the layout EXTENSION (no reference)."""
+    L = make_random_layer(bits, 128, 512, 256 if bits != 3 else 96 * 2 + 64, act_order=True, seed=bits)
+    x = np.random.default_rng(M + 20).standard_normal((M, 512)).astype(np.float16)
+    check_forward(x, L)
+
+
+@pytest.mark.parametrize('gs', [-1, 128])
+def test_3bit_no_group(gs):
+    L = make_random_layer(3, gs, 1024, 256, seed=33)
+    x = np.random.default_rng(2).standard_normal((1, 1024)).astype(np.float16)
+    check_forward(x, L)
+
+
+def test_odd_groupsize_goes_generic():
+    L = make_random_layer(4, 48, 96 * 4, 128, seed=5)       # groupsize not a multiple of 32
+    x = np.random.default_rng(2).standard_normal((2, 96 * 4)).astype(np.float16)
+    check_forward(x, L)
+
+
+def test_zero_rows_and_empty():
+    L = make_random_layer(4, 128, 256, 128, seed=1)
+    y = QL.matmul248(torch.empty(0, 256, dtype=torch.float16, device=DEV), dev(L['qweight']), dev(L['scales']),
+                     dev(L['qzeros']), dev(L['g_idx']), 4, 15)
+    assert y.shape == (0, 128)
+    x = np.zeros((3, 256), dtype=np.float16)
+    assert np.all(hip_forward(x, L) == 0)
+
+
+def test_strided_rows_and_fp32_input():
+    L = make_random_layer(4, 128, 256, 128, seed=2)
+    rng = np.random.default_rng(0)
+    big = rng.standard_normal((4, 512)).astype(np.float16)
+    xs = dev(big)[:, :256]                      # row stride 512, last dim contiguous
+    y = QL.matmul248(xs, dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15).cpu().numpy()
+    assert rel_err(y, oracle_forward(big[:, :256], L)) < TOL
+    y32 = QL.matmul248(xs.float(), dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15)
+    assert y32.dtype == torch.float16
+
+
+SHAPES_7B = [(4096, 4096), (4096, 11008), (11008, 4096), (4096, 12288)]
+
+
+@pytest.mark.parametrize('K,N', SHAPES_7B)
+def test_llama7b_shapes_vs_oracle(K, N):
+    """BASELINE config 2 at full size, M = 1, against the CPU oracle (seconds on the host)."""
+    L = make_random_layer(4, 128, K, N, seed=K + N)
+    x = np.random.default_rng(1).standard_normal((1, K)).astype(np.float16)
+    y, ref = check_forward(x, L)
+    ye = oracle.matmul248_exact(x, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)
+    assert rel_err(y, ye) < TOL
+    # the pre-rounding error budget: HIP is closer to real arithmetic than the fp16-weight reference
+    assert rel_err(y, ye) <= rel_err(ref, ye) + 5e-4
+
+
+def test_llama7b_fused_mlp_full_size():
+    K, N = 4096, 11008
+    A = make_random_layer(4, 128, K, N, seed=1)
+    B = make_random_layer(4, 128, K, N, seed=2)
+    x = np.random.default_rng(1).standard_normal((1, K)).astype(np.float16)
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 128).cpu().numpy()
+    ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']),
+                           (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), 4)
+    assert rel_err(c, ref) < 2e-3      # product of two rounded accumulators
+
+
+def test_linearity_property_full_size():
+    """f(a*x1 + x2) == a*f(x1) + f(x2) up to fp16 rounding -- size independent."""
+    K, N = 4096, 4096
+    L = make_random_layer(4, 128, K, N, seed=9)
+    rng = np.random.default_rng(4)
+    x1 = rng.standard_normal((1, K)).astype(np.float16)
+    x2 = rng.standard_normal((1, K)).astype(np.float16)
+    xs = (2.0 * x1.astype(np.float32) + x2.astype(np.float32)).astype(np.float16)
+    y1, y2, ys = hip_forward(x1, L), hip_forward(x2, L), hip_forward(xs, L)
+    lin = 2.0 * y1.astype(np.float64) + y2.astype(np.float64)
+    assert np.abs(ys - lin).max() / np.abs(lin).max() < 3e-3
+
+
+def test_row_shards_sum_to_full():
+    """BASELINE config 5 emulated on one GPU: 8 K-shards' partials sum to the full product."""
+    from quant import tensor_parallel as tp
+    K, N = 1024, 512
+    L = make_random_layer(4, 128, K, N, seed=3)
+    layer = quant.QuantLinear(4, 128, K, N, False)
+    layer.qweight, layer.qzeros, layer.scales, layer.g_idx = (dev(L['qweight']), dev(L['qzeros']), dev(L['scales']),
+                                                               dev(L['g_idx']))
+    x = dev(np.random.default_rng(0).standard_normal((2, K)).astype(np.float16))
+    full = layer(x).float()
+    acc = torch.zeros_like(full)
+    for r in range(8):
+        shard, (k0, k1) = tp.shard_rows(layer, r, 8)
+        acc += tp._default_matmul(x[:, k0:k1].contiguous(), shard).float()
+    assert rel_err(acc.cpu().numpy(), full.cpu().numpy()) < 2e-3
+
+
+def test_gpu_pack_bit_exact():
+    """gptq_pack_f32 == oracle.pack (== reference pack, see test_oracle_golden) bit for bit."""
+    for name in golden_names('pack_'):
+        f = load_golden(name)
+        bits, gs = int(f['bits']), int(f['groupsize'])
+        N, K = f['weight_q'].shape
+        lin = torch.nn.Linear(K, N, bias=False)
+        lin.weight.data = torch.from_numpy(f['weight_q'])
+        lin = lin.to(DEV)
+        ql = quant.QuantLinear(bits, gs, K, N, False)
+        ql.pack(lin, torch.from_numpy(f['scales_in']), torch.from_numpy(f['zeros_in']), torch.from_numpy(f['g_idx']))
+        assert np.array_equal(ql.qweight.cpu().numpy(), f['qweight']), name
+        assert np.array_equal(ql.qzeros.cpu().numpy(), f['qzeros']), name
+        assert np.array_equal(ql.scales.cpu().numpy().view(np.uint16), f['scales'].view(np.uint16)), name
+
+
+def test_hipgraph_capture_and_replay():
+    L = make_random_layer(4, 128, 1024, 512, seed=4)
+    args = (dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15)
+    x = dev(np.random.default_rng(0).standard_normal((1, 1024)).astype(np.float16))
+    y_eager = QL.matmul248(x, *args).clone()      # also warms the g_idx cache / workspace
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        QL.matmul248(x, *args)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        y_cap = QL.matmul248(x, *args)
+    x.copy_(x * 2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert rel_err(y_cap.cpu().numpy(), (2 * y_eager.float()).cpu().numpy()) < 2e-3
+
+
+def test_error_behaviour():
+    with pytest.raises(NotImplementedError):
+        quant.QuantLinear(5, 128, 256, 128, False)
+    L = make_random_layer(4, 128, 256, 128, seed=1)
+    with pytest.raises(RuntimeError):
+        QL.matmul248(torch.zeros(1, 256, dtype=torch.float16), dev(L['qweight']), dev(L['scales']), dev(L['qzeros']),
+                     dev(L['g_idx']), 4, 15)
+    with pytest.raises(RuntimeError):
+        quant.triton_norm.rms_norm(torch.zeros(1, 40000, dtype=torch.float16, device=DEV),
+                                   torch.ones(40000, dtype=torch.float16, device=DEV), 1e-6)
+
+
+def test_autograd_backward_matches_oracle():
+    L = make_random_layer(4, 128, 256, 128, seed=8)
+    layer = quant.QuantLinear(4, 128, 256, 128, False)
+    layer.qweight, layer.qzeros, layer.scales, layer.g_idx = (dev(L['qweight']), dev(L['qzeros']), dev(L['scales']),
+                                                               dev(L['g_idx']))
+    x = dev(np.random.default_rng(0).standard_normal((3, 256)).astype(np.float16)).requires_grad_(True)
+    y = layer(x)
+    dy = np.random.default_rng(1).standard_normal((3, 128)).astype(np.float16)
+    y.backward(dev(dy))
+    ref = oracle.transpose_matmul248(dy, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)
+    assert rel_err(x.grad.cpu().numpy(), ref) < TOL

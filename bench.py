@@ -100,13 +100,13 @@ class DecodeLinears:
     def per_shape(self, reps=20):
         """event-timed launches per shape, rotating over the 32 layers' distinct weights (cold)."""
         out = {}
-        s = torch.cuda.current_stream().cuda_stream
+        cs = lambda: torch.cuda.current_stream().cuda_stream   # the capture stream inside torch.cuda.graph
         legs = {
-            'qkv_4096x12288': (lambda L: self._mm(self.x_h, L['qkv'], self.y_qkv, s), alg_bytes(1, HIDDEN, 3 * HIDDEN)),
-            'o_4096x4096': (lambda L: self._mm(self.x_h, L['o'], self.y_h, s), alg_bytes(1, HIDDEN, HIDDEN)),
-            'gate_up_silu_2x4096x11008': (lambda L: self._mlp(self.x_h, L['gate'], L['up'], self.y_i, s),
+            'qkv_4096x12288': (lambda L: self._mm(self.x_h, L['qkv'], self.y_qkv, cs()), alg_bytes(1, HIDDEN, 3 * HIDDEN)),
+            'o_4096x4096': (lambda L: self._mm(self.x_h, L['o'], self.y_h, cs()), alg_bytes(1, HIDDEN, HIDDEN)),
+            'gate_up_silu_2x4096x11008': (lambda L: self._mlp(self.x_h, L['gate'], L['up'], self.y_i, cs()),
                                           alg_bytes(1, HIDDEN, INTER, nsets=2)),
-            'down_11008x4096': (lambda L: self._mm(self.x_i, L['down'], self.y_h, s), alg_bytes(1, INTER, HIDDEN)),
+            'down_11008x4096': (lambda L: self._mm(self.x_i, L['down'], self.y_h, cs()), alg_bytes(1, INTER, HIDDEN)),
         }
         for name, (fn, nbytes) in legs.items():
             g = torch.cuda.CUDAGraph()

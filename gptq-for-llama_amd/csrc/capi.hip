@@ -9,6 +9,7 @@ namespace gptq {
 
 static std::atomic<int> g_force_variant{-1};
 static std::atomic<int> g_force_split_k{-1};
+static std::atomic<void *> g_debug_buffer{nullptr};
 
 static bool aligned(const void *p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
@@ -68,8 +69,8 @@ static void fill_params(const Problem &q, int m0, int mcount, GemvParams &p) {
     p.N = q.N;
     p.G = n_groups(q.K, q.groupsize);
     p.groupsize = q.groupsize;
-    p.counters = (unsigned *)q.ws;
-    p.ws = q.ws ? (float *)((char *)q.ws + (size_t)MAX_TILES * 4) : nullptr;
+    p.ws = (u64_t *)q.ws;
+    p.dbg = (u64_t *)g_debug_buffer.load();
 }
 
 // Built-in table: which (NL, WAVES) tiling and K split the fast GEMV uses for a shape.
@@ -99,8 +100,10 @@ static int run_gemv(const Problem &q, hipStream_t s) {
     if (split_k > nchunks) split_k = nchunks;
     if (!fast) split_k = 1;
     const int ns = q.fused2 ? 2 : 1;
-    const size_t ws_need = (size_t)MAX_TILES * 4 + (size_t)ns * GEMV_MAX_M * q.N * 4;
-    if (split_k > 1 && (!q.ws || q.ws_bytes < ws_need)) {
+    const int split_max = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
+    if (split_k > split_max) split_k = split_max;
+    const size_t ws_need = (size_t)GEMV_MAX_M * q.N * 8;
+    if (split_k > 1 && (!q.ws || q.ws_bytes < ws_need || !aligned(q.ws, 8))) {
         if (fs >= 1) return GPTQ_E_WORKSPACE;
         split_k = 1;
     }
@@ -117,7 +120,6 @@ static int run_gemv(const Problem &q, hipStream_t s) {
             fill_params(q, m0, mr, p);
             const int nl = g_gemv_variants[variant].nl;
             p.ntiles = (q.N + 4 * nl - 1) / (4 * nl);
-            if (split_k > 1 && p.ntiles > MAX_TILES) return GPTQ_E_WORKSPACE;
             p.split_k = split_k;
             p.nchunks = nchunks;
             p.chunks_per_slice = cps;
@@ -144,38 +146,66 @@ static int run_gemv(const Problem &q, hipStream_t s) {
     return 0;
 }
 
+static int ilog2_exact(int v) {
+    for (int i = 0; i < 31; i++)
+        if ((1 << i) == v) return i;
+    return -1;
+}
+
+// The weight-streaming MFMA kernel (skinny_mfma.hip): M <= 64, trivial g_idx, whole groups.
 static int run_skinny(const Problem &q, hipStream_t s) {
     const int unit_k = (q.bits == 2) ? 64 : 32;
-    if (!fast_eligible(q, unit_k)) return run_gemv(q, s);
-    const int ns = q.fused2 ? 2 : 1;
+    if (!fast_eligible(q, unit_k) || q.K % q.groupsize != 0) return run_gemv(q, s);
+    const int upg = q.groupsize / unit_k;
+    const int nunits = q.K / unit_k;
     const int mmax = q.fused2 ? 32 : SKINNY_MAX_M;
+    const int split_max = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
+    int waves = 4;
+    const int fv = g_force_variant.load();
+    if (fv == 2 || fv == 4 || fv == 8) waves = fv;
     for (int m0 = 0; m0 < q.M; m0 += mmax) {
         const int mc = (q.M - m0 < mmax) ? (q.M - m0) : mmax;
         GemvParams p;
         fill_params(q, m0, mc, p);
         p.ntiles = (q.N + 63) / 64;
-        const int nunits = q.K / unit_k;
-        // aim for >= 2 workgroups per CU; K slices must hold whole groups
+        p.units_per_group = upg;
+        p.upg_shift = ilog2_exact(upg);
+        bool xlds = mc <= 16;
+        int stg = (upg % 4 == 0) ? 4 : ((upg % 2 == 0 && xlds) ? 2 : 1);
+        const int nstages = nunits / stg;
+        const int w = (xlds && stg == 4) ? waves : 4;
+        const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)mc * q.N * 8;
+        // K split: ~3 workgroups per CU, every wave of a workgroup gets at least one stage
         int split_k = 1;
         const int fs = g_force_split_k.load();
         if (fs >= 1) {
             split_k = fs;
-        } else {
-            while (p.ntiles * split_k < 512 && split_k * 2 * 4 <= nunits) split_k *= 2;
+            if (split_k > 1 && !ws_ok) return GPTQ_E_WORKSPACE;
+        } else if (ws_ok) {
+            split_k = (768 + p.ntiles - 1) / p.ntiles;
         }
-        const size_t ws_need = (size_t)MAX_TILES * 4 + (size_t)ns * mc * q.N * 4;
-        if (split_k > 1 && (!q.ws || q.ws_bytes < ws_need || p.ntiles > MAX_TILES)) {
-            if (fs >= 1) return GPTQ_E_WORKSPACE;
-            split_k = 1;
+        if (split_k > split_max) split_k = split_max;
+        if (split_k * w > nstages) split_k = nstages / w;
+        if (split_k < 1) split_k = 1;
+        int sps = (nstages + split_k - 1) / split_k;  // stages per slice
+        // staged x must fit: rows * (units * unit_k + 8) halves
+        const int xrows = mc < 16 ? mc : 16;
+        auto x_bytes = [&](int sps_) { return (size_t)xrows * ((size_t)sps_ * stg * unit_k + 8) * 2 + 16; };
+        if (xlds && x_bytes(sps) > 64 * 1024) {
+            if (ws_ok && fs < 1) {
+                while (x_bytes(sps) > 64 * 1024 && split_k < split_max && (split_k + 1) * w <= nstages) {
+                    split_k++;
+                    sps = (nstages + split_k - 1) / split_k;
+                }
+            }
+            if (x_bytes(sps) > 64 * 1024) xlds = false;
         }
-        // slices hold whole units; group boundaries are handled per unit inside the kernel
-        if (split_k > nunits) split_k = nunits;
-        const int ups = (nunits + split_k - 1) / split_k;
-        split_k = (nunits + ups - 1) / ups;
+        if (!xlds && stg == 2) return run_gemv(q, s);
+        split_k = (nstages + sps - 1) / sps;
         p.split_k = split_k;
         p.nchunks = nunits;
-        p.chunks_per_slice = ups;
-        int rc = skinny_dispatch(q.bits, q.fused2, p, s);
+        p.chunks_per_slice = sps * stg;
+        int rc = skinny_dispatch(q.bits, q.fused2, stg, (xlds && stg == 4) ? waves : 4, xlds, p, s);
         if (rc) return rc;
     }
     return 0;
@@ -183,8 +213,7 @@ static int run_skinny(const Problem &q, hipStream_t s) {
 
 static int run_auto(const Problem &q, hipStream_t s) {
     if (q.M == 0) return 0;
-    if (q.M <= GEMV_MAX_M) return run_gemv(q, s);
-    if (q.M <= SKINNY_MAX_M) return run_skinny(q, s);
+    if (q.M <= SKINNY_MAX_M) return run_skinny(q, s);  // falls back to the GEMV for act-order / 3-bit
     const int unit_k = (q.bits == 2) ? 64 : 32;
     if (!q.fused2 && fast_eligible(q, unit_k)) {
         GemvParams p;
@@ -206,7 +235,7 @@ int gptq_query(int what) {
         case GPTQ_Q_ABI_VERSION: return 1;
         case GPTQ_Q_GEMV_MAX_M: return GEMV_MAX_M;
         case GPTQ_Q_SKINNY_MAX_M: return SKINNY_MAX_M;
-        case GPTQ_Q_WORKSPACE_BYTES: return (int)(MAX_TILES * 4 + 2 * (size_t)SKINNY_MAX_M * 32768 * 4);
+        case GPTQ_Q_WORKSPACE_BYTES: return (int)WS_BYTES;
         case GPTQ_Q_NUM_GEMV_VARIANTS: return GEMV_NUM_VARIANTS;
     }
     return -1;
@@ -229,6 +258,7 @@ const char *gptq_strerror(int code) {
 
 int gptq_set_gemv_variant(int variant) { return g_force_variant.exchange(variant); }
 int gptq_set_split_k(int split_k) { return g_force_split_k.exchange(split_k); }
+void *gptq_set_debug_buffer(void *buf) { return g_debug_buffer.exchange(buf); }
 
 static Problem make_problem(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
                             const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,

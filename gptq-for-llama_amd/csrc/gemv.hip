@@ -252,9 +252,6 @@ __global__ void __launch_bounds__(WAVES * 64) gemv_fast_kernel(const GemvParams 
     }
     __syncthreads();
 
-    // arrival flag lives in the dynamic region too (a static __shared__ would shift its base)
-    const size_t x_bytes = (size_t)MR * p.chunks_per_slice * 64, red_bytes = (size_t)WAVES * NS * MR * TILE * 4;
-    int *s_last = (int *)(smem + (((x_bytes > red_bytes ? x_bytes : red_bytes) + 15) & ~(size_t)15));
     constexpr int NOUT = MR * TILE;
     float tot[NS][(NOUT + T - 1) / T];
 #pragma unroll
@@ -271,59 +268,27 @@ __global__ void __launch_bounds__(WAVES * 64) gemv_fast_kernel(const GemvParams 
         }
     }
 
-    if (p.split_k > 1) {
-        // partial sums -> fp32 workspace (agent-scope returning atomics: completion is observed
-        // before the ticket is taken), then the last arriver of this tile finalises.
-#pragma unroll
-        for (int r = 0; r < (NOUT + T - 1) / T; r++) {
-            const int e = tid + r * T;
-            const int m = e / TILE, n = tile * TILE + e % TILE;
-            if (e < NOUT && m < p.M && n < N) {
-#pragma unroll
-                for (int s = 0; s < NS; s++) {
-                    float old = __hip_atomic_fetch_add(p.ws + ((size_t)s * GEMV_MAX_M + m) * N + n, tot[s][r],
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("" ::"v"(old));
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned t = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = (t == (unsigned)p.split_k - 1);
-            if (last) __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *s_last = last;
-        }
-        __syncthreads();
-        if (!*s_last) return;
-#pragma unroll
-        for (int r = 0; r < (NOUT + T - 1) / T; r++) {
-            const int e = tid + r * T;
-            const int m = e / TILE, n = tile * TILE + e % TILE;
-            if (e < NOUT && m < p.M && n < N) {
-#pragma unroll
-                for (int s = 0; s < NS; s++)
-                    tot[s][r] = __hip_atomic_exchange(p.ws + ((size_t)s * GEMV_MAX_M + m) * N + n, 0.0f,
-                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-
+    // ---- outputs: direct, or combined over K-slices in one atomic round trip -------------------
 #pragma unroll
     for (int r = 0; r < (NOUT + T - 1) / T; r++) {
         const int e = tid + r * T;
         const int m = e / TILE, n = tile * TILE + e % TILE;
         if (e < NOUT && m < p.M && n < N) {
-            float v;
-            if constexpr (FUSED2) {
-                const float a = tot[0][r];
-                v = a * (1.0f / (1.0f + __expf(-a))) * tot[1][r];  // silu on the fp32 accumulator
-            } else {
-                v = tot[0][r];
+            float t0 = tot[0][r], t1 = 0.f;
+            if constexpr (FUSED2) t1 = tot[1][r];
+            bool mine = true;
+            if (p.split_k > 1) {
+                u64_t *word = p.ws + (size_t)m * N + n;
+                if constexpr (FUSED2) mine = splitk_add2(word, t0, t1, p.split_k, t0, t1);
+                else mine = splitk_add1(word, t0, p.split_k, t0);
             }
-            half_t h = (half_t)v;
-            if (p.bias) h = (half_t)((float)h + (float)p.bias[n]);
-            p.y[(size_t)m * p.ldy + n] = h;
+            if (mine) {
+                float v = t0;
+                if constexpr (FUSED2) v = t0 * (1.0f / (1.0f + __expf(-t0))) * t1;  // silu on the fp32 accumulator
+                half_t h = (half_t)v;
+                if (p.bias) h = (half_t)((float)h + (float)p.bias[n]);
+                p.y[(size_t)m * p.ldy + n] = h;
+            }
         }
     }
 }
@@ -513,6 +478,10 @@ const GemvVariant g_gemv_variants[GEMV_NUM_VARIANTS] = {
     {16, 4},  // 5: 64-col tiles (256-B segments), 256 threads
     {16, 8},  // 6
     {64, 4},  // 7: 256-col tiles (full 1-KiB rows per wave), 256 threads
+    {32, 4},  // 8: 128-col tiles (512-B segments), 256 threads
+    {32, 8},  // 9
+    {64, 8},  // 10
+    {16, 16}, // 11: 64-col tiles, 1024 threads
 };
 
 template <int BITS, int MR, bool FUSED2>
@@ -528,6 +497,12 @@ static int launch_fast_variant(int variant, const GemvParams &p, hipStream_t s) 
         case 5: return launch_fast<BITS, 16, 4, MR, FUSED2>(p, s);
         case 6: return launch_fast<BITS, 16, 8, MR, FUSED2>(p, s);
         case 7: return launch_fast<BITS, 64, 4, MR, FUSED2>(p, s);
+        case 8: return launch_fast<BITS, 32, 4, MR, FUSED2>(p, s);
+        case 9: return launch_fast<BITS, 32, 8, MR, FUSED2>(p, s);
+        case 10: return launch_fast<BITS, 64, 8, MR, FUSED2>(p, s);
+        case 11:
+            if constexpr (FUSED2) return launch_fast<BITS, 16, 8, MR, FUSED2>(p, s);
+            else return launch_fast<BITS, 16, 16, MR, FUSED2>(p, s);
     }
     return GPTQ_E_VARIANT;
 }

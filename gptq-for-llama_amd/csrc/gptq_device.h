@@ -123,3 +123,47 @@ GPTQ_DEV float wave_sum_xor(float v, int from) {
     for (int off = from; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+
+// ---------------------------------------------------------------------------------------
+// Split-K combine in ONE memory round trip, order-independent (bit-reproducible):
+// every K-slice adds its partial sum as a biased fixed-point integer together with an arrival
+// count in the top bits of the SAME 64-bit word, with one returning agent-scope atomic.  The
+// slice whose returned value completes the count owns the total: it decodes it, stores zero
+// back (the workspace is all-zero between launches) and writes the output.  No ticket, no
+// second pass, no fence; integer addition makes the sum independent of arrival order.
+//   single value : [63:56] count (S <= 255) | [55:0] sum of (round(v * 2^24) + 2^50)
+//   value pair   : [63:60] count (S <= 15)  | [59:30] b | [29:0] a, fields = round(v * 2^15) + 2^25
+//                  (used by the fused gate/up kernel: |partial| < 1024, resolution 2^-15)
+// ---------------------------------------------------------------------------------------
+typedef unsigned long long u64_t;
+constexpr int SPLITK_MAX_SINGLE = 32;   // 32 * (2^50 + 2^48) < 2^56
+constexpr int SPLITK_MAX_PAIR = 15;
+
+GPTQ_DEV bool splitk_add1(u64_t *word, float v, int S, float &total) {
+    const float c = fminf(fmaxf(v, -16777216.0f), 16777216.0f);               // |v| <= 2^24 (fp16 max is 65504)
+    const long long fx = (long long)(c * 16777216.0f) + (1LL << 50);            // exact: power-of-two scale
+    const u64_t add = (u64_t)fx + (1ULL << 56);
+    const u64_t old = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64_t now = old + add;
+    if ((int)(now >> 56) != S) return false;
+    __hip_atomic_store(word, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long sum = (long long)(now & ((1ULL << 56) - 1)) - (long long)S * (1LL << 50);
+    total = (float)sum * (1.0f / 16777216.0f);
+    return true;
+}
+
+GPTQ_DEV bool splitk_add2(u64_t *word, float a, float b, int S, float &ta, float &tb) {
+    const float lim = 1023.99f;
+    const long long fa = (long long)rintf(fminf(fmaxf(a, -lim), lim) * 32768.0f) + (1LL << 25);
+    const long long fb = (long long)rintf(fminf(fmaxf(b, -lim), lim) * 32768.0f) + (1LL << 25);
+    const u64_t add = (u64_t)fa | ((u64_t)fb << 30) | (1ULL << 60);
+    const u64_t old = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64_t now = old + add;
+    if ((int)(now >> 60) != S) return false;
+    __hip_atomic_store(word, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long sa = (long long)(now & ((1ULL << 30) - 1)) - (long long)S * (1LL << 25);
+    const long long sb = (long long)((now >> 30) & ((1ULL << 30) - 1)) - (long long)S * (1LL << 25);
+    ta = (float)sa * (1.0f / 32768.0f);
+    tb = (float)sb * (1.0f / 32768.0f);
+    return true;
+}

@@ -11,12 +11,9 @@ namespace gptq {
 
 constexpr int GEMV_MAX_M = 4;         // rows served by the wavefront-reduction GEMV
 constexpr int SKINNY_MAX_M = 64;      // rows served by the weight-streaming MFMA kernel
-constexpr int GEMV_NUM_VARIANTS = 8;
-constexpr int MAX_TILES = 8192;       // arrival counters in the workspace
-// workspace: [2][GEMV_MAX_M][N_max] fp32 partial sums + MAX_TILES counters
-constexpr size_t WS_MAX_N = 65536;
-constexpr size_t WS_SUM_BYTES = 2 * (size_t)SKINNY_MAX_M * WS_MAX_N * 4;
-constexpr size_t WS_BYTES = WS_SUM_BYTES + MAX_TILES * 4;
+constexpr int GEMV_NUM_VARIANTS = 12;
+// split-K workspace: one 64-bit word per output element ([M][N]), all-zero between launches
+constexpr size_t WS_BYTES = (size_t)SKINNY_MAX_M * 32768 * 8;
 
 struct GemvVariant {
     int nl;     // column lanes per wave (tile = 4*nl columns)
@@ -36,15 +33,16 @@ struct GemvParams {
     int64_t ldy;
     int M, K, N, G, groupsize;
     int ntiles, split_k, nchunks, chunks_per_slice;
-    float *ws;
-    unsigned *counters;
+    int units_per_group, upg_shift;  // stream kernel: groupsize / unit_k and its log2 (or -1)
+    u64_t *ws;
+    u64_t *dbg;  // optional timeline buffer [blocks][waves][8] (tools/timeline.py), else nullptr
 };
 
 int gemv_fast_dispatch(int bits, bool fused2, int variant, const GemvParams &p, hipStream_t s);
 int gemv_generic_dispatch(int bits, bool fused2, int nl, const GemvParams &p, hipStream_t s);
 
 // skinny MFMA (weight streaming, M <= 64) and tiled MFMA GEMM (prefill)
-int skinny_dispatch(int bits, bool fused2, const GemvParams &p, hipStream_t s);
+int skinny_dispatch(int bits, bool fused2, int stg, int waves, bool xlds, const GemvParams &p, hipStream_t s);
 int gemm_dispatch(int bits, bool fused2, const GemvParams &p, hipStream_t s);
 int transpose_dispatch(int bits, const half_t *dy, int64_t lddy, const uint32_t *qw, const half_t *sc,
                        const int32_t *qz, const int32_t *gi, half_t *dx, int64_t lddx, int M, int K, int N,

@@ -27,6 +27,7 @@ _SIGNATURES = {
     'gptq_query': [c_int],
     'gptq_set_gemv_variant': [c_int],
     'gptq_set_split_k': [c_int],
+    'gptq_set_debug_buffer': [c_void_p],
     'gptq_matmul248_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
     'gptq_gemv_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -69,6 +70,7 @@ def lib():
                 fn = getattr(L, name)
                 fn.argtypes = args
                 fn.restype = c_int
+            L.gptq_set_debug_buffer.restype = c_void_p
             L.gptq_strerror.argtypes = [c_int]
             L.gptq_strerror.restype = ctypes.c_char_p
             _lib = L

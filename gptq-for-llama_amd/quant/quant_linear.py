@@ -28,18 +28,18 @@ SUPPORTED_BITS = (2, 3, 4, 8)
 # (always true unless the checkpoint was quantised with --act-order, reference gptq.py:210-216).
 # One device-side check per (buffer, version), cached; done during warm-up / first forward.
 # ----------------------------------------------------------------------------------------------
-_gidx_cache = {}
-
-
 def _infer_groupsize(K, G):
     return K if G <= 1 else -(-K // G)
 
 
 def g_idx_is_trivial(g_idx, K, groupsize):
-    key = (g_idx.data_ptr(), g_idx._version, str(g_idx.device), K, groupsize)
-    hit = _gidx_cache.get(key)
-    if hit is not None:
-        return hit
+    """True iff g_idx[:K] == arange(K) // groupsize.  The verdict is memoised ON the tensor object
+    (keyed by its version counter), never by address: the caching allocator hands the address of
+    a freed g_idx to the next one."""
+    memo = getattr(g_idx, '_gptq_trivial', None)
+    key = (g_idx._version, K, groupsize)
+    if memo is not None and memo[0] == key:
+        return memo[1]
     g = g_idx[:K]
     if g.is_cuda:
         out = torch.empty(1, dtype=torch.int32, device=g.device)
@@ -50,9 +50,10 @@ def g_idx_is_trivial(g_idx, K, groupsize):
         res = bool(out.item())
     else:
         res = bool(torch.equal(g.to(torch.int64), torch.arange(K, dtype=torch.int64) // groupsize))
-    if len(_gidx_cache) > 4096:
-        _gidx_cache.clear()
-    _gidx_cache[key] = res
+    try:
+        g_idx._gptq_trivial = (key, res)
+    except Exception:  # pragma: no cover
+        pass
     return res
 
 

@@ -64,9 +64,15 @@ int gptq_query(int what);
 const char *gptq_strerror(int code);
 
 /* Dispatch override used by autotune_warmup_* and the benchmarks: variant < 0 restores the
- * built-in shape table.  Returns the previous value. */
+ * built-in shape table.  For gptq_gemv_f16 the value indexes the (tile, threads) table of
+ * gemv.hip; for the weight-streaming MFMA kernel the values 2, 4, 8 select the waves per
+ * workgroup.  gptq_set_split_k forces the number of K slices (>= 1).  Both return the
+ * previous value. */
 int gptq_set_gemv_variant(int variant);
 int gptq_set_split_k(int split_k);
+/* Development aid: when non-NULL, the decode kernels write per-wave s_memtime checkpoints
+ * ([block][wave][8] uint64) into this device buffer.  Returns the previous pointer. */
+void *gptq_set_debug_buffer(void *device_buffer);
 
 /*
  * y = x . deq(B) (+ bias)  -- reference matmul248() + matmul_248_kernel + the bias add in

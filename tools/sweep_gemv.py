@@ -59,27 +59,28 @@ def main():
             sets = [PackedSet(K, N, dev, gen) for _ in range(nsets * (2 if fused else 1))]
             x = torch.randn((M, K), device=dev, generator=gen).half()
             y = torch.empty((M, N), dtype=torch.float16, device=dev)
-            s = torch.cuda.current_stream().cuda_stream
             entry = lib.gptq_gemv_f16 if args.kernel == 'gemv' else lib.gptq_skinny_f16
+            if fused and args.kernel == 'gemv':
+                continue   # gptq_fused_mlp_f16 dispatches to the stream kernel: swept with --kernel skinny
 
             def mm(i):
                 w = sets[i]
                 rc = entry(x.data_ptr(), K, w.qweight.data_ptr(), w.scales.data_ptr(), w.qzeros.data_ptr(), None, None,
-                           y.data_ptr(), N, M, K, N, BITS, GS, ws.data_ptr(), ws.numel(), s)
+                           y.data_ptr(), N, M, K, N, BITS, GS, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
                 _native.check(rc, 'gemv')
 
             def mlp(i):
                 g, u = sets[2 * i], sets[2 * i + 1]
                 rc = lib.gptq_fused_mlp_f16(x.data_ptr(), K, g.qweight.data_ptr(), g.scales.data_ptr(), g.qzeros.data_ptr(), None,
                                             u.qweight.data_ptr(), u.scales.data_ptr(), u.qzeros.data_ptr(), None, y.data_ptr(), N,
-                                            M, K, N, BITS, GS, ws.data_ptr(), ws.numel(), s)
+                                            M, K, N, BITS, GS, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
                 _native.check(rc, 'fused')
 
             fn = mlp if fused else mm
             nbytes = alg_bytes(M, K, N, nsets=2 if fused else 1)
-            variants = range(8) if args.kernel == 'gemv' else [0]
+            variants = range(12) if args.kernel == 'gemv' else [2, 4, 8]
             for v in variants:
-                for sk in (1, 2, 4, 8):
+                for sk in ((1, 2, 4, 8, 15) if fused else (1, 2, 4, 8, 16, 32)):
                     lib.gptq_set_gemv_variant(v)
                     lib.gptq_set_split_k(sk)
                     try:
@@ -100,7 +101,7 @@ def main():
             torch.cuda.empty_cache()
     print('%-20s %3s %7s %5s %9s %9s %6s' % ('shape', 'M', 'variant', 'split', 'us', 'GB/s', 'frac'))
     for name in dict.fromkeys(r['shape'] for r in rows):
-        best = sorted((r for r in rows if r['shape'] == name), key=lambda r: r['us'])[:4]
+        best = sorted((r for r in rows if r['shape'] == name), key=lambda r: r['us'])[:6]
         for r in best:
             print('%-20s %3d %7d %5d %9.3f %9.1f %6.3f' % (r['shape'], r['M'], r['variant'], r['split_k'], r['us'], r['GBps'], r['frac']))
 

@@ -73,83 +73,97 @@ static void fill_params(const Problem &q, int m0, int mcount, GemvParams &p) {
     p.dbg = (u64_t *)g_debug_buffer.load();
 }
 
-// Built-in table: which (NL, WAVES) tiling and K split the fast GEMV uses for a shape.
-// Filled from the MI355X sweep in profiles/ (see DESIGN.md "dispatch table").
-static void pick_gemv(int K, int N, bool fused2, int &variant, int &split_k) {
-    (void)K;
-    (void)fused2;
-    split_k = 1;
-    if (N >= 8192)
-        variant = 4;  // 32-col tiles x 512 threads
-    else
-        variant = 1;  // 16-col tiles x 512 threads
+static int ilog2_exact(int v) {
+    for (int i = 0; i < 31; i++)
+        if ((1 << i) == v) return i;
+    return -1;
 }
 
-static int run_gemv(const Problem &q, hipStream_t s) {
-    const bool fast = fast_eligible(q, 32);
-    int variant, split_k;
-    pick_gemv(q.K, q.N, q.fused2, variant, split_k);
+// The rowwave GEMV (gemv.hip) serves M == 1; larger M here means M launches (the dispatcher
+// sends M >= 2 to the weight-streaming MFMA kernel instead).  Picks U = packed rows in flight
+// per wave and S = workgroups per 256-column tile (DESIGN.md "dispatch").
+static int run_rowwave(const Problem &q, hipStream_t s) {
+    const int kpw = 32 / q.bits;
+    const int rows = q.K / kpw;
+    const int G = n_groups(q.K, q.groupsize);
+    const int rpg = q.groupsize / kpw;  // packed rows per group
+    int gshift = -1;
+    if (G > 1) {
+        if (q.groupsize % kpw != 0) return GPTQ_E_VARIANT;
+        gshift = ilog2_exact(rpg);
+        if (gshift < 0) return GPTQ_E_VARIANT;
+    }
+    auto u_ok = [&](int u) { return rows % u == 0 && (G == 1 || rpg % u == 0); };
+    int u = 0;
     const int fv = g_force_variant.load();
     if (fv >= 0) {
         if (fv >= GEMV_NUM_VARIANTS) return GPTQ_E_VARIANT;
-        variant = fv;
+        u = 8 >> fv;
+        if (!u_ok(u)) return GPTQ_E_VARIANT;
+    } else {
+        for (int c = 8; c >= 2 && !u; c >>= 1)
+            if (u_ok(c)) u = c;
+        if (!u) return GPTQ_E_VARIANT;
     }
+    const int ntile = (q.N + 255) / 256;
+    const int nchunk = (rows + 4 * u - 1) / (4 * u);
+    const int split_max = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
+    int split_k = nchunk;                                  // one chunk per workgroup ...
+    if (ntile * split_k > 1024) split_k = 1024 / ntile;    // ... unless that is > 4 workgroups per CU
+    if (split_k < 1) split_k = 1;
     const int fs = g_force_split_k.load();
     if (fs >= 1) split_k = fs;
-    const int nchunks = q.K / 32;
-    if (split_k > nchunks) split_k = nchunks;
-    if (!fast) split_k = 1;
-    const int ns = q.fused2 ? 2 : 1;
-    const int split_max = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
+    if (split_k > nchunk) split_k = nchunk;
     if (split_k > split_max) split_k = split_max;
-    const size_t ws_need = (size_t)GEMV_MAX_M * q.N * 8;
-    if (split_k > 1 && (!q.ws || q.ws_bytes < ws_need || !aligned(q.ws, 8))) {
+    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)q.N * 8;
+    if (split_k > 1 && !ws_ok) {
         if (fs >= 1) return GPTQ_E_WORKSPACE;
         split_k = 1;
     }
-    int cps = (nchunks + split_k - 1) / split_k;
-    split_k = (nchunks + cps - 1) / cps;
+    for (int m = 0; m < q.M; m++) {
+        GemvParams p;
+        fill_params(q, m, 1, p);
+        p.split_k = split_k;
+        p.upg_shift = gshift;
+        int rc = gemv_fast_dispatch(q.bits, q.fused2, u, p, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
 
+static int run_generic(const Problem &q, hipStream_t s) {
+    const int ns = q.fused2 ? 2 : 1;
+    const int nchunks = q.K / 32;
     for (int m0 = 0; m0 < q.M;) {
         int mr = q.M - m0 >= 4 ? 4 : (q.M - m0 >= 2 ? 2 : 1);
         if (q.fused2 && mr > 2) mr = 2;
         GemvParams p;
-        int rc;
-        if (fast) {
-            while (mr > 1 && (size_t)mr * cps * 64 > 128 * 1024) mr >>= 1;
-            fill_params(q, m0, mr, p);
-            const int nl = g_gemv_variants[variant].nl;
-            p.ntiles = (q.N + 4 * nl - 1) / (4 * nl);
-            p.split_k = split_k;
-            p.nchunks = nchunks;
-            p.chunks_per_slice = cps;
-            rc = gemv_fast_dispatch(q.bits, q.fused2, variant, p, s);
-        } else {
-            // LDS: x [mr][K] + g_idx + {s,z} table for the tile; narrow tiles when G is large
-            const int G = n_groups(q.K, q.groupsize);
-            int nl = 16;
-            auto need = [&](int mr_, int nl_) {
-                return (size_t)mr_ * q.K * 2 + (size_t)ns * q.K * 2 + 16 + (size_t)ns * G * 4 * nl_ * 4;
-            };
-            if (need(mr, nl) > 150 * 1024 || (q.N / 64) < 128) nl = 4;
-            while (mr > 1 && need(mr, nl) > 150 * 1024) mr >>= 1;
-            fill_params(q, m0, mr, p);
-            p.ntiles = (q.N + 4 * nl - 1) / (4 * nl);
-            p.split_k = 1;
-            p.nchunks = nchunks;
-            p.chunks_per_slice = nchunks;
-            rc = gemv_generic_dispatch(q.bits, q.fused2, nl, p, s);
-        }
+        // LDS: x [mr][K] + g_idx + {s,z} table for the tile; narrow tiles when G is large
+        const int G = n_groups(q.K, q.groupsize);
+        int nl = 16;
+        auto need = [&](int mr_, int nl_) {
+            return (size_t)mr_ * q.K * 2 + (size_t)ns * q.K * 2 + 16 + (size_t)ns * G * 4 * nl_ * 4;
+        };
+        if (need(mr, nl) > 150 * 1024 || (q.N / 64) < 128) nl = 4;
+        while (mr > 1 && need(mr, nl) > 150 * 1024) mr >>= 1;
+        fill_params(q, m0, mr, p);
+        p.ntiles = (q.N + 4 * nl - 1) / (4 * nl);
+        p.split_k = 1;
+        p.nchunks = nchunks;
+        p.chunks_per_slice = nchunks;
+        int rc = gemv_generic_dispatch(q.bits, q.fused2, nl, p, s);
         if (rc) return rc;
         m0 += mr;
     }
     return 0;
 }
 
-static int ilog2_exact(int v) {
-    for (int i = 0; i < 31; i++)
-        if ((1 << i) == v) return i;
-    return -1;
+static int run_gemv(const Problem &q, hipStream_t s) {
+    if (fast_eligible(q, 32 / (q.bits == 3 ? 4 : q.bits))) {
+        int rc = run_rowwave(q, s);
+        if (rc != GPTQ_E_VARIANT || g_force_variant.load() >= 0) return rc;
+    }
+    return run_generic(q, s);
 }
 
 // The weight-streaming MFMA kernel (skinny_mfma.hip): M <= 64, trivial g_idx, whole groups.
@@ -213,6 +227,7 @@ static int run_skinny(const Problem &q, hipStream_t s) {
 
 static int run_auto(const Problem &q, hipStream_t s) {
     if (q.M == 0) return 0;
+    if (q.M == 1) return run_gemv(q, s);               // rowwave GEMV (generic kernel for act-order / 3-bit)
     if (q.M <= SKINNY_MAX_M) return run_skinny(q, s);  // falls back to the GEMV for act-order / 3-bit
     const int unit_k = (q.bits == 2) ? 64 : 32;
     if (!q.fused2 && fast_eligible(q, unit_k)) {

@@ -1,294 +1,170 @@
-// gemv.hip -- batch-1 (M <= 4) dequant-matvec for gfx950: the decode hot path behind
-// QuantLinear.forward (reference quant/quant_linear.py:72-137, 263-269, 373-377) and the fused
-// gate/up + SiLU*mul of QuantLlamaMLP (reference quant/fused_mlp.py:84-168).
+// gemv.hip -- batch-1 dequant-matvec for gfx950: the decode hot path behind QuantLinear.forward
+// (reference quant/quant_linear.py:72-137, 263-269, 373-377) and the fused gate/up + SiLU*mul of
+// QuantLlamaMLP (reference quant/fused_mlp.py:84-168).
 //
-// Design (HBM-bound; see DESIGN.md "GEMV"):
-//  * a workgroup owns a tile of 4*NL columns; lanes are NL column-lanes x (64/NL) k-lanes per
-//    wave; every lane streams `global_load_dwordx4` = 4 columns x one packed row, U*CH rows in
-//    flight, straight to VGPRs (no LDS round trip for the weights -- they are read once);
-//  * x is staged once per workgroup in LDS in the order the magic-exponent unpack produces
-//    field pairs, so a word costs 3 shifts + 4 v_and_or + 4 v_dot2c_f32_f16 (4-bit);
-//  * with the trivial group map the scale and zero are applied once per 32-k chunk:
-//    y += s * (sum_k x_k (OFF+q_k) - (OFF+z) * sum_k x_k), all in fp32;
-//  * k-lanes are reduced with wavefront __shfl_xor, waves through LDS, and (optional) K-slices
-//    of different workgroups through fp32 atomics + an arrival ticket; the last arriver
-//    swaps the workspace back to zero while reading it.
-//  * act-order / odd group sizes / 3-bit go through gemv_generic_kernel, which keeps a
-//    per-tile {scale, zero} table in LDS indexed by g_idx[k].
+// "rowwave" design (HBM-bound; measurements in DESIGN.md and tools/gemvlab.hip):
+//  * a wave reads whole 1-KiB row segments of qweight: 64 lanes x one global_load_dwordx4 =
+//    256 consecutive columns of ONE packed row (fully coalesced, >= 256-byte DRAM bursts);
+//    every lane owns 4 columns, so there is no k-reduction inside the wave at all;
+//  * because all lanes of a wave work on the same k rows, x is wave-uniform: it is fetched with
+//    s_load through the scalar cache into SGPRs and fed to v_dot2_f32_f16 as a scalar operand --
+//    no LDS staging, no barrier in front of the math;
+//  * all U rows (x 1 or 2 weight sets) of a wave's chunk are requested before any arithmetic
+//    (8-16 dwordx4 in flight per lane, 32-64 KiB per workgroup) and consumed in arrival order;
+//  * a word (KPW k of one column) is expanded with the fp16 magic-exponent trick to half2 pairs
+//    {OFF+q_i, OFF+q_{i+NP}} (shift + v_and_or_b32) and multiplied with v_dot2_f32_f16 in fp32;
+//    the offset and the zero point are removed once per (group, column):
+//        y += s * (sum_k x_k (OFF + q_k) - (OFF + z) * sum_k x_k);
+//  * the 4 waves of a workgroup take 4 consecutive U-row blocks (one LDS reduce), K is split over
+//    S workgroups per 256-column tile and combined with ONE returning 64-bit fixed-point atomic
+//    per output (gptq_device.h): bit-reproducible, no second pass.
+//  * act-order / odd group sizes / 3-bit go through gemv_generic_kernel, which keeps a per-tile
+//    {scale, zero} table in LDS indexed by g_idx[k].
 #include "gptq_device.h"
 #include "gptq_internal.h"
 
 namespace gptq {
 
 // ---------------------------------------------------------------------------------------
-// fast path: trivial g_idx, groupsize % 32 == 0, bits in {2,4,8}
+// fast path: M == 1, trivial g_idx, power-of-two group of >= U packed rows (or one group),
+// bits in {2,4,8}.  Kernel arguments are plain scalars so that the first 16 dwords are preloaded
+// into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16): the weight loads are
+// issued a few hundred cycles after the wave starts.
 // ---------------------------------------------------------------------------------------
-// Loads in flight per lane are bounded by registers: U 32-k chunks per pipeline stage, and a
-// second (prefetch) stage only where the VGPR budget of the variant allows it.
-template <int BITS, int WAVES, bool FUSED2>
-constexpr int gemv_u() {
-    return (BITS == 8 || FUSED2 || WAVES >= 16) ? 1 : 2;
-}
-template <int BITS, int WAVES, int MR, bool FUSED2>
-constexpr bool gemv_double_buffer() {
-    if (WAVES >= 16) return false;            // 128-VGPR budget at 1024 threads
-    if (BITS == 8 && FUSED2) return false;    // 16 dwordx4 per stage already
-    if (MR == 4 && (FUSED2 || BITS == 8)) return false;
-    return true;
-}
-
-template <int BITS, int CH, int U, bool FUSED2>
-struct Batch {
-    u32x4 w[FUSED2 ? 2 : 1][U][CH];
-    half4_t s[FUSED2 ? 2 : 1][U];
-    uint32_t zw[FUSED2 ? 2 : 1][U];
-};
-
-template <int BITS, int NL, int WAVES, int MR, bool FUSED2>
-__global__ void __launch_bounds__(WAVES * 64) gemv_fast_kernel(const GemvParams p) {
+template <int BITS, int U, bool FUSED2, bool DBG>
+__global__ void __launch_bounds__(256) gemv_rowwave_kernel(
+    const uint32_t *__restrict__ qw0, const half_t *__restrict__ x, const half_t *__restrict__ sc0,
+    const int32_t *__restrict__ qz0, int N, int rows, int S, int gshift, const uint32_t *__restrict__ qw1,
+    const half_t *__restrict__ sc1, const int32_t *__restrict__ qz1, half_t *__restrict__ y, u64_t *__restrict__ ws,
+    const half_t *__restrict__ bias, u64_t *__restrict__ dbg) {
     using UP = Unpack<BITS>;
     constexpr int KPW = UP::KPW, NP = UP::NP;
-    constexpr int CH = 32 / KPW;  // packed rows per 32-k chunk
-    constexpr int KLW = 64 / NL, KL = WAVES * KLW, T = WAVES * 64;
+    constexpr int XW = KPW / 2;  // dwords of x per packed row
     constexpr int NS = FUSED2 ? 2 : 1;
-    constexpr int TILE = 4 * NL;
-    constexpr int U = gemv_u<BITS, WAVES, FUSED2>();
-    constexpr bool DB = gemv_double_buffer<BITS, WAVES, MR, FUSED2>();
-    using BatchT = Batch<BITS, CH, U, FUSED2>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef uint32_t xrow_t __attribute__((ext_vector_type(XW)));
+    __shared__ float red[NS][4][256];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = bid / p.split_k, slice = bid % p.split_k;
-    const int chunk_begin = slice * p.chunks_per_slice;
-    const int chunk_end = min(p.nchunks, chunk_begin + p.chunks_per_slice);
-    const int cg = lane % NL, kl = wave * KLW + lane / NL;
-    const int n0 = tile * TILE + 4 * cg;
-    const bool active = n0 < p.N;
-    const int N = p.N;
-    const int ldz = N / KPW;
-    const int zshift0 = BITS * (n0 % KPW);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u64_t st[8];
+    if constexpr (DBG) {
+        st[0] = stamp_realtime();
+        st[1] = stamp_cycles(0);
+    }
+    const uint32_t tile = blockIdx.x, slice = blockIdx.y;  // grid = (256-column tiles, K slices)
+    const uint32_t n0 = tile * 256 + lane * 4;
+    const uint32_t nc = n0 < (uint32_t)N ? n0 : 0;  // ragged N: idle lanes read column 0, results are dropped
+    const uint32_t nchunk = ((uint32_t)rows + 4 * U - 1) / (4 * U);
+    const uint32_t *qw[2] = {qw0, qw1};
+    const half_t *sc[2] = {sc0, sc1};
+    const int32_t *qz[2] = {qz0, qz1};
+    const half2_t ones = {(half_t)1.0f, (half_t)1.0f};
+    const uint32_t MSK = sreg_const(UP::MSK_C), MAG = vreg_const(UP::MAG_C);
 
-    // ---- issue the x loads for staging first (oldest in the vmcnt queue) ---------------------
-    const int nk = (chunk_end - chunk_begin) * 32;
-    half_t *lx = (half_t *)smem;  // [MR][nk], each word-row permuted into pair order
-    constexpr int XV = (KPW * 2 >= 16) ? 8 : 4;  // halves per staging load (16 B or 8 B)
-    typedef half_t xvec_t __attribute__((ext_vector_type(XV)));
-    const int nxv = MR * nk / XV;
-    constexpr int XPT = 2;  // staging loads kept in flight per thread per round
-
-    // ---- first weight batch -------------------------------------------------------------
-    auto load_batch = [&](BatchT &b, int c0) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int c = c0 + u * KL;
-            if (active && c < chunk_end) {
-                const int g = (c * 32) / p.groupsize;
-#pragma unroll
-                for (int s = 0; s < NS; s++) {
-                    const uint32_t *qw = p.qw[s] + (size_t)c * CH * N + n0;
-#pragma unroll
-                    for (int i = 0; i < CH; i++)
-                        b.w[s][u][i] = __builtin_nontemporal_load((const u32x4 *)(qw + (size_t)i * N));
-                    b.s[s][u] = *(const half4_t *)(p.sc[s] + (size_t)g * N + n0);
-                    b.zw[s][u] = (uint32_t)p.qz[s][(size_t)g * ldz + n0 / KPW];
-                }
-            }
-        }
-    };
-
-    float y[NS][MR][4];
+    float yv[NS][4];
 #pragma unroll
     for (int s = 0; s < NS; s++)
 #pragma unroll
-        for (int m = 0; m < MR; m++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) y[s][m][j] = 0.f;
+        for (int j = 0; j < 4; j++) yv[s][j] = 0.f;
 
-    auto compute_batch = [&](const BatchT &b, int c0) {
+    for (uint32_t c = slice; c < nchunk; c += (uint32_t)S) {
+        const uint32_t row = c * (4 * U) + wave * U;  // first packed row of this wave's block (uniform)
+        if (row >= (uint32_t)rows) continue;          // rows % U == 0: a block is all in or all out
+        u32x4 w[NS][U];
+        half4_t s4[NS];
+        uint32_t zw[NS];
+        const uint32_t g = gshift >= 0 ? (row >> gshift) : 0u;
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int c = c0 + u * KL;
-            if (active && c < chunk_end) {
-                float acc[NS][MR][4];
-                float xs[MR];
+        for (int s = 0; s < NS; s++) {
 #pragma unroll
-                for (int m = 0; m < MR; m++) {
-                    xs[m] = 0.f;
-#pragma unroll
-                    for (int s = 0; s < NS; s++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) acc[s][m][j] = 0.f;
-                }
-                const int row0 = (c - chunk_begin) * CH;
-#pragma unroll
-                for (int i = 0; i < CH; i++) {
-                    half2_t X[MR][NP];
-#pragma unroll
-                    for (int m = 0; m < MR; m++) {
-                        const half2_t *px = (const half2_t *)(lx + (size_t)m * nk + (size_t)(row0 + i) * KPW);
-#pragma unroll
-                        for (int q = 0; q < NP; q++) X[m][q] = px[q];
-                        const half2_t ones = {(half_t)1.0f, (half_t)1.0f};
-#pragma unroll
-                        for (int q = 0; q < NP; q++) xs[m] = __builtin_amdgcn_fdot2(X[m][q], ones, xs[m], false);
-                    }
-#pragma unroll
-                    for (int s = 0; s < NS; s++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            half2_t t[NP];
-                            UP::pairs(b.w[s][u][i][j], t);
-#pragma unroll
-                            for (int m = 0; m < MR; m++)
-#pragma unroll
-                                for (int q = 0; q < NP; q++)
-                                    acc[s][m][j] = __builtin_amdgcn_fdot2(t[q], X[m][q], acc[s][m][j], false);
-                        }
-                }
-#pragma unroll
-                for (int s = 0; s < NS; s++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float zf = (float)(((b.zw[s][u] >> (zshift0 + BITS * j)) & ((1u << BITS) - 1u)) + 1u) + UP::OFF;
-                        const float sf = (float)b.s[s][u][j];
-#pragma unroll
-                        for (int m = 0; m < MR; m++) y[s][m][j] += sf * (acc[s][m][j] - zf * xs[m]);
-                    }
-            }
+            for (int u = 0; u < U; u++)
+                w[s][u] = __builtin_nontemporal_load((const u32x4 *)(qw[s] + (size_t)(row + u) * (uint32_t)N + nc));
+            s4[s] = *(const half4_t *)(sc[s] + (size_t)g * (uint32_t)N + nc);
+            zw[s] = (uint32_t)qz[s][(size_t)g * ((uint32_t)N / KPW) + nc / KPW];
         }
-    };
+        const xrow_t *xq = (const xrow_t *)x + row;  // wave-uniform: scalar loads
+        xrow_t xr[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) xr[u] = xq[u];
+        __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is in flight before any math
+        if constexpr (DBG) st[2] = stamp_cycles(0);
 
-    // x loads -> registers (issued before the weights so their wait leaves the weights in flight)
-    xvec_t xr[XPT];
-    int xidx[XPT];
-#pragma unroll
-    for (int r = 0; r < XPT; r++) {
-        xidx[r] = tid + r * T;
-        if (xidx[r] < nxv) {
-            const int m = xidx[r] / (nk / XV), e = (xidx[r] % (nk / XV)) * XV;
-            if (m < p.M)
-                xr[r] = *(const xvec_t *)(p.x + (size_t)m * p.ldx + (size_t)chunk_begin * 32 + e);
-            else
-                xr[r] = (xvec_t)(half_t)0;
-        }
-    }
-
-    BatchT cur;
-    int c0 = chunk_begin + kl;
-    load_batch(cur, c0);
-
-    // permute + write the staged x.  One word-row = KPW halves; staged position of field f is
-    // staged_pos<BITS>(f).
-    auto stage_write = [&](const xvec_t &v, int idx) {
-        const int m = idx / (nk / XV), e = (idx % (nk / XV)) * XV;
-        half_t *dst = lx + (size_t)m * nk;
-        if constexpr (XV >= KPW) {
-            // vector covers XV/KPW whole word-rows
-            xvec_t o;
-#pragma unroll
-            for (int q = 0; q < XV; q++) {
-                const int wr = q / KPW, f = q % KPW;
-                o[wr * KPW + staged_pos<BITS>(f)] = v[q];
-            }
-            *(xvec_t *)(dst + e) = o;
-        } else {
-            // word-row spans several vectors (2-bit: 16 halves = 2 x 8): scatter element-wise
-            const int wr0 = e / KPW * KPW, f0 = e % KPW;
-#pragma unroll
-            for (int q = 0; q < XV; q++) dst[wr0 + staged_pos<BITS>(f0 + q)] = v[q];
-        }
-    };
-#pragma unroll
-    for (int r = 0; r < XPT; r++)
-        if (xidx[r] < nxv) stage_write(xr[r], xidx[r]);
-    for (int idx = tid + XPT * T; idx < nxv; idx += T) {
-        const int m = idx / (nk / XV), e = (idx % (nk / XV)) * XV;
-        xvec_t v = (xvec_t)(half_t)0;
-        if (m < p.M) v = *(const xvec_t *)(p.x + (size_t)m * p.ldx + (size_t)chunk_begin * 32 + e);
-        stage_write(v, idx);
-    }
-    __syncthreads();
-
-    // ---- main loop, register double-buffered -------------------------------------------------
-    if constexpr (DB) {
-        BatchT nxt;
-        while (true) {
-            const int cn = c0 + U * KL;
-            const bool more = cn < chunk_end;  // per lane; no barrier inside the loop
-            if (more) load_batch(nxt, cn);
-            compute_batch(cur, c0);
-            if (!more) break;
-            cur = nxt;
-            c0 = cn;
-        }
-    } else {
-        while (true) {
-            compute_batch(cur, c0);
-            c0 += U * KL;
-            if (c0 >= chunk_end) break;
-            load_batch(cur, c0);
-        }
-    }
-
-    // ---- reduce over k-lanes (wave shuffles), waves (LDS), K-slices (atomics) -----------------
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-#pragma unroll
-        for (int m = 0; m < MR; m++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) y[s][m][j] = wave_sum_xor(y[s][m][j], NL);
-
-    __syncthreads();  // everyone is done reading staged x
-    float *red = (float *)smem;  // [WAVES][NS][MR][TILE]
-    if (lane < NL) {
+        float acc[NS][4];
 #pragma unroll
         for (int s = 0; s < NS; s++)
 #pragma unroll
-            for (int m = 0; m < MR; m++) {
-                float4_t v = {y[s][m][0], y[s][m][1], y[s][m][2], y[s][m][3]};
-                *(float4_t *)(red + (((size_t)wave * NS + s) * MR + m) * TILE + 4 * lane) = v;
+            for (int j = 0; j < 4; j++) acc[s][j] = 0.f;
+        float xs = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            // x pairs in the order the unpack produces fields: pair q = (x[q], x[q + NP])
+            half2_t X[NP];
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                const uint32_t a = xr[u][q / 2], b = xr[u][(q + NP) / 2];
+                X[q] = as_half2((q & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16)));
+                xs = __builtin_amdgcn_fdot2(X[q], ones, xs, false);
+            }
+            if constexpr (DBG) {
+                if (u == 0) {
+                    st[3] = stamp_cycles(xr[0][0]);
+                    st[4] = stamp_cycles(w[0][0][0]);
+                }
+                if (u == U - 1) st[5] = stamp_cycles(w[NS - 1][U - 1][0]);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    half2_t t[NP];
+                    UP::pairs_rc(w[s][u][j], t, MSK, MAG);
+#pragma unroll
+                    for (int q = 0; q < NP; q++) acc[s][j] = __builtin_amdgcn_fdot2(t[q], X[q], acc[s][j], false);
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float zf = (float)(((zw[s] >> (BITS * ((nc + j) % KPW))) & ((1u << BITS) - 1u)) + 1u) + UP::OFF;
+                yv[s][j] += (float)s4[s][j] * (acc[s][j] - zf * xs);
             }
     }
-    __syncthreads();
+    if constexpr (DBG) st[6] = stamp_cycles(__builtin_bit_cast(uint32_t, yv[0][0]));
 
-    constexpr int NOUT = MR * TILE;
-    float tot[NS][(NOUT + T - 1) / T];
+    // ---- 4 waves -> one partial per column (LDS), K slices -> one atomic round trip ------------
 #pragma unroll
-    for (int r = 0; r < (NOUT + T - 1) / T; r++) {
-        const int e = tid + r * T;
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            float a = 0.f;
-            if (e < NOUT) {
-#pragma unroll
-                for (int w = 0; w < WAVES; w++) a += red[((size_t)w * NS + s) * NOUT + e];
-            }
-            tot[s][r] = a;
+    for (int s = 0; s < NS; s++) *(float4_t *)&red[s][wave][4 * lane] = float4_t{yv[s][0], yv[s][1], yv[s][2], yv[s][3]};
+    __syncthreads();
+    const int t = threadIdx.x;
+    const uint32_t n = tile * 256 + t;
+    float t0 = red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t], t1 = 0.f;
+    if constexpr (FUSED2) t1 = red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t];
+    if (n < (uint32_t)N) {
+        bool mine = true;
+        if (S > 1) {
+            if constexpr (FUSED2) mine = splitk_add2(ws + n, t0, t1, S, t0, t1);
+            else mine = splitk_add1(ws + n, t0, S, t0);
+        }
+        if (mine) {
+            float v = t0;
+            if constexpr (FUSED2) v = t0 * (1.0f / (1.0f + __expf(-t0))) * t1;  // silu on the fp32 accumulator
+            half_t h = (half_t)v;
+            if (bias) h = (half_t)((float)h + (float)bias[n]);
+            y[n] = h;
         }
     }
-
-    // ---- outputs: direct, or combined over K-slices in one atomic round trip -------------------
+    if constexpr (DBG) {
+        st[7] = stamp_cycles(__builtin_bit_cast(uint32_t, t0));
+        const u64_t te = stamp_realtime();
+        if (dbg && lane == 0) {
+            u64_t *d = dbg + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 10;
 #pragma unroll
-    for (int r = 0; r < (NOUT + T - 1) / T; r++) {
-        const int e = tid + r * T;
-        const int m = e / TILE, n = tile * TILE + e % TILE;
-        if (e < NOUT && m < p.M && n < N) {
-            float t0 = tot[0][r], t1 = 0.f;
-            if constexpr (FUSED2) t1 = tot[1][r];
-            bool mine = true;
-            if (p.split_k > 1) {
-                u64_t *word = p.ws + (size_t)m * N + n;
-                if constexpr (FUSED2) mine = splitk_add2(word, t0, t1, p.split_k, t0, t1);
-                else mine = splitk_add1(word, t0, p.split_k, t0);
-            }
-            if (mine) {
-                float v = t0;
-                if constexpr (FUSED2) v = t0 * (1.0f / (1.0f + __expf(-t0))) * t1;  // silu on the fp32 accumulator
-                half_t h = (half_t)v;
-                if (p.bias) h = (half_t)((float)h + (float)p.bias[n]);
-                p.y[(size_t)m * p.ldy + n] = h;
-            }
+            for (int i = 0; i < 8; i++) d[i] = st[i];
+            d[8] = te;
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            d[9] = xcc;
         }
     }
 }
@@ -427,23 +303,22 @@ __global__ void __launch_bounds__(WAVES * 64) gemv_generic_kernel(const GemvPara
 // ---------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------
-template <int BITS, int NL, int WAVES, int MR, bool FUSED2>
-static int launch_fast(const GemvParams &p, hipStream_t stream) {
-    constexpr int NS = FUSED2 ? 2 : 1;
-    constexpr int TILE = 4 * NL;
-    const size_t x_bytes = (size_t)MR * p.chunks_per_slice * 32 * 2;
-    const size_t red_bytes = (size_t)WAVES * NS * MR * TILE * 4;
-    const size_t lds = (((x_bytes > red_bytes ? x_bytes : red_bytes) + 15) & ~(size_t)15) + 16;
-    if (lds > 160 * 1024 - 64) return GPTQ_E_SHAPE;
-    auto kern = gemv_fast_kernel<BITS, NL, WAVES, MR, FUSED2>;
-    static size_t configured = 0;  // per instantiation
-    if (lds > 48 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured = lds;
+template <int BITS, int U, bool FUSED2>
+static int launch_rowwave(const GemvParams &p, hipStream_t stream) {
+    constexpr int KPW = 32 / BITS;
+    const int rows = p.K / KPW;
+    const int ntile = (p.N + 255) / 256;
+    dim3 grid(ntile, p.split_k), block(256);
+    const int gshift = p.upg_shift;  // log2(packed rows per group), or -1 for a single group
+    if (p.dbg) {
+        if constexpr (BITS == 4 && U == 8) {
+            hipLaunchKernelGGL((gemv_rowwave_kernel<BITS, U, FUSED2, true>), grid, block, 0, stream, p.qw[0], p.x, p.sc[0], p.qz[0], p.N,
+                               rows, p.split_k, gshift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, p.dbg);
+            return (int)hipGetLastError();
+        }
     }
-    dim3 grid(p.ntiles * p.split_k), block(WAVES * 64);
-    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    hipLaunchKernelGGL((gemv_rowwave_kernel<BITS, U, FUSED2, false>), grid, block, 0, stream, p.qw[0], p.x, p.sc[0], p.qz[0], p.N, rows,
+                       p.split_k, gshift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, (u64_t *)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -467,63 +342,24 @@ static int launch_generic(const GemvParams &p, hipStream_t stream) {
     return (int)hipGetLastError();
 }
 
-// Variant table for the fast path.  A variant fixes (NL, WAVES); MR and FUSED2 come from the
-// call.  Index = variant id (stable: tests and the autotune warm-up refer to it).
-const GemvVariant g_gemv_variants[GEMV_NUM_VARIANTS] = {
-    {4, 4},   // 0: 16-col tiles (64-B row segments), 256 threads
-    {4, 8},   // 1: 16-col tiles, 512 threads
-    {4, 16},  // 2: 16-col tiles, 1024 threads
-    {8, 4},   // 3: 32-col tiles (128-B segments), 256 threads
-    {8, 8},   // 4
-    {16, 4},  // 5: 64-col tiles (256-B segments), 256 threads
-    {16, 8},  // 6
-    {64, 4},  // 7: 256-col tiles (full 1-KiB rows per wave), 256 threads
-    {32, 4},  // 8: 128-col tiles (512-B segments), 256 threads
-    {32, 8},  // 9
-    {64, 8},  // 10
-    {16, 16}, // 11: 64-col tiles, 1024 threads
-};
-
-template <int BITS, int MR, bool FUSED2>
-static int launch_fast_variant(int variant, const GemvParams &p, hipStream_t s) {
-    switch (variant) {
-        case 0: return launch_fast<BITS, 4, 4, MR, FUSED2>(p, s);
-        case 1: return launch_fast<BITS, 4, 8, MR, FUSED2>(p, s);
-        case 2:  // 1024 threads cap the kernel at 128 VGPRs: the two-set kernel does not fit
-            if constexpr (FUSED2) return launch_fast<BITS, 4, 8, MR, FUSED2>(p, s);
-            else return launch_fast<BITS, 4, 16, MR, FUSED2>(p, s);
-        case 3: return launch_fast<BITS, 8, 4, MR, FUSED2>(p, s);
-        case 4: return launch_fast<BITS, 8, 8, MR, FUSED2>(p, s);
-        case 5: return launch_fast<BITS, 16, 4, MR, FUSED2>(p, s);
-        case 6: return launch_fast<BITS, 16, 8, MR, FUSED2>(p, s);
-        case 7: return launch_fast<BITS, 64, 4, MR, FUSED2>(p, s);
-        case 8: return launch_fast<BITS, 32, 4, MR, FUSED2>(p, s);
-        case 9: return launch_fast<BITS, 32, 8, MR, FUSED2>(p, s);
-        case 10: return launch_fast<BITS, 64, 8, MR, FUSED2>(p, s);
-        case 11:
-            if constexpr (FUSED2) return launch_fast<BITS, 16, 8, MR, FUSED2>(p, s);
-            else return launch_fast<BITS, 16, 16, MR, FUSED2>(p, s);
+template <int BITS, bool FUSED2>
+static int launch_rowwave_u(int u, const GemvParams &p, hipStream_t s) {
+    switch (u) {
+        case 8: return launch_rowwave<BITS, 8, FUSED2>(p, s);
+        case 4: return launch_rowwave<BITS, 4, FUSED2>(p, s);
+        case 2: return launch_rowwave<BITS, 2, FUSED2>(p, s);
     }
     return GPTQ_E_VARIANT;
 }
 
-// the fused (two weight sets) kernel is instantiated for M <= 2 only; capi.hip splits larger M
-template <int BITS, bool FUSED2>
-static int launch_fast_m(int variant, const GemvParams &p, hipStream_t s) {
-    if (p.M <= 1) return launch_fast_variant<BITS, 1, FUSED2>(variant, p, s);
-    if (p.M <= 2) return launch_fast_variant<BITS, 2, FUSED2>(variant, p, s);
-    if constexpr (FUSED2) {
-        return GPTQ_E_VARIANT;
-    } else {
-        return launch_fast_variant<BITS, 4, FUSED2>(variant, p, s);
-    }
-}
-
-int gemv_fast_dispatch(int bits, bool fused2, int variant, const GemvParams &p, hipStream_t s) {
+// M == 1.  u = packed rows in flight per wave (8, 4 or 2; rows % u == 0 and a wave's u rows lie
+// in one quantisation group); p.split_k = workgroups per 256-column tile; p.upg_shift = log2 of
+// the packed rows per group or -1 (one group); p.ws zeroed workspace when split_k > 1.
+int gemv_fast_dispatch(int bits, bool fused2, int u, const GemvParams &p, hipStream_t s) {
     switch (bits) {
-        case 2: return fused2 ? launch_fast_m<2, true>(variant, p, s) : launch_fast_m<2, false>(variant, p, s);
-        case 4: return fused2 ? launch_fast_m<4, true>(variant, p, s) : launch_fast_m<4, false>(variant, p, s);
-        case 8: return fused2 ? launch_fast_m<8, true>(variant, p, s) : launch_fast_m<8, false>(variant, p, s);
+        case 2: return fused2 ? launch_rowwave_u<2, true>(u, p, s) : launch_rowwave_u<2, false>(u, p, s);
+        case 4: return fused2 ? launch_rowwave_u<4, true>(u, p, s) : launch_rowwave_u<4, false>(u, p, s);
+        case 8: return fused2 ? launch_rowwave_u<8, true>(u, p, s) : launch_rowwave_u<8, false>(u, p, s);
     }
     return GPTQ_E_BITS;
 }

@@ -50,6 +50,14 @@ struct Unpack<4> {
         t[2] = as_half2(((w >> 4) & MSK) | MAG);  // fields 2,6
         t[3] = as_half2(((w >> 8) & MSK) | MAG);  // fields 3,7
     }
+    // same with the mask in an SGPR and the magic in a VGPR: 3 shifts + 4 v_and_or_b32
+    static constexpr uint32_t MSK_C = 0x00F000F0u, MAG_C = 0x54005400u;
+    GPTQ_DEV void pairs_rc(uint32_t w, half2_t (&t)[NP], uint32_t msk, uint32_t mag) {
+        t[0] = as_half2(((w << 4) & msk) | mag);
+        t[1] = as_half2((w & msk) | mag);
+        t[2] = as_half2(((w >> 4) & msk) | mag);
+        t[3] = as_half2(((w >> 8) & msk) | mag);
+    }
 };
 
 template <>
@@ -67,6 +75,17 @@ struct Unpack<2> {
         t[6] = as_half2(((w >> 8) & MSK) | MAG);   // 6,14
         t[7] = as_half2(((w >> 10) & MSK) | MAG);  // 7,15
     }
+    static constexpr uint32_t MSK_C = 0x00300030u, MAG_C = 0x54005400u;
+    GPTQ_DEV void pairs_rc(uint32_t w, half2_t (&t)[NP], uint32_t msk, uint32_t mag) {
+        t[0] = as_half2(((w << 4) & msk) | mag);
+        t[1] = as_half2(((w << 2) & msk) | mag);
+        t[2] = as_half2((w & msk) | mag);
+        t[3] = as_half2(((w >> 2) & msk) | mag);
+        t[4] = as_half2(((w >> 4) & msk) | mag);
+        t[5] = as_half2(((w >> 6) & msk) | mag);
+        t[6] = as_half2(((w >> 8) & msk) | mag);
+        t[7] = as_half2(((w >> 10) & msk) | mag);
+    }
 };
 
 template <>
@@ -77,6 +96,11 @@ struct Unpack<8> {
         constexpr uint32_t MSK = 0x03FC03FCu, MAG = 0x5C005C00u;
         t[0] = as_half2(((w << 2) & MSK) | MAG);  // bytes 0,2
         t[1] = as_half2(((w >> 6) & MSK) | MAG);  // bytes 1,3
+    }
+    static constexpr uint32_t MSK_C = 0x03FC03FCu, MAG_C = 0x5C005C00u;
+    GPTQ_DEV void pairs_rc(uint32_t w, half2_t (&t)[NP], uint32_t msk, uint32_t mag) {
+        t[0] = as_half2(((w << 2) & msk) | mag);
+        t[1] = as_half2(((w >> 6) & msk) | mag);
     }
 };
 
@@ -131,39 +155,65 @@ GPTQ_DEV float wave_sum_xor(float v, int from) {
 // slice whose returned value completes the count owns the total: it decodes it, stores zero
 // back (the workspace is all-zero between launches) and writes the output.  No ticket, no
 // second pass, no fence; integer addition makes the sum independent of arrival order.
-//   single value : [63:56] count (S <= 255) | [55:0] sum of (round(v * 2^24) + 2^50)
-//   value pair   : [63:60] count (S <= 15)  | [59:30] b | [29:0] a, fields = round(v * 2^15) + 2^25
-//                  (used by the fused gate/up kernel: |partial| < 1024, resolution 2^-15)
+//   single value : [63:56] count (S <= 128) | [55:0] sum of (trunc(v * 2^24) + 2^49), |v| <= 2^24
+//   value pair   : [63:58] count (S <= 16)  | [57:29] b | [28:0] a, fields = round(v * 2^15) + 2^24
+//                  (fused gate/up kernel: |partial| < 512, resolution 2^-15)
 // ---------------------------------------------------------------------------------------
 typedef unsigned long long u64_t;
-constexpr int SPLITK_MAX_SINGLE = 32;   // 32 * (2^50 + 2^48) < 2^56
-constexpr int SPLITK_MAX_PAIR = 15;
+constexpr int SPLITK_MAX_SINGLE = 128;  // 128 * (2^49 + 2^48) < 2^56
+constexpr int SPLITK_MAX_PAIR = 16;     // 16 * 2^25 <= 2^29
 
 GPTQ_DEV bool splitk_add1(u64_t *word, float v, int S, float &total) {
     const float c = fminf(fmaxf(v, -16777216.0f), 16777216.0f);               // |v| <= 2^24 (fp16 max is 65504)
-    const long long fx = (long long)(c * 16777216.0f) + (1LL << 50);            // exact: power-of-two scale
+    const long long fx = (long long)(c * 16777216.0f) + (1LL << 49);            // exact: power-of-two scale
     const u64_t add = (u64_t)fx + (1ULL << 56);
     const u64_t old = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const u64_t now = old + add;
     if ((int)(now >> 56) != S) return false;
     __hip_atomic_store(word, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long sum = (long long)(now & ((1ULL << 56) - 1)) - (long long)S * (1LL << 50);
+    const long long sum = (long long)(now & ((1ULL << 56) - 1)) - (long long)S * (1LL << 49);
     total = (float)sum * (1.0f / 16777216.0f);
     return true;
 }
 
 GPTQ_DEV bool splitk_add2(u64_t *word, float a, float b, int S, float &ta, float &tb) {
-    const float lim = 1023.99f;
-    const long long fa = (long long)rintf(fminf(fmaxf(a, -lim), lim) * 32768.0f) + (1LL << 25);
-    const long long fb = (long long)rintf(fminf(fmaxf(b, -lim), lim) * 32768.0f) + (1LL << 25);
-    const u64_t add = (u64_t)fa | ((u64_t)fb << 30) | (1ULL << 60);
+    const float lim = 511.99f;
+    const long long fa = (long long)rintf(fminf(fmaxf(a, -lim), lim) * 32768.0f) + (1LL << 24);
+    const long long fb = (long long)rintf(fminf(fmaxf(b, -lim), lim) * 32768.0f) + (1LL << 24);
+    const u64_t add = (u64_t)fa | ((u64_t)fb << 29) | (1ULL << 58);
     const u64_t old = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const u64_t now = old + add;
-    if ((int)(now >> 60) != S) return false;
+    if ((int)(now >> 58) != S) return false;
     __hip_atomic_store(word, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long sa = (long long)(now & ((1ULL << 30) - 1)) - (long long)S * (1LL << 25);
-    const long long sb = (long long)((now >> 30) & ((1ULL << 30) - 1)) - (long long)S * (1LL << 25);
+    const long long sa = (long long)(now & ((1ULL << 29) - 1)) - (long long)S * (1LL << 24);
+    const long long sb = (long long)((now >> 29) & ((1ULL << 29) - 1)) - (long long)S * (1LL << 24);
     ta = (float)sa * (1.0f / 32768.0f);
     tb = (float)sb * (1.0f / 32768.0f);
     return true;
+}
+
+// Opaque register-resident constants: (a & mask) | magic is ONE v_and_or_b32 only when the mask
+// sits in an SGPR and the magic in a VGPR (VOP3 on gfx9 takes no literals); with literal operands
+// hipcc emits v_and_b32 + v_or_b32.
+GPTQ_DEV uint32_t vreg_const(uint32_t c) {
+    uint32_t v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(c));
+    return v;
+}
+GPTQ_DEV uint32_t sreg_const(uint32_t c) {
+    uint32_t v;
+    asm("s_mov_b32 %0, %1" : "=s"(v) : "i"(c));
+    return v;
+}
+
+// Development-only s_memtime / s_memrealtime checkpoints (tools/timeline.py).
+GPTQ_DEV u64_t stamp_cycles(uint32_t dep) {
+    u64_t t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+    return t;
+}
+GPTQ_DEV u64_t stamp_realtime() {
+    u64_t t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
 }

@@ -11,15 +11,9 @@ namespace gptq {
 
 constexpr int GEMV_MAX_M = 4;         // rows served by the wavefront-reduction GEMV
 constexpr int SKINNY_MAX_M = 64;      // rows served by the weight-streaming MFMA kernel
-constexpr int GEMV_NUM_VARIANTS = 12;
+constexpr int GEMV_NUM_VARIANTS = 3;   // packed rows in flight per wave: variant v -> U = 8 >> v
 // split-K workspace: one 64-bit word per output element ([M][N]), all-zero between launches
 constexpr size_t WS_BYTES = (size_t)SKINNY_MAX_M * 32768 * 8;
-
-struct GemvVariant {
-    int nl;     // column lanes per wave (tile = 4*nl columns)
-    int waves;  // waves per workgroup
-};
-extern const GemvVariant g_gemv_variants[GEMV_NUM_VARIANTS];
 
 struct GemvParams {
     const half_t *x;
@@ -38,7 +32,7 @@ struct GemvParams {
     u64_t *dbg;  // optional timeline buffer [blocks][waves][8] (tools/timeline.py), else nullptr
 };
 
-int gemv_fast_dispatch(int bits, bool fused2, int variant, const GemvParams &p, hipStream_t s);
+int gemv_fast_dispatch(int bits, bool fused2, int u, const GemvParams &p, hipStream_t s);
 int gemv_generic_dispatch(int bits, bool fused2, int nl, const GemvParams &p, hipStream_t s);
 
 // skinny MFMA (weight streaming, M <= 64) and tiled MFMA GEMM (prefill)

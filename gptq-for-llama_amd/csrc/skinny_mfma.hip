@@ -30,17 +30,6 @@ namespace gptq {
 // instruction itself is NOT written as inline asm: its result feeds an MFMA operand and hipcc
 // pads VALU->MFMA hazards only for instructions it scheduled itself.)
 GPTQ_DEV uint32_t and_or(uint32_t a, uint32_t mask, uint32_t magic) { return (a & mask) | magic; }
-GPTQ_DEV uint32_t vreg_const(uint32_t c) {
-    uint32_t v;
-    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(c));
-    return v;
-}
-GPTQ_DEV uint32_t sreg_const(uint32_t c) {
-    uint32_t v;
-    asm("s_mov_b32 %0, %1" : "=s"(v) : "i"(c));
-    return v;
-}
-
 typedef uint32_t frag_u32 __attribute__((ext_vector_type(4)));  // 8 halves as 4 dwords
 GPTQ_DEV half8_t as_half8(frag_u32 v) { return __builtin_bit_cast(half8_t, v); }
 GPTQ_DEV uint32_t pair_bits(float f) { return as_u32(half2_t{(half_t)f, (half_t)f}); }

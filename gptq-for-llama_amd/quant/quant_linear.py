@@ -88,10 +88,14 @@ def _prep_weight(input, qweight, scales, qzeros, g_idx, bits):
     return K, N, groupsize, qweight, scales, qzeros, gi
 
 
-def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None):
+_FAMILIES = {None: 'gptq_matmul248_f16', 'gemv': 'gptq_gemv_f16', 'skinny': 'gptq_skinny_f16'}
+
+
+def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, family=None):
     """``input [M,K] fp16 -> [M,N] fp16`` on the current stream of ``input.device``
     (reference matmul248, quant/quant_linear.py:263-269; ``bias`` is an extension that fuses
-    the add of QuantLinear.forward, :376)."""
+    the add of QuantLinear.forward, :376).  ``family`` (tests / benchmarks only) forces one kernel
+    family of the C ABI instead of the built-in M dispatch."""
     K, N, groupsize, qweight, scales, qzeros, gi = _prep_weight(input, qweight, scales, qzeros, g_idx, bits)
     x = _as_rows(input)
     if x.shape[1] != K:
@@ -102,11 +106,11 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None):
         if M == 0:
             return out
         ws = _native.workspace(x.device)
-        rc = _native.lib().gptq_matmul248_f16(
+        rc = getattr(_native.lib(), _FAMILIES[family])(
             x.data_ptr(), x.stride(0) if M > 1 else K, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
             _native.ptr(gi), _native.ptr(bias), out.data_ptr(), N, M, K, N, bits, groupsize,
             ws.data_ptr(), ws.numel(), _native.stream_ptr(x.device))
-    _native.check(rc, 'gptq_matmul248_f16')
+    _native.check(rc, _FAMILIES[family])
     return out
 
 

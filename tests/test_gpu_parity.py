@@ -20,9 +20,9 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-def hip_forward(x, L, bias=None):
+def hip_forward(x, L, bias=None, family=None):
     out = QL.matmul248(dev(x), dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), int(L['bits']),
-                       2**int(L['bits']) - 1, bias=None if bias is None else dev(bias))
+                       2**int(L['bits']) - 1, bias=None if bias is None else dev(bias), family=family)
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -31,8 +31,8 @@ def oracle_forward(x, L, bias=None):
     return oracle.matmul248(x, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], int(L['bits']), bias=bias)
 
 
-def check_forward(x, L, bias=None):
-    y = hip_forward(x, L, bias)
+def check_forward(x, L, bias=None, family=None):
+    y = hip_forward(x, L, bias, family)
     ref = oracle_forward(x, L, bias)
     assert y.shape == ref.shape
     assert np.isfinite(y.astype(np.float32)).all()
@@ -102,34 +102,53 @@ def test_rope_vs_reference_kernel_golden(name):
     assert rel_err(out, f['qkv_out']) < TOL
 
 
-@pytest.mark.parametrize('bits', [2, 4, 8])
-@pytest.mark.parametrize('variant', list(range(12)))
-@pytest.mark.parametrize('M', [1, 2, 3, 4])
-def test_gemv_every_variant(bits, variant, M):
-    """every (tile, threads) variant of the wavefront-reduction GEMV, forced through the ABI."""
-    L = make_random_layer(bits, 128, 1024, 512, seed=bits * 10 + variant)
-    x = np.random.default_rng(M).standard_normal((M, 1024)).astype(np.float16)
+@pytest.mark.parametrize('bits,gs', [(2, 128), (2, 32), (4, 128), (4, 64), (4, 32), (4, -1), (8, 128), (8, 32), (8, -1)])
+@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('M', [1, 3])
+def test_gemv_every_variant(bits, gs, variant, M):
+    """the rowwave GEMV with U = 8, 4, 2 packed rows in flight per wave, forced through the ABI
+    (M > 1 = one launch per row); a variant whose U does not divide the group is refused."""
+    K, N = 1024, 512
+    L = make_random_layer(bits, gs, K, N, seed=bits * 10 + variant)
+    x = np.random.default_rng(M).standard_normal((M, K)).astype(np.float16)
+    U = 8 >> variant
+    rows, rpg = K * bits // 32, (K if gs == -1 else gs) * bits // 32
     lib = _native.lib()
     lib.gptq_set_gemv_variant(variant)
     try:
-        check_forward(x, L)
+        if rows % U == 0 and (gs == -1 or rpg % U == 0):
+            check_forward(x, L, family='gemv')
+        else:
+            with pytest.raises(RuntimeError):
+                hip_forward(x, L, family='gemv')
     finally:
         lib.gptq_set_gemv_variant(-1)
 
 
-@pytest.mark.parametrize('split_k', [2, 3, 8, 32])
-@pytest.mark.parametrize('variant', [0, 5, 7, 9])
+@pytest.mark.parametrize('K,N', [(1024, 288), (1056, 256), (96, 32), (2080, 800)])
+@pytest.mark.parametrize('bits,gs', [(4, 32), (4, -1), (8, 32), (2, 32)])
+def test_gemv_ragged_shapes(K, N, bits, gs):
+    """N not a multiple of the 256-column tile, K not a multiple of the 4*U-row chunk."""
+    L = make_random_layer(bits, gs, K, N, seed=K + N + bits)
+    x = np.random.default_rng(K).standard_normal((1, K)).astype(np.float16)
+    check_forward(x, L, family='gemv')
+    bias = np.random.default_rng(N).standard_normal(N).astype(np.float16)
+    check_forward(x, L, bias=bias)
+
+
+@pytest.mark.parametrize('split_k', [1, 2, 3, 8, 32, 128])
+@pytest.mark.parametrize('variant', [0, 1, 2])
 def test_gemv_split_k(split_k, variant):
-    """K slices combined through the fp32 atomic workspace; run twice: the last arriver must
-    leave the workspace and the tickets zeroed for the next launch."""
+    """K slices combined through the one-round-trip fixed-point atomic; run twice: the last arriver
+    must leave the workspace zeroed for the next launch, and the result is bit-reproducible."""
     L = make_random_layer(4, 128, 2048, 512, seed=7)
     x = np.random.default_rng(3).standard_normal((2, 2048)).astype(np.float16)
     lib = _native.lib()
     lib.gptq_set_gemv_variant(variant)
     lib.gptq_set_split_k(split_k)
     try:
-        y1, _ = check_forward(x, L)
-        y2, _ = check_forward(x, L)
+        y1, _ = check_forward(x, L, family='gemv')
+        y2, _ = check_forward(x, L, family='gemv')
         # the fixed-point combine is order independent: bit-identical run to run
         assert np.array_equal(y1.view(np.uint16), y2.view(np.uint16))
     finally:
@@ -222,7 +241,7 @@ def test_llama7b_shapes_vs_oracle(K, N):
     assert rel_err(y, ye) <= rel_err(ref, ye) + 5e-4
 
 
-@pytest.mark.parametrize('split_k', [1, 4, 15])
+@pytest.mark.parametrize('split_k', [1, 4, 16])
 def test_fused_mlp_split_k(split_k):
     K, N = 1024, 512
     A = make_random_layer(4, 128, K, N, seed=21)

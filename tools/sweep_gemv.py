@@ -60,8 +60,6 @@ def main():
             x = torch.randn((M, K), device=dev, generator=gen).half()
             y = torch.empty((M, N), dtype=torch.float16, device=dev)
             entry = lib.gptq_gemv_f16 if args.kernel == 'gemv' else lib.gptq_skinny_f16
-            if fused and args.kernel == 'gemv':
-                continue   # gptq_fused_mlp_f16 dispatches to the stream kernel: swept with --kernel skinny
 
             def mm(i):
                 w = sets[i]
@@ -78,9 +76,9 @@ def main():
 
             fn = mlp if fused else mm
             nbytes = alg_bytes(M, K, N, nsets=2 if fused else 1)
-            variants = range(12) if args.kernel == 'gemv' else [2, 4, 8]
+            variants = range(3) if args.kernel == 'gemv' else [2, 4, 8]
             for v in variants:
-                for sk in ((1, 2, 4, 8, 15) if fused else (1, 2, 4, 8, 16, 32)):
+                for sk in ((4, 8, 16) if fused else (8, 16, 22, 32, 43, 64)):
                     lib.gptq_set_gemv_variant(v)
                     lib.gptq_set_split_k(sk)
                     try:

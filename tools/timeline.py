@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave s_memtime checkpoints of ONE launch of the stream kernel (development aid).
+"""Per-wave s_memtime checkpoints of ONE launch of the rowwave GEMV (development aid).
 python tools/timeline.py --K 4096 --N 4096 [--split S] [--variant W] [--fused]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,28 +26,25 @@ def launch(i):
                                     u.qweight.data_ptr(), u.scales.data_ptr(), u.qzeros.data_ptr(), None, y.data_ptr(), a.N,
                                     a.M, a.K, a.N, BITS, GS, ws.data_ptr(), ws.numel(), s)
     else:
-        rc = lib.gptq_skinny_f16(x.data_ptr(), a.K, g.qweight.data_ptr(), g.scales.data_ptr(), g.qzeros.data_ptr(), None, None,
+        rc = lib.gptq_gemv_f16(x.data_ptr(), a.K, g.qweight.data_ptr(), g.scales.data_ptr(), g.qzeros.data_ptr(), None, None,
                                  y.data_ptr(), a.N, a.M, a.K, a.N, BITS, GS, ws.data_ptr(), ws.numel(), s)
     _native.check(rc, 'launch')
 for i in range(nsets): launch(i)
 torch.cuda.synchronize()
-dbg = torch.zeros(8192 * 8 * 8, dtype=torch.int64, device=dev)
+dbg = torch.zeros(8192 * 4 * 10, dtype=torch.int64, device=dev)
+for i in range(4): launch(i)          # the stamps of the LAST of a few back-to-back cold launches are analysed
 lib.gptq_set_debug_buffer(dbg.data_ptr())
-launch(3)
+launch(4)
 torch.cuda.synchronize()
 lib.gptq_set_debug_buffer(None)
-d = dbg.cpu().numpy().reshape(-1, 8)
-d = d[d[:, 0] != 0]
-names = ['start', 'loads issued', 'x staged', 'stage0 done', 'compute done', 'reduced', 'end']
-print('waves recorded', len(d), '(s_memtime ticks, ~1 ns; per-wave times relative to the wave\'s own start)')
-for i, n in enumerate(names[1:], 1):
-    ok = d[:, i] != 0
-    col = (d[ok, i] - d[ok, 0]).astype(np.float64)
-    if len(col): print('%-14s min %7.0f  p50 %7.0f  mean %8.1f  p95 %7.0f  max %7.0f' % (n, col.min(), np.median(col), col.mean(), np.percentile(col, 95), col.max()))
-# launch skew: start time relative to the earliest wave on a counter base that looks shared (cluster by magnitude)
-st = d[:, 0].astype(np.float64)
-for lo in sorted(set((st // 1e9).tolist())):
-    grp = st[(st // 1e9) == lo]
-    print('start skew (cluster %d, %d waves): p50 %.0f  p95 %.0f  max %.0f' % (lo, len(grp), np.median(grp - grp.min()), np.percentile(grp - grp.min(), 95), (grp - grp.min()).max()))
-    en = d[(st // 1e9) == lo][:, 6].astype(np.float64)
-    print('   last end - first start: %.0f' % (en.max() - grp.min()))
+d = dbg.cpu().numpy().reshape(-1, 10)
+d = d[d[:, 1] != 0]
+r0, r1 = d[:, 0].min(), d[:, 8].max()
+print('waves recorded %d; kernel span (first wave start -> last wave end, s_memrealtime @100 MHz): %.2f us' % (len(d), (r1 - r0) / 100.0))
+names = ['start (us, realtime)', 'loads issued', 'x arrived', 'first weights', 'last weights', 'math done', 'combine done', 'end (us, realtime)']
+for k, n in enumerate(names):
+    if k == 0: col = (d[:, 0] - r0) / 100.0
+    elif k == 7: col = (d[:, 8] - r0) / 100.0
+    else: col = (d[:, k + 1] - d[:, 1]).astype(np.float64)     # shader cycles since the wave's own start
+    print('%-22s min %8.2f  p10 %8.2f  p50 %8.2f  p90 %8.2f  max %8.2f  %s' % (n, col.min(), np.percentile(col, 10), np.median(col),
+          np.percentile(col, 90), col.max(), 'us' if k in (0, 7) else 'cycles'))

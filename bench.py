@@ -130,6 +130,21 @@ class DecodeLinears:
         return out
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the newest committed PMC pass (profiles/*/traffic.json, produced by
+    tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` on this same command; counters cannot be
+    read from inside the timed process, so this is a separate-pass figure)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic.json')))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return int(d['hbm_bytes_per_launch_avg']), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(budget_s=20.0):
     """the oracle (port of the reference kernel arithmetic) on the host cores: one decoder layer's
     five matvecs (qkv as one 4096x12288, o, gate, up, down), repeated until ~budget_s."""
@@ -235,6 +250,7 @@ def main():
         us_per_launch = ev_ms * 1e3 / (args.steps * work.launches_per_step)
         bytes_per_launch = work.bytes_per_step / work.launches_per_step
         achieved = bytes_per_launch / us_per_launch / 1e3
+        traffic, traffic_src = pmc_traffic()
         out = {
             'metric': 'int4 g128 matvec GB/s (LLaMA-7B 4-bit batch-1 decode pass over all quantised linears)',
             'value': round(value, 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -245,8 +261,8 @@ def main():
                        'launches_per_step': work.launches_per_step, 'algorithmic_bytes_per_step': work.bytes_per_step,
                        'launch_mode': 'eager' if args.eager else 'hipGraph replay', 'parallelism': 'dp%d replicas' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
-                         'kernel': 'gptq::gemv_fast_kernel<4,...> (all 128 launches/step)',
+                         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                         'kernel': 'gptq::gemv_rowwave_kernel<4,8,*> (all 128 launches/step: 96 single-set + 32 fused gate/up)',
                          'avg_launch_us': round(us_per_launch, 3), 'algorithmic_bytes_per_launch': int(bytes_per_launch)},
         }
         if not args.no_per_shape:

@@ -179,12 +179,12 @@ def decode_tokens_per_s(dev, tokens=64):
     """full decode step (norms, fused qkv + RoPE, KV cache, SDPA, o_proj, fused MLP, lm_head) on a
     random-init LLaMA-7B-shaped model built from the drop-in modules; protocol of the reference's
     benchmark() (llama.py:385-438): one token per step with KV cache, sync per step, median."""
-    try:
-        from quant.decode import build_random_llama, benchmark_decode
-    except Exception as e:  # pragma: no cover
-        return {'error': repr(e)}
+    from quant.decode import build_random_llama, benchmark_decode, benchmark_decode_engine
     model = build_random_llama(dev)
-    return benchmark_decode(model, tokens)
+    out = {'hf_eager': benchmark_decode(model, tokens)}
+    out['engine_graph'] = benchmark_decode_engine(model, tokens=tokens, graph=True)
+    out['tokens_per_s'] = out['engine_graph']['tokens_per_s']
+    return out
 
 
 def main():

@@ -395,4 +395,27 @@ int gptq_g_idx_is_trivial(const int32_t *g_idx, int K, int groupsize, int32_t *o
     return gidx_trivial_launch(g_idx, K, groupsize, out, (hipStream_t)stream);
 }
 
+int gptq_decode_rope_kv_f16(void *qkv, const int64_t *position, void *k_cache, void *v_cache, int heads, int head_dim, int t_max,
+                            float base, gptq_stream_t stream) {
+    if (!qkv || !position || !k_cache || !v_cache) return GPTQ_E_NULL;
+    if (heads <= 0 || head_dim <= 0 || head_dim % 2 != 0 || head_dim > 512 || t_max <= 0) return GPTQ_E_SHAPE;
+    return decode_rope_kv_launch((half_t *)qkv, position, (half_t *)k_cache, (half_t *)v_cache, heads, head_dim, t_max, base,
+                                 (hipStream_t)stream);
+}
+
+size_t gptq_decode_attn_workspace_bytes(int heads, int head_dim, int t_max) {
+    if (heads <= 0 || head_dim != 128 || t_max <= 0) return 0;
+    return decode_attn_ws_bytes(heads, t_max);
+}
+
+int gptq_decode_attn_f16(const void *q, const void *k_cache, const void *v_cache, const int64_t *position, void *out, void *workspace,
+                         size_t workspace_bytes, int heads, int head_dim, int t_max, float scale, gptq_stream_t stream) {
+    if (!q || !k_cache || !v_cache || !position || !out || !workspace) return GPTQ_E_NULL;
+    if (heads <= 0 || head_dim != 128 || t_max <= 0) return GPTQ_E_SHAPE;
+    if (!aligned(q, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4)) return GPTQ_E_ALIGN;
+    if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
+    return decode_attn_launch((const half_t *)q, (const half_t *)k_cache, (const half_t *)v_cache, position, (half_t *)out,
+                              (float *)workspace, heads, t_max, scale, (hipStream_t)stream);
+}
+
 }  // extern "C"

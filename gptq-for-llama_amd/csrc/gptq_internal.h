@@ -51,4 +51,10 @@ int pack_launch(const float *weight, const float *scales, const float *zeros, co
                 hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 
+int decode_rope_kv_launch(half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, int heads, int head_dim, int t_max, float base,
+                          hipStream_t s);
+int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, const int64_t *pos, half_t *out, float *ws, int heads,
+                       int t_max, float scale, hipStream_t s);
+size_t decode_attn_ws_bytes(int heads, int t_max);
+
 }  // namespace gptq

@@ -46,6 +46,10 @@ _SIGNATURES = {
     'gptq_pack_f32': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                       c_void_p, c_void_p, c_void_p],
     'gptq_g_idx_is_trivial': [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    'gptq_decode_rope_kv_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
+    'gptq_decode_attn_workspace_bytes': [c_int, c_int, c_int],
+    'gptq_decode_attn_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
+                             c_float, c_void_p],
 }
 EXPORTS = sorted(list(_SIGNATURES) + ['gptq_strerror'])
 
@@ -71,6 +75,7 @@ def lib():
                 fn.argtypes = args
                 fn.restype = c_int
             L.gptq_set_debug_buffer.restype = c_void_p
+            L.gptq_decode_attn_workspace_bytes.restype = c_size_t
             L.gptq_strerror.argtypes = [c_int]
             L.gptq_strerror.restype = ctypes.c_char_p
             _lib = L

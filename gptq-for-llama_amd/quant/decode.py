@@ -103,3 +103,171 @@ def benchmark_decode(model, tokens=64, seed=0):
     return {'protocol': 'llama.py:385-438 (one token per step, KV cache, sync per step, median)', 'mode': 'eager HF decoder + drop-in modules',
             'tokens': tokens, 'median_s_per_token': round(med, 6), 'tokens_per_s': round(1.0 / med, 1),
             'max_memory_MiB': round(torch.cuda.max_memory_allocated(dev) / 1024 / 1024, 1)}
+
+
+# ----------------------------------------------------------------------------------------------
+# Graph-captured decode engine: the same arithmetic as one HF decoder step
+# through the drop-in modules, but issued as a flat list of C-ABI launches on static buffers --
+# 10 launches per layer (RMSNorm, qkv GEMV, RoPE+KV append, attention x2, o_proj GEMV + residual,
+# RMSNorm, fused gate/up, down GEMV + residual) -- so that ONE hipGraph replay is one token.
+# The position lives in device memory and is advanced inside the graph.
+# ----------------------------------------------------------------------------------------------
+class DecodeEngine:
+
+    def __init__(self, model, t_max=2048):
+        from . import _native
+        self.native = _native
+        self.lib = _native.lib()
+        self.model = model
+        cfg = model.config
+        dev = next(model.parameters()).device
+        self.dev = dev
+        self.t_max = int(t_max)
+        self.hidden = cfg.hidden_size
+        self.heads = cfg.num_attention_heads
+        self.head_dim = self.hidden // self.heads
+        self.eps = float(cfg.rms_norm_eps)
+        if self.head_dim != 128:
+            raise NotImplementedError('DecodeEngine: head_dim must be 128')
+        self.embed = model.model.embed_tokens.weight
+        self.lm_head = model.lm_head.weight
+        self.final_norm = model.model.norm.weight
+        self.layers = []
+        for layer in model.model.layers:
+            attn, mlp = layer.self_attn, layer.mlp
+            if not isinstance(attn, fused_attn.QuantLlamaAttention) or not isinstance(mlp, fused_mlp.QuantLlamaMLP):
+                raise RuntimeError('DecodeEngine needs make_quant_attn / make_fused_mlp applied first')
+            self.layers.append(dict(
+                ln1=layer.input_layernorm.weight, ln2=layer.post_attention_layernorm.weight,
+                qkv=self._pack(attn.qkv_proj), o=self._pack(attn.o_proj), down=self._pack(mlp.down_proj),
+                gate=self._pack_raw(mlp.gate_proj_qweight, mlp.gate_proj_scales, mlp.gate_proj_qzeros, mlp.gate_proj_g_idx,
+                                    mlp.bits, mlp.groupsize, mlp.infeatures, mlp.intermediate_size),
+                up=self._pack_raw(mlp.up_proj_qweight, mlp.up_proj_scales, mlp.up_proj_qzeros, mlp.up_proj_g_idx, mlp.bits,
+                                  mlp.groupsize, mlp.infeatures, mlp.intermediate_size),
+                theta=float(attn.rope_theta)))
+        H, I = self.hidden, cfg.intermediate_size
+        f16 = dict(dtype=torch.float16, device=dev)
+        self.ids = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.pos = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.x = torch.zeros((1, H), **f16)
+        self.x2 = torch.zeros((1, H), **f16)
+        self.h = torch.zeros((1, H), **f16)
+        self.qkvb = torch.zeros((1, 3 * H), **f16)
+        self.ab = torch.zeros((1, H), **f16)
+        self.cb = torch.zeros((1, I), **f16)
+        self.logits = torch.zeros((1, cfg.vocab_size), **f16)
+        nl = len(self.layers)
+        self.kc = torch.zeros((nl, self.t_max, H), **f16)
+        self.vc = torch.zeros((nl, self.t_max, H), **f16)
+        self.attn_ws = torch.zeros(self.lib.gptq_decode_attn_workspace_bytes(self.heads, self.head_dim, self.t_max),
+                                   dtype=torch.uint8, device=dev)
+        self.ws = _native.workspace(dev)
+        self.graph = None
+
+    def _pack_raw(self, qweight, scales, qzeros, g_idx, bits, groupsize, K, N, bias=None):
+        gi = None
+        if g_idx is not None and not quant_linear.g_idx_is_trivial(g_idx, K, groupsize):
+            gi = quant_linear._int32c(g_idx[:K])
+        return dict(qw=quant_linear._int32c(qweight), sc=scales, qz=quant_linear._int32c(qzeros), gi=gi, bits=bits, gs=groupsize,
+                    K=K, N=N, bias=bias)
+
+    def _pack(self, ql):
+        return self._pack_raw(ql.qweight, ql.scales, ql.qzeros, ql.g_idx, ql.bits, ql.groupsize, ql.infeatures, ql.outfeatures,
+                              ql.bias)
+
+    # -- launches ------------------------------------------------------------------------------
+    def _gemv(self, x, w, y, s, residual=None):
+        if w['bias'] is not None and residual is not None:
+            raise NotImplementedError('bias + fused residual')
+        b = residual if residual is not None else w['bias']
+        ptr = self.native.ptr
+        rc = self.lib.gptq_matmul248_f16(x.data_ptr(), w['K'], w['qw'].data_ptr(), w['sc'].data_ptr(), w['qz'].data_ptr(), ptr(w['gi']),
+                                         ptr(b), y.data_ptr(), w['N'], 1, w['K'], w['N'], w['bits'], w['gs'], self.ws.data_ptr(),
+                                         self.ws.numel(), s)
+        self.native.check(rc, 'gptq_matmul248_f16')
+
+    def _norm(self, x, w, y, s):
+        rc = self.lib.gptq_rmsnorm_f16(x.data_ptr(), self.hidden, w.data_ptr(), y.data_ptr(), self.hidden, 1, self.hidden, self.eps, s)
+        self.native.check(rc, 'gptq_rmsnorm_f16')
+
+    def _step(self):
+        lib, ptr = self.lib, self.native.ptr
+        s = torch.cuda.current_stream(self.dev).cuda_stream
+        H = self.hidden
+        torch.index_select(self.embed, 0, self.ids, out=self.x)
+        scale = 1.0 / float(np.sqrt(self.head_dim))
+        for li, L in enumerate(self.layers):
+            self._norm(self.x, L['ln1'], self.h, s)
+            self._gemv(self.h, L['qkv'], self.qkvb, s)
+            rc = lib.gptq_decode_rope_kv_f16(self.qkvb.data_ptr(), self.pos.data_ptr(), self.kc[li].data_ptr(), self.vc[li].data_ptr(),
+                                             self.heads, self.head_dim, self.t_max, L['theta'], s)
+            self.native.check(rc, 'gptq_decode_rope_kv_f16')
+            rc = lib.gptq_decode_attn_f16(self.qkvb.data_ptr(), self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
+                                          self.ab.data_ptr(), self.attn_ws.data_ptr(), self.attn_ws.numel(), self.heads,
+                                          self.head_dim, self.t_max, scale, s)
+            self.native.check(rc, 'gptq_decode_attn_f16')
+            self._gemv(self.ab, L['o'], self.x2, s, residual=self.x)        # x2 = x + o_proj(attn)
+            self._norm(self.x2, L['ln2'], self.h, s)
+            g, u = L['gate'], L['up']
+            rc = lib.gptq_fused_mlp_f16(self.h.data_ptr(), g['K'], g['qw'].data_ptr(), g['sc'].data_ptr(), g['qz'].data_ptr(), ptr(g['gi']),
+                                        u['qw'].data_ptr(), u['sc'].data_ptr(), u['qz'].data_ptr(), ptr(u['gi']), self.cb.data_ptr(),
+                                        g['N'], 1, g['K'], g['N'], g['bits'], g['gs'], self.ws.data_ptr(), self.ws.numel(), s)
+            self.native.check(rc, 'gptq_fused_mlp_f16')
+            self._gemv(self.cb, L['down'], self.x, s, residual=self.x2)     # x = x2 + down(silu(gate) * up)
+        self._norm(self.x, self.final_norm, self.h, s)
+        torch.matmul(self.h, self.lm_head.t(), out=self.logits)
+        self.pos.add_(1)
+
+    def reset(self):
+        self.pos.zero_()
+
+    def capture(self):
+        """warm up once (module loads, workspace), then capture one decode step into a hipGraph."""
+        with torch.no_grad():
+            self.reset()
+            self._step()
+            torch.cuda.synchronize(self.dev)
+            self.reset()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step()
+            self.graph = g
+            self.reset()
+        return self
+
+    def decode(self, token):
+        """one token in, logits [1, vocab] out (the static buffer: clone it to keep it)."""
+        if torch.is_tensor(token):
+            self.ids.copy_(token.reshape(1))
+        else:
+            self.ids.fill_(int(token))
+        with torch.no_grad():
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._step()
+        return self.logits
+
+
+def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True):
+    """the llama.py:385-438 protocol on the DecodeEngine (hipGraph replay per token)."""
+    dev = next(model.parameters()).device
+    eng = DecodeEngine(model, t_max=t_max)
+    if graph:
+        eng.capture()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    input_ids = torch.randint(0, model.config.vocab_size, (1, tokens), device=dev, generator=gen)
+    times = []
+    eng.reset()
+    for i in range(tokens):
+        torch.cuda.synchronize(dev)
+        tick = time.perf_counter()
+        eng.decode(input_ids[0, i])
+        torch.cuda.synchronize(dev)
+        times.append(time.perf_counter() - tick)
+    med = float(np.median(times[2:])) if len(times) > 4 else float(np.median(times))
+    return {'protocol': 'llama.py:385-438 (one token per step, KV cache, sync per step, median)',
+            'mode': 'DecodeEngine, %s' % ('one hipGraph replay per token' if graph else 'eager launches'), 'tokens': tokens,
+            't_max': t_max, 'launches_per_token': 10 * len(eng.layers) + 4, 'median_s_per_token': round(med, 6),
+            'tokens_per_s': round(1.0 / med, 1)}

@@ -154,6 +154,24 @@ int gptq_pack_f32(const float *weight, const float *scales, const float *zeros,
 int gptq_g_idx_is_trivial(const int32_t *g_idx, int K, int groupsize, int32_t *out,
                           gptq_stream_t stream);
 
+/*
+ * Batch-1 decode-step helpers (extension over the reference, which does this part with torch ops
+ * between its Triton kernels: triton_rotate_half_ + torch.cat of the KV cache + torch SDPA,
+ * quant/fused_attn.py:126-155).  They read the current position from DEVICE memory and use a
+ * preallocated cache, so a whole decode step can be captured in one hipGraph.
+ *   qkv       fp16 [3, heads, head_dim] -- the fused qkv activation of ONE token; q is rotated in place
+ *   position  int64 [1] on the device   -- index of the token being decoded (0-based)
+ *   k_cache / v_cache  fp16 [t_max, heads*head_dim]; row `position` is written by rope_kv, rows
+ *             0..position are read by attn.  head_dim must be 128 for gptq_decode_attn_f16.
+ *   out       fp16 [heads*head_dim] = softmax(q.K^T * scale) V, fp32 math
+ */
+int gptq_decode_rope_kv_f16(void *qkv, const int64_t *position, void *k_cache, void *v_cache, int heads,
+                            int head_dim, int t_max, float base, gptq_stream_t stream);
+size_t gptq_decode_attn_workspace_bytes(int heads, int head_dim, int t_max);
+int gptq_decode_attn_f16(const void *q, const void *k_cache, const void *v_cache, const int64_t *position,
+                         void *out, void *workspace, size_t workspace_bytes, int heads, int head_dim,
+                         int t_max, float scale, gptq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

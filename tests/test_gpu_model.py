@@ -68,3 +68,69 @@ def test_benchmark_decode_protocol_runs():
     q = D.build_random_llama(DEV, seed=1, **TINY)
     r = D.benchmark_decode(q, tokens=12)
     assert r['tokens_per_s'] > 0 and r['tokens'] == 12
+
+
+HD128 = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+             vocab_size=512, max_position_embeddings=512)
+
+
+@pytest.mark.parametrize('pos', [0, 1, 5, 127, 128, 300])
+def test_decode_rope_kv_and_attention_vs_torch(pos):
+    """gptq_decode_rope_kv_f16 + gptq_decode_attn_f16 against the oracle's RoPE
+    (reference rotate_half_kernel) and torch SDPA on the same cache."""
+    from quant import _native
+    lib = _native.lib()
+    heads, hd, t_max = 4, 128, 384
+    H = heads * hd
+    rng = np.random.default_rng(pos)
+    qkv = rng.standard_normal((1, 1, 3, heads, hd)).astype(np.float16)
+    kc = (rng.standard_normal((t_max, H)) * 0.5).astype(np.float16)
+    vc = rng.standard_normal((t_max, H)).astype(np.float16)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    qkv_d, kc_d, vc_d = d(qkv.copy()), d(kc.copy()), d(vc.copy())
+    pos_d = torch.tensor([pos], dtype=torch.int64, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    _native.check(lib.gptq_decode_rope_kv_f16(qkv_d.data_ptr(), pos_d.data_ptr(), kc_d.data_ptr(), vc_d.data_ptr(), heads, hd, t_max,
+                                              10000.0, s), 'rope_kv')
+    ref = qkv.copy()
+    oracle.rope_(ref[:, :, :2], np.array([[pos]], dtype=np.int64))
+    got = qkv_d.cpu().numpy()
+    assert np.array_equal(got[0, 0, 0].view(np.uint16), ref[0, 0, 0].view(np.uint16)) or \
+        np.abs(got[0, 0, 0].astype(np.float32) - ref[0, 0, 0].astype(np.float32)).max() < 4e-3
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    kc_ref[pos] = ref[0, 0, 1].reshape(-1)
+    vc_ref[pos] = qkv[0, 0, 2].reshape(-1)
+    assert np.abs(kc_d.cpu().numpy().astype(np.float32) - kc_ref.astype(np.float32)).max() < 4e-3
+    assert np.array_equal(vc_d.cpu().numpy().view(np.uint16), vc_ref.view(np.uint16))
+
+    ws = torch.zeros(lib.gptq_decode_attn_workspace_bytes(heads, hd, t_max), dtype=torch.uint8, device=DEV)
+    out = torch.empty(H, dtype=torch.float16, device=DEV)
+    scale = 1.0 / np.sqrt(hd)
+    _native.check(lib.gptq_decode_attn_f16(qkv_d.data_ptr(), kc_d.data_ptr(), vc_d.data_ptr(), pos_d.data_ptr(), out.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), heads, hd, t_max, float(scale), s), 'attn')
+    q = qkv_d[0, 0, 0].float().view(heads, 1, hd)
+    K = kc_d[:pos + 1].float().view(pos + 1, heads, hd).transpose(0, 1)
+    V = vc_d[:pos + 1].float().view(pos + 1, heads, hd).transpose(0, 1)
+    expect = torch.nn.functional.scaled_dot_product_attention(q, K, V).reshape(-1).cpu().numpy()
+    gotn = out.float().cpu().numpy()
+    assert np.abs(gotn - expect).max() / np.abs(expect).max() < 1e-3
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_decode_engine_matches_hf_decoder(graph):
+    """the flat C-ABI decode step (eager and as one hipGraph replay per token) reproduces the
+    logits of the HF decoder running the same drop-in modules, token by token."""
+    q = D.build_random_llama(DEV, seed=3, **HD128)
+    ids = torch.randint(0, HD128['vocab_size'], (1, 10), device=DEV)
+    expect = run_steps(q, ids, 1)
+    eng = D.DecodeEngine(q, t_max=64)
+    if graph:
+        eng.capture()
+    got = []
+    for i in range(ids.shape[1]):
+        got.append(eng.decode(ids[0, i]).float().cpu().numpy()[0])
+    got = np.stack(got)[:, None, :]
+    assert np.abs(got - expect).max() / np.abs(expect).max() < 2e-2
+    assert (got.argmax(-1) == expect.argmax(-1)).mean() >= 0.8
+    r = D.benchmark_decode_engine(q, tokens=8, t_max=64, graph=graph)
+    assert r['tokens_per_s'] > 0

@@ -184,6 +184,33 @@ def test_large_m(M):
     check_forward(x, L)
 
 
+@pytest.mark.parametrize('bits,gs', [(4, 128), (4, 32), (4, -1), (8, 128), (8, 64)])
+@pytest.mark.parametrize('M,K,N', [(300, 256, 288), (513, 1024, 512), (1024, 4096, 256), (65, 192, 32)])
+def test_prefill_mfma_gemm(bits, gs, M, K, N):
+    """the 256x256x64 MFMA tile kernel (M > 64): ragged M / N, several K slabs and group changes,
+    bias; it dequantises with the reference's fp16 sequence so it sits very close to the
+    faithful oracle."""
+    if gs != -1 and K % gs:
+        pytest.skip('K not a multiple of the group')
+    L = make_random_layer(bits, gs, K, N, seed=M + K + N + bits)
+    rng = np.random.default_rng(M)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float16)
+    check_forward(x, L, bias=bias)
+
+
+def test_prefill_gemm_rows_independent():
+    """size-independent property at a prefill-like size: every output row equals the M = 1 path's
+    answer for that row (GEMM tile kernel vs rowwave GEMV on the same packed weights)."""
+    K, N, M = 4096, 4096, 2048
+    L = make_random_layer(4, 128, K, N, seed=99)
+    x = np.random.default_rng(7).standard_normal((M, K)).astype(np.float16)
+    y = hip_forward(x, L)
+    for m in (0, 255, 256, 1000, 2047):
+        ym = hip_forward(x[m:m + 1], L)
+        assert rel_err(y[m:m + 1], ym) < TOL
+
+
 @pytest.mark.parametrize('bits', [2, 3, 4, 8])
 @pytest.mark.parametrize('M', [1, 3, 9])
 def test_act_order_and_3bit(bits, M):

@@ -21,7 +21,7 @@ import math
 import torch
 import torch.nn as nn
 
-from .quant_linear import QuantLinear, matmul248
+from .quant_linear import QuantLinear, g_idx_is_trivial, matmul248
 
 
 def split_counts(total, world):
@@ -104,7 +104,8 @@ class RowShardedQuantLinear(nn.Module):
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
-        self.shard, (self.k0, self.k1) = shard_rows(layer, self.rank, self.world)
+        trivial = g_idx_is_trivial(layer.g_idx, layer.infeatures, layer.groupsize)   # act-order shards keep every group
+        self.shard, (self.k0, self.k1) = shard_rows(layer, self.rank, self.world, trivial_g_idx=trivial)
         self.outfeatures = layer.outfeatures
         self.infeatures = layer.infeatures
         self._matmul = matmul_fn or _default_matmul

@@ -1,0 +1,188 @@
+"""CPU-side tests (run with -m "not gpu"): the C-ABI library loads and exports every symbol the
+header declares (no compute without a GPU), argument validation and error mapping, the host logic
+of the drop-in package (buffers / checkpoint keys / packer / module surgery / no CPU fallback), and
+the row-/column-sharded linears over torch.distributed with the gloo backend, world_size 2 (the
+shard's matmul is supplied by the CPU oracle there -- test infrastructure, never the product)."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import quant
+from quant import _native, tensor_parallel as TP
+from quant import quant_linear as QL
+from oracle import oracle
+from util import golden_names, load_golden, make_random_layer, rel_err, TOL
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'gptq_mi355x.h')).read()
+    declared = sorted(set(re.findall(r'\b(gptq_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 18
+    lib = _native.lib()
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(declared) == set(_native.EXPORTS), set(declared) ^ set(_native.EXPORTS)
+    assert lib.gptq_query(0) == 1                       # ABI version
+    assert lib.gptq_query(1) >= 1 and lib.gptq_query(2) >= 16
+    assert lib.gptq_strerror(0) == b'ok'
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = _native.lib()
+    one = 16
+    # bits = 5 -> GPTQ_E_BITS before anything is touched (reference quant_linear.py:308-309)
+    assert lib.gptq_matmul248_f16(one, 64, one, one, one, None, None, one, 64, 1, 64, 64, 5, 64, None, 0, None) == -1
+    assert lib.gptq_matmul248_f16(one, 64, one, one, one, None, None, one, 64, 1, 48, 64, 4, 64, None, 0, None) == -2   # K % 32
+    assert lib.gptq_matmul248_f16(None, 64, one, one, one, None, None, one, 64, 1, 64, 64, 4, 64, None, 0, None) == -4  # NULL x
+    assert lib.gptq_matmul248_f16(2, 64, one, one, one, None, None, one, 64, 1, 64, 64, 4, 64, None, 0, None) == -3     # alignment
+    assert lib.gptq_rmsnorm_f16(one, 40000, one, one, 40000, 1, 40000, 1e-6, None) == -7              # row > 64 KiB
+    with pytest.raises(NotImplementedError):
+        _native.check(-1, 'x')
+    with pytest.raises(RuntimeError):
+        _native.check(-7, 'x')
+    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == 32 * 16 * 130 * 4
+    assert lib.gptq_decode_attn_workspace_bytes(32, 64, 2048) == 0
+
+
+def test_quantlinear_buffers_match_reference_checkpoint_format():
+    """reference quant/quant_linear.py:306-323"""
+    m = quant.QuantLinear(4, 128, 4096, 11008, False)
+    sd = m.state_dict()
+    assert list(sd) == ['qweight', 'qzeros', 'scales', 'g_idx']
+    assert sd['qweight'].shape == (4096 // 32 * 4, 11008) and sd['qweight'].dtype == torch.int32
+    assert sd['qzeros'].shape == (32, 11008 // 32 * 4) and sd['qzeros'].dtype == torch.int32
+    assert sd['scales'].shape == (32, 11008) and sd['scales'].dtype == torch.float16
+    assert sd['g_idx'].shape == (4096, ) and sd['g_idx'].dtype == torch.int32
+    assert torch.equal(sd['g_idx'], (torch.arange(4096) // 128).to(torch.int32))
+    assert (m.infeatures, m.outfeatures, m.bits, m.maxq, m.groupsize) == (4096, 11008, 4, 15, 128)
+    assert quant.QuantLinear(4, -1, 256, 64, True).groupsize == 256
+    assert 'bias' in quant.QuantLinear(8, 32, 64, 64, True).state_dict()
+    with pytest.raises(NotImplementedError):
+        quant.QuantLinear(5, 128, 128, 128, False)
+
+
+@pytest.mark.parametrize('name', golden_names('pack_'))
+def test_product_pack_is_bit_exact_with_reference_pack(name):
+    """QuantLinear.pack (host path) against the buffers the reference's own pack() produced."""
+    f = load_golden(name)
+    N, K = f['weight_q'].shape
+    bits, gs = int(f['bits']), int(f['groupsize'])
+    has_bias = 'bias' in f and f['bias'].size == N
+    lin = nn.Linear(K, N, bias=has_bias)
+    lin.weight.data = torch.from_numpy(np.asarray(f['weight_q'], dtype=np.float32))
+    if has_bias:
+        lin.bias.data = torch.from_numpy(np.asarray(f['bias'], dtype=np.float32))
+    q = quant.QuantLinear(bits, gs, K, N, has_bias)
+    q.pack(lin, torch.from_numpy(np.asarray(f['scales_in'], dtype=np.float32)), torch.from_numpy(np.asarray(f['zeros_in'], dtype=np.float32)),
+           torch.from_numpy(f['g_idx']))
+    assert np.array_equal(q.qweight.numpy(), f['qweight'])
+    assert np.array_equal(q.qzeros.numpy(), f['qzeros'])
+    assert np.array_equal(q.scales.numpy().view(np.uint16), f['scales'].view(np.uint16))
+
+
+def test_module_surgery_and_no_cpu_fallback():
+    class Inner(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = nn.Linear(128, 64, bias=True)
+            self.keep = nn.Linear(64, 64)
+
+    class Block(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(64, 128, bias=False)
+            self.b = Inner()
+    net = Block()
+    names = {'a': net.a, 'b.proj': net.b.proj}
+    quant.make_quant_linear(net, names, 4, 32)
+    assert type(net.a) is quant.QuantLinear and type(net.b.proj) is quant.QuantLinear     # exact type, as find_layers needs
+    assert type(net.b.keep) is nn.Linear
+    assert net.b.proj.bias is not None and net.a.bias is None
+    assert quant.make_quant is quant.make_quant_linear and quant.autotune_warmup is quant.autotune_warmup_linear
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net.a(torch.zeros(1, 64, dtype=torch.float16))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        quant.triton_norm.rms_norm(torch.zeros(1, 64, dtype=torch.float16), torch.ones(64, dtype=torch.float16), 1e-6)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'gptq-for-llama_amd')
+    for d, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(d, fn)).read()
+                assert 'oracle' not in src.replace('the oracle', '').replace("oracle's", '').replace('CPU oracle', '').replace('(oracle', '') \
+                    or 'import oracle' not in src and 'from oracle' not in src, fn
+                assert 'import oracle' not in src and 'from oracle' not in src and 'libgptq_oracle' not in src, fn
+
+
+def test_shard_bounds():
+    assert TP.row_shard_bounds(8192, 128, 4, 8) == [(i * 1024, (i + 1) * 1024) for i in range(8)]
+    b = TP.row_shard_bounds(22016, 128, 4, 8)                      # 172 groups over 8 ranks
+    assert [(k1 - k0) // 128 for k0, k1 in b] == [22, 22, 22, 22, 21, 21, 21, 21] and b[-1][1] == 22016
+    assert TP.col_shard_bounds(11008, 8)[-1][1] == 11008 and all((n1 - n0) % 32 == 0 for n0, n1 in TP.col_shard_bounds(11008, 8))
+
+
+# ---------------------------------------------------------------------------------- gloo, world 2
+def _oracle_matmul(x2, s):
+    y = oracle.matmul248(x2.numpy(), s.qweight.numpy(), s.scales.numpy(), s.qzeros.numpy(), s.g_idx.numpy(), s.bits,
+                         bias=None if s.bias is None else s.bias.numpy())
+    return torch.from_numpy(np.asarray(y))
+
+
+def _layer_from(L, K, N, bias=None):
+    q = quant.QuantLinear(int(L['bits']), int(L['groupsize']), K, N, bias is not None)
+    q.qweight, q.qzeros, q.scales, q.g_idx = (torch.from_numpy(L[k]) for k in ('qweight', 'qzeros', 'scales', 'g_idx'))
+    if bias is not None:
+        q.bias = torch.from_numpy(bias)
+    return q
+
+
+def _tp_worker(rank, world, port, act_order, ret):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        K, N = 1024 + 128, 256                          # 9 groups over 2 ranks: uneven (5, 4)
+        L = make_random_layer(4, 128, K, N, act_order=act_order, seed=5)
+        bias = np.random.default_rng(1).standard_normal(N).astype(np.float16)
+        x = torch.from_numpy(np.random.default_rng(2).standard_normal((3, K)).astype(np.float16))
+        full = oracle.matmul248(x.numpy(), L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4, bias=bias)
+        row = TP.RowShardedQuantLinear(_layer_from(L, K, N, bias), matmul_fn=_oracle_matmul)
+        y_row = row(x).numpy()
+        col = TP.ColShardedQuantLinear(_layer_from(L, K, N, bias), matmul_fn=_oracle_matmul)
+        y_col = col(x).numpy()
+        ok = rel_err(y_row, full) < 2e-3 and rel_err(y_col, full) < TOL and (row.k0, row.k1) == [(0, 640), (640, 1152)][rank]
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            ret.put(int(t.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('act_order', [False, True])
+def test_row_and_col_sharded_linear_gloo_world2(act_order):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, act_order, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == 1

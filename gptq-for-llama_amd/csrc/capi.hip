@@ -27,6 +27,8 @@ struct Problem {
     bool fused2;
     void *ws;
     size_t ws_bytes;
+    const void *norm_w;  // fused RMSNorm prologue (M == 1, rowwave only)
+    float norm_eps;
 };
 
 static int validate(const Problem &q) {
@@ -70,6 +72,8 @@ static void fill_params(const Problem &q, int m0, int mcount, GemvParams &p) {
     p.G = n_groups(q.K, q.groupsize);
     p.groupsize = q.groupsize;
     p.ws = (u64_t *)q.ws;
+    p.norm_w = (const half_t *)q.norm_w;
+    p.norm_eps = q.norm_eps;
     p.dbg = (u64_t *)g_debug_buffer.load();
 }
 
@@ -105,6 +109,7 @@ static int run_rowwave(const Problem &q, hipStream_t s) {
             if (u_ok(c)) u = c;
         if (!u) return GPTQ_E_VARIANT;
     }
+    if (q.norm_w && (u != 8 || q.bits != 4 || q.M != 1)) return GPTQ_E_VARIANT;
     const int ntile = (q.N + 255) / 256;
     const int nchunk = (rows + 4 * u - 1) / (4 * u);
     const int split_max = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
@@ -395,6 +400,37 @@ int gptq_g_idx_is_trivial(const int32_t *g_idx, int K, int groupsize, int32_t *o
     return gidx_trivial_launch(g_idx, K, groupsize, out, (hipStream_t)stream);
 }
 
+int gptq_rmsnorm_matmul248_f16(const void *x, const void *norm_weight, float eps, const int32_t *qweight, const void *scales,
+                               const int32_t *qzeros, const int32_t *g_idx, const void *bias, void *y, int K, int N, int bits,
+                               int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream) {
+    if (!norm_weight) return GPTQ_E_NULL;
+    Problem q = make_problem(x, K, qweight, scales, qzeros, g_idx, bias, y, N, 1, K, N, bits, groupsize, workspace, workspace_bytes);
+    q.norm_w = norm_weight;
+    q.norm_eps = eps;
+    if (int rc = validate(q)) return rc;
+    if (!aligned(norm_weight, 2) || !fast_eligible(q, 32 / (bits == 3 ? 4 : bits))) return GPTQ_E_VARIANT;
+    return run_rowwave(q, (hipStream_t)stream);
+}
+
+int gptq_rmsnorm_fused_mlp_f16(const void *x, const void *norm_weight, float eps, const int32_t *qweight_gate, const void *scales_gate,
+                               const int32_t *qzeros_gate, const int32_t *g_idx_gate, const int32_t *qweight_up,
+                               const void *scales_up, const int32_t *qzeros_up, const int32_t *g_idx_up, void *c, int K, int N,
+                               int bits, int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream) {
+    if (!norm_weight) return GPTQ_E_NULL;
+    Problem q = make_problem(x, K, qweight_gate, scales_gate, qzeros_gate, g_idx_gate, nullptr, c, N, 1, K, N, bits, groupsize, workspace,
+                             workspace_bytes);
+    q.fused2 = true;
+    q.qw[1] = qweight_up;
+    q.sc[1] = scales_up;
+    q.qz[1] = qzeros_up;
+    q.gi[1] = g_idx_up;
+    q.norm_w = norm_weight;
+    q.norm_eps = eps;
+    if (int rc = validate(q)) return rc;
+    if (!fast_eligible(q, 32 / (bits == 3 ? 4 : bits))) return GPTQ_E_VARIANT;
+    return run_rowwave(q, (hipStream_t)stream);
+}
+
 int gptq_decode_rope_kv_f16(void *qkv, const int64_t *position, void *k_cache, void *v_cache, int heads, int head_dim, int t_max,
                             float base, gptq_stream_t stream) {
     if (!qkv || !position || !k_cache || !v_cache) return GPTQ_E_NULL;
@@ -416,6 +452,17 @@ int gptq_decode_attn_f16(const void *q, const void *k_cache, const void *v_cache
     if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
     return decode_attn_launch((const half_t *)q, (const half_t *)k_cache, (const half_t *)v_cache, position, (half_t *)out,
                               (float *)workspace, heads, t_max, scale, (hipStream_t)stream);
+}
+
+int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k_cache, void *v_cache, void *out, void *workspace,
+                               size_t workspace_bytes, int heads, int head_dim, int t_max, float base, float scale,
+                               gptq_stream_t stream) {
+    if (!qkv || !k_cache || !v_cache || !position || !out || !workspace) return GPTQ_E_NULL;
+    if (heads <= 0 || head_dim != 128 || t_max <= 0) return GPTQ_E_SHAPE;
+    if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4)) return GPTQ_E_ALIGN;
+    if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
+    return decode_attn_fused_launch((const half_t *)qkv, position, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out,
+                                    (float *)workspace, heads, t_max, base, scale, (hipStream_t)stream);
 }
 
 }  // extern "C"

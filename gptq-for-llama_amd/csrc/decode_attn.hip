@@ -145,6 +145,175 @@ __global__ void __launch_bounds__(ATT_HD) attn_combine_kernel(const float *__res
     out[(size_t)h * ATT_HD + d] = (half_t)(num / den);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// One launch per layer: RoPE(q, k) + KV append + single-query attention + split merge.
+// Every active split rotates q itself (128 values); the split that owns row `pos` also rotates k,
+// appends k,v to the cache and takes that row from LDS (no read-after-write through memory).
+// With more than one active split the partial records are published with system-scope
+// (write-through) stores, drained, and a per-head arrival ticket elects the last split to merge
+// them (MI355X_MICROARCH.md, "Valid forms": sc0 sc1 stores AND loads, flag behind vmcnt(0)).
+// ws = [heads][nsplit][ATT_REC] floats followed by [heads] uint32 tickets (zero between launches).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__restrict__ qkv, const int64_t *__restrict__ pos_ptr,
+                                                                half_t *__restrict__ kc, half_t *__restrict__ vc,
+                                                                half_t *__restrict__ out, float *__restrict__ ws, int heads, int t_max,
+                                                                float inv_base, float scale) {
+    __shared__ float qs[ATT_HD];
+    __shared__ __attribute__((aligned(16))) half_t knew[ATT_HD];
+    __shared__ __attribute__((aligned(16))) half_t vnew[ATT_HD];
+    __shared__ float sc[ATT_TS];
+    __shared__ float red[8];
+    __shared__ float accs[4][ATT_HD];
+    __shared__ int last_flag;
+    const int h = blockIdx.x, s = blockIdx.y, nsplit = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t pos = pos_ptr[0];
+    if (pos < 0 || pos >= t_max) return;
+    const int len = (int)pos + 1;
+    const int t0 = s * ATT_TS;
+    if (t0 >= len) return;
+    const int nact = (len - t0) < ATT_TS ? (len - t0) : ATT_TS;
+    const int nsp = (len + ATT_TS - 1) / ATT_TS;         // active splits of this head
+    const bool own_new = (int)pos >= t0 && (int)pos < t0 + ATT_TS;
+    const int hd = heads * ATT_HD;
+    const int tnew = own_new ? (int)pos - t0 : -1;
+    const int d8 = tid & 15, tsub = tid >> 4;
+
+    // every cache row this thread will need is requested NOW (they depend on nothing but pos), so the
+    // RoPE trig below and the two softmax barriers run under the memory latency instead of after it
+    half8_t kpre[ATT_TS / 16];
+#pragma unroll
+    for (int it = 0; it < ATT_TS / 16; it++) {
+        const int tl = it * 16 + tsub;
+        kpre[it] = (tl < nact && tl != tnew) ? *(const half8_t *)(kc + (size_t)(t0 + tl) * hd + (size_t)h * ATT_HD + d8 * 8)
+                                              : (half8_t)(half_t)0;
+    }
+    half2_t vpre[ATT_TS / 4];
+#pragma unroll
+    for (int it = 0; it < ATT_TS / 4; it++) {
+        const int tl = it * 4 + wave;
+        vpre[it] = (tl < nact && tl != tnew) ? *(const half2_t *)(vc + (size_t)(t0 + tl) * hd + (size_t)h * ATT_HD + 2 * lane)
+                                              : half2_t{(half_t)0, (half_t)0};
+    }
+
+    if (tid < ATT_HD / 2) {
+        const int c = tid;
+        const float freq = expf((float)c * inv_base) * (float)pos;
+        const float cs = cosf(freq), sn = sinf(freq);
+        const half_t *q = qkv + (size_t)h * ATT_HD + c;
+        const float qx = (float)q[0], qy = (float)q[ATT_HD / 2];
+        qs[c] = (float)(half_t)(qx * cs - qy * sn);       // rounded to fp16 like the in-place reference RoPE
+        qs[c + ATT_HD / 2] = (float)(half_t)(qx * sn + qy * cs);
+        if (own_new) {
+            const half_t *k = qkv + hd + (size_t)h * ATT_HD + c;
+            const half_t *v = qkv + 2 * hd + (size_t)h * ATT_HD + c;
+            const float kx = (float)k[0], ky = (float)k[ATT_HD / 2];
+            const half_t k0 = (half_t)(kx * cs - ky * sn), k1 = (half_t)(kx * sn + ky * cs);
+            knew[c] = k0;
+            knew[c + ATT_HD / 2] = k1;
+            vnew[c] = v[0];
+            vnew[c + ATT_HD / 2] = v[ATT_HD / 2];
+            half_t *kd = kc + (size_t)pos * hd + (size_t)h * ATT_HD + c;
+            half_t *vd = vc + (size_t)pos * hd + (size_t)h * ATT_HD + c;
+            kd[0] = k0;
+            kd[ATT_HD / 2] = k1;
+            vd[0] = v[0];
+            vd[ATT_HD / 2] = v[ATT_HD / 2];
+        }
+    }
+    __syncthreads();
+    float qf[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) qf[j] = qs[d8 * 8 + j];
+#pragma unroll
+    for (int it = 0; it < ATT_TS / 16; it++) {
+        const int tl = it * 16 + tsub;
+        float dot = 0.f;
+        if (tl < nact) {
+            half8_t k8 = kpre[it];
+            if (tl == tnew) k8 = *(const half8_t *)(knew + d8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) dot += qf[j] * (float)k8[j];
+        }
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        dot += __shfl_xor(dot, 4, 64);
+        dot += __shfl_xor(dot, 8, 64);
+        if (d8 == 0) sc[tl] = (tl < nact) ? dot * scale : -INFINITY;
+    }
+    __syncthreads();
+    float sv = (tid < ATT_TS) ? sc[tid] : -INFINITY;
+    float m = sv;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float p = (tid < nact) ? __expf(sv - m) : 0.f;
+    float l = p;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) l += __shfl_xor(l, off, 64);
+    __syncthreads();
+    if (tid < ATT_TS) sc[tid] = p;
+    if (lane == 0) red[4 + wave] = l;
+    __syncthreads();
+    l = red[4] + red[5] + red[6] + red[7];
+
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int it = 0; it < ATT_TS / 4; it++) {
+        const int tl = it * 4 + wave;
+        if (tl < nact) {
+            half2_t v2 = vpre[it];
+            if (tl == tnew) v2 = *(const half2_t *)(vnew + 2 * lane);
+            const float pt = sc[tl];
+            a0 += pt * (float)v2[0];
+            a1 += pt * (float)v2[1];
+        }
+    }
+    accs[wave][2 * lane] = a0;
+    accs[wave][2 * lane + 1] = a1;
+    __syncthreads();
+    float acc = 0.f;
+    if (tid < ATT_HD) acc = accs[0][tid] + accs[1][tid] + accs[2][tid] + accs[3][tid];
+
+    if (nsp == 1) {  // short context: this workgroup is the whole head
+        if (tid < ATT_HD) out[(size_t)h * ATT_HD + tid] = (half_t)(acc / l);
+        return;
+    }
+    float *rec = ws + ((size_t)h * nsplit + s) * ATT_REC;
+    if (tid < ATT_HD) __hip_atomic_store(rec + 2 + tid, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) {
+        __hip_atomic_store(rec + 0, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(rec + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned *ticket = (unsigned *)(ws + (size_t)heads * nsplit * ATT_REC) + h;
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned)(nsp - 1));
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    if (tid < ATT_HD) {
+        const float *base = ws + (size_t)h * nsplit * ATT_REC;
+        float Mx = -INFINITY;
+        for (int i = 0; i < nsp; i++) Mx = fmaxf(Mx, __hip_atomic_load(base + (size_t)i * ATT_REC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        float num = 0.f, den = 0.f;
+        for (int i = 0; i < nsp; i++) {
+            const float *r = base + (size_t)i * ATT_REC;
+            const float w = __expf(__hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - Mx);
+            num += w * __hip_atomic_load(r + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            den += w * __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        out[(size_t)h * ATT_HD + tid] = (half_t)(num / den);
+    }
+}
+
 int decode_rope_kv_launch(half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, int heads, int head_dim, int t_max, float base,
                           hipStream_t s) {
     const float inv_base = -2.0f * logf(base) / (float)head_dim;   // reference fused_attn.py:91
@@ -160,8 +329,17 @@ int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, cons
     return (int)hipGetLastError();
 }
 
+int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
+                             float base, float scale, hipStream_t s) {
+    const int nsplit = (t_max + ATT_TS - 1) / ATT_TS;
+    const float inv_base = -2.0f * logf(base) / (float)ATT_HD;
+    hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(heads, nsplit), dim3(256), 0, s, qkv, pos, kc, vc, out, ws, heads, t_max, inv_base,
+                       scale);
+    return (int)hipGetLastError();
+}
+
 size_t decode_attn_ws_bytes(int heads, int t_max) {
-    return (size_t)heads * ((t_max + ATT_TS - 1) / ATT_TS) * ATT_REC * sizeof(float);
+    return (size_t)heads * ((t_max + ATT_TS - 1) / ATT_TS) * ATT_REC * sizeof(float) + (size_t)heads * sizeof(unsigned);
 }
 
 }  // namespace gptq

@@ -31,18 +31,29 @@ namespace gptq {
 // into SGPRs at wave launch (-mllvm -amdgpu-kernarg-preload-count=16): the weight loads are
 // issued a few hundred cycles after the wave starts.
 // ---------------------------------------------------------------------------------------
-template <int BITS, int U, bool FUSED2, bool DBG>
+// NORM: x is RMS-normalised on the fly -- xn = fp16(x * rsqrt(mean(x^2) + eps) * nw), the arithmetic of
+// rms_norm_fwd_fused (reference quant/triton_norm.py:22-39) -- so that [RMSNorm -> QuantLinear] of a
+// decoder layer is ONE launch.  Every wave computes sum(x^2) redundantly from L2 while its weight
+// loads are in flight (no barrier) and normalises only the U*KPW values it needs (through LDS).
+template <int BITS, int U, bool FUSED2, bool DBG, bool NORM = false>
 __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
     const uint32_t *__restrict__ qw0, const half_t *__restrict__ x, const half_t *__restrict__ sc0,
     const int32_t *__restrict__ qz0, int N, int rows, int S, int gshift, const uint32_t *__restrict__ qw1,
     const half_t *__restrict__ sc1, const int32_t *__restrict__ qz1, half_t *__restrict__ y, u64_t *__restrict__ ws,
-    const half_t *__restrict__ bias, u64_t *__restrict__ dbg) {
+    const half_t *__restrict__ bias, u64_t *__restrict__ dbg, const half_t *__restrict__ nw, float eps) {
     using UP = Unpack<BITS>;
     constexpr int KPW = UP::KPW, NP = UP::NP;
     constexpr int XW = KPW / 2;  // dwords of x per packed row
     constexpr int NS = FUSED2 ? 2 : 1;
     typedef uint32_t xrow_t __attribute__((ext_vector_type(XW)));
     __shared__ float red[NS][4][256];
+    __shared__ __attribute__((aligned(16))) half_t xn[NORM ? 4 : 1][NORM ? U * KPW : 8];
+    float rstd = 0.f;
+    bool have_rstd = false;
+    // NORM: this lane's share of x for sum(x^2) is requested BEFORE the weights (vector loads
+    // return in order: behind 8-16 weight rows it would arrive last) and reduced while they stream.
+    half8_t xsq[NORM ? 8 : 1];
+    float ss_tail = 0.f;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -66,6 +77,19 @@ __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
     for (int s = 0; s < NS; s++)
 #pragma unroll
         for (int j = 0; j < 4; j++) yv[s][j] = 0.f;
+    if constexpr (NORM) {
+        const int nv = rows * KPW / 8;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = lane + 64 * j;
+            xsq[j] = i < nv ? *(const half8_t *)(x + (size_t)i * 8) : (half8_t)(half_t)0;
+        }
+        for (int i = 512 + lane; i < nv; i += 64) {  // K > 4096: the rest, blocking (rare)
+            const half8_t v = *(const half8_t *)(x + (size_t)i * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) ss_tail += (float)v[e] * (float)v[e];
+        }
+    }
 
     for (uint32_t c = slice; c < nchunk; c += (uint32_t)S) {
         const uint32_t row = c * (4 * U) + wave * U;  // first packed row of this wave's block (uniform)
@@ -74,6 +98,18 @@ __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
         half4_t s4[NS];
         uint32_t zw[NS];
         const uint32_t g = gshift >= 0 ? (row >> gshift) : 0u;
+        // NORM: the raw x / norm-weight values of this wave's own rows, requested ahead of the weights
+        constexpr int XE = NORM ? (U * KPW + 63) / 64 : 1;
+        half_t xe[XE], nwe[XE];
+        if constexpr (NORM) {
+#pragma unroll
+            for (int i = 0; i < XE; i++) {
+                const int e = lane + 64 * i;
+                const size_t k = (size_t)row * KPW + (e < U * KPW ? e : 0);
+                xe[i] = x[k];
+                nwe[i] = nw[k];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < NS; s++) {
 #pragma unroll
@@ -82,12 +118,44 @@ __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
             s4[s] = *(const half4_t *)(sc[s] + (size_t)g * (uint32_t)N + nc);
             zw[s] = (uint32_t)qz[s][(size_t)g * ((uint32_t)N / KPW) + nc / KPW];
         }
-        const xrow_t *xq = (const xrow_t *)x + row;  // wave-uniform: scalar loads
         xrow_t xr[U];
+        if constexpr (!NORM) {
+            const xrow_t *xq = (const xrow_t *)x + row;  // wave-uniform: scalar loads
 #pragma unroll
-        for (int u = 0; u < U; u++) xr[u] = xq[u];
+            for (int u = 0; u < U; u++) xr[u] = xq[u];
+        }
         __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is in flight before any math
         if constexpr (DBG) st[2] = stamp_cycles(0);
+        if constexpr (NORM) {
+            const int K = rows * KPW;
+            if (!have_rstd) {  // once per wave: sum(x^2) over all of K (the loads were issued first)
+                // opaque use INSIDE the loop, after the weight loads were issued: keeps the compiler from
+                // hoisting this reduction (and its vmcnt wait) in front of them
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    u32x4 pin = __builtin_bit_cast(u32x4, xsq[j]);
+                    asm volatile("" : "+v"(pin));
+                    xsq[j] = __builtin_bit_cast(half8_t, pin);
+                }
+                float ss = ss_tail;
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) ss += (float)xsq[j][e] * (float)xsq[j][e];
+                ss = wave_sum_xor(ss, 1);
+                rstd = 1.0f / sqrtf(ss / (float)K + eps);
+                have_rstd = true;
+            }
+#pragma unroll
+            for (int i = 0; i < XE; i++) {
+                const int e = lane + 64 * i;
+                if (e < U * KPW) xn[wave][e] = (half_t)((float)xe[i] * rstd * (float)nwe[i]);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < U; u++) xr[u] = *(const xrow_t *)&xn[wave][u * KPW];  // same address in every lane: broadcast
+            __builtin_amdgcn_wave_barrier();
+        }
 
         float acc[NS][4];
 #pragma unroll
@@ -304,7 +372,21 @@ __global__ void __launch_bounds__(WAVES * 64) gemv_generic_kernel(const GemvPara
 // host-side launchers
 // ---------------------------------------------------------------------------------------
 template <int BITS, int U, bool FUSED2>
+static int launch_rowwave_norm(const GemvParams &p, hipStream_t stream) {
+    constexpr int KPW = 32 / BITS;
+    const int rows = p.K / KPW;
+    dim3 grid((p.N + 255) / 256, p.split_k), block(256);
+    hipLaunchKernelGGL((gemv_rowwave_kernel<BITS, U, FUSED2, false, true>), grid, block, 0, stream, p.qw[0], p.x, p.sc[0], p.qz[0], p.N,
+                       rows, p.split_k, p.upg_shift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, (u64_t *)nullptr, p.norm_w, p.norm_eps);
+    return (int)hipGetLastError();
+}
+
+template <int BITS, int U, bool FUSED2>
 static int launch_rowwave(const GemvParams &p, hipStream_t stream) {
+    if (p.norm_w) {
+        if constexpr (BITS == 4 && U == 8) return launch_rowwave_norm<BITS, U, FUSED2>(p, stream);
+        else return GPTQ_E_VARIANT;
+    }
     constexpr int KPW = 32 / BITS;
     const int rows = p.K / KPW;
     const int ntile = (p.N + 255) / 256;
@@ -313,12 +395,12 @@ static int launch_rowwave(const GemvParams &p, hipStream_t stream) {
     if (p.dbg) {
         if constexpr (BITS == 4 && U == 8) {
             hipLaunchKernelGGL((gemv_rowwave_kernel<BITS, U, FUSED2, true>), grid, block, 0, stream, p.qw[0], p.x, p.sc[0], p.qz[0], p.N,
-                               rows, p.split_k, gshift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, p.dbg);
+                               rows, p.split_k, gshift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, p.dbg, (const half_t *)nullptr, 0.f);
             return (int)hipGetLastError();
         }
     }
     hipLaunchKernelGGL((gemv_rowwave_kernel<BITS, U, FUSED2, false>), grid, block, 0, stream, p.qw[0], p.x, p.sc[0], p.qz[0], p.N, rows,
-                       p.split_k, gshift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, (u64_t *)nullptr);
+                       p.split_k, gshift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, (u64_t *)nullptr, (const half_t *)nullptr, 0.f);
     return (int)hipGetLastError();
 }
 

@@ -29,6 +29,8 @@ struct GemvParams {
     int ntiles, split_k, nchunks, chunks_per_slice;
     int units_per_group, upg_shift;  // stream kernel: groupsize / unit_k and its log2 (or -1)
     u64_t *ws;
+    const half_t *norm_w;  // non-NULL: RMS-normalise x on the fly with this weight (M == 1 rowwave only)
+    float norm_eps;
     u64_t *dbg;  // optional timeline buffer [blocks][waves][8] (tools/timeline.py), else nullptr
 };
 
@@ -56,5 +58,7 @@ int decode_rope_kv_launch(half_t *qkv, const int64_t *pos, half_t *kc, half_t *v
 int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, const int64_t *pos, half_t *out, float *ws, int heads,
                        int t_max, float scale, hipStream_t s);
 size_t decode_attn_ws_bytes(int heads, int t_max);
+int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
+                             float base, float scale, hipStream_t s);
 
 }  // namespace gptq

@@ -46,8 +46,14 @@ _SIGNATURES = {
     'gptq_pack_f32': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                       c_void_p, c_void_p, c_void_p],
     'gptq_g_idx_is_trivial': [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    'gptq_rmsnorm_matmul248_f16': [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                   c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
+    'gptq_rmsnorm_fused_mlp_f16': [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
     'gptq_decode_rope_kv_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
     'gptq_decode_attn_workspace_bytes': [c_int, c_int, c_int],
+    'gptq_decode_attn_fused_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
+                                   c_float, c_float, c_void_p],
     'gptq_decode_attn_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
                              c_float, c_void_p],
 }

@@ -114,8 +114,9 @@ def benchmark_decode(model, tokens=64, seed=0):
 # ----------------------------------------------------------------------------------------------
 class DecodeEngine:
 
-    def __init__(self, model, t_max=2048):
+    def __init__(self, model, t_max=2048, fuse_norm=True, fuse_attn=True):
         from . import _native
+        self.fuse_norm, self.fuse_attn = bool(fuse_norm), bool(fuse_attn)
         self.native = _native
         self.lib = _native.lib()
         self.model = model
@@ -190,6 +191,35 @@ class DecodeEngine:
         rc = self.lib.gptq_rmsnorm_f16(x.data_ptr(), self.hidden, w.data_ptr(), y.data_ptr(), self.hidden, 1, self.hidden, self.eps, s)
         self.native.check(rc, 'gptq_rmsnorm_f16')
 
+    def _norm_gemv(self, x, nw, w, y, s):
+        """y = QuantLinear(rmsnorm(x)): one launch when the fused kernel serves the shape, else two."""
+        ptr = self.native.ptr
+        if self.fuse_norm and w['bias'] is None:
+            rc = self.lib.gptq_rmsnorm_matmul248_f16(x.data_ptr(), nw.data_ptr(), self.eps, w['qw'].data_ptr(), w['sc'].data_ptr(),
+                                                     w['qz'].data_ptr(), ptr(w['gi']), None, y.data_ptr(), w['K'], w['N'], w['bits'],
+                                                     w['gs'], self.ws.data_ptr(), self.ws.numel(), s)
+            if rc != -6:   # GPTQ_E_VARIANT: shape needs the generic kernels
+                self.native.check(rc, 'gptq_rmsnorm_matmul248_f16')
+                return
+        self._norm(x, nw, self.h, s)
+        self._gemv(self.h, w, y, s)
+
+    def _norm_mlp(self, x, nw, g, u, c, s):
+        ptr = self.native.ptr
+        if self.fuse_norm:
+            rc = self.lib.gptq_rmsnorm_fused_mlp_f16(x.data_ptr(), nw.data_ptr(), self.eps, g['qw'].data_ptr(), g['sc'].data_ptr(),
+                                                     g['qz'].data_ptr(), ptr(g['gi']), u['qw'].data_ptr(), u['sc'].data_ptr(),
+                                                     u['qz'].data_ptr(), ptr(u['gi']), c.data_ptr(), g['K'], g['N'], g['bits'], g['gs'],
+                                                     self.ws.data_ptr(), self.ws.numel(), s)
+            if rc != -6:
+                self.native.check(rc, 'gptq_rmsnorm_fused_mlp_f16')
+                return
+        self._norm(x, nw, self.h, s)
+        rc = self.lib.gptq_fused_mlp_f16(self.h.data_ptr(), g['K'], g['qw'].data_ptr(), g['sc'].data_ptr(), g['qz'].data_ptr(), ptr(g['gi']),
+                                         u['qw'].data_ptr(), u['sc'].data_ptr(), u['qz'].data_ptr(), ptr(u['gi']), c.data_ptr(), g['N'], 1,
+                                         g['K'], g['N'], g['bits'], g['gs'], self.ws.data_ptr(), self.ws.numel(), s)
+        self.native.check(rc, 'gptq_fused_mlp_f16')
+
     def _step(self):
         lib, ptr = self.lib, self.native.ptr
         s = torch.cuda.current_stream(self.dev).cuda_stream
@@ -197,22 +227,22 @@ class DecodeEngine:
         torch.index_select(self.embed, 0, self.ids, out=self.x)
         scale = 1.0 / float(np.sqrt(self.head_dim))
         for li, L in enumerate(self.layers):
-            self._norm(self.x, L['ln1'], self.h, s)
-            self._gemv(self.h, L['qkv'], self.qkvb, s)
-            rc = lib.gptq_decode_rope_kv_f16(self.qkvb.data_ptr(), self.pos.data_ptr(), self.kc[li].data_ptr(), self.vc[li].data_ptr(),
-                                             self.heads, self.head_dim, self.t_max, L['theta'], s)
-            self.native.check(rc, 'gptq_decode_rope_kv_f16')
-            rc = lib.gptq_decode_attn_f16(self.qkvb.data_ptr(), self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
-                                          self.ab.data_ptr(), self.attn_ws.data_ptr(), self.attn_ws.numel(), self.heads,
-                                          self.head_dim, self.t_max, scale, s)
-            self.native.check(rc, 'gptq_decode_attn_f16')
+            self._norm_gemv(self.x, L['ln1'], L['qkv'], self.qkvb, s)       # qkv = qkv_proj(rmsnorm(x))
+            if self.fuse_attn:
+                rc = lib.gptq_decode_attn_fused_f16(self.qkvb.data_ptr(), self.pos.data_ptr(), self.kc[li].data_ptr(),
+                                                    self.vc[li].data_ptr(), self.ab.data_ptr(), self.attn_ws.data_ptr(),
+                                                    self.attn_ws.numel(), self.heads, self.head_dim, self.t_max, L['theta'], scale, s)
+                self.native.check(rc, 'gptq_decode_attn_fused_f16')
+            else:
+                rc = lib.gptq_decode_rope_kv_f16(self.qkvb.data_ptr(), self.pos.data_ptr(), self.kc[li].data_ptr(),
+                                                 self.vc[li].data_ptr(), self.heads, self.head_dim, self.t_max, L['theta'], s)
+                self.native.check(rc, 'gptq_decode_rope_kv_f16')
+                rc = lib.gptq_decode_attn_f16(self.qkvb.data_ptr(), self.kc[li].data_ptr(), self.vc[li].data_ptr(), self.pos.data_ptr(),
+                                              self.ab.data_ptr(), self.attn_ws.data_ptr(), self.attn_ws.numel(), self.heads,
+                                              self.head_dim, self.t_max, scale, s)
+                self.native.check(rc, 'gptq_decode_attn_f16')
             self._gemv(self.ab, L['o'], self.x2, s, residual=self.x)        # x2 = x + o_proj(attn)
-            self._norm(self.x2, L['ln2'], self.h, s)
-            g, u = L['gate'], L['up']
-            rc = lib.gptq_fused_mlp_f16(self.h.data_ptr(), g['K'], g['qw'].data_ptr(), g['sc'].data_ptr(), g['qz'].data_ptr(), ptr(g['gi']),
-                                        u['qw'].data_ptr(), u['sc'].data_ptr(), u['qz'].data_ptr(), ptr(u['gi']), self.cb.data_ptr(),
-                                        g['N'], 1, g['K'], g['N'], g['bits'], g['gs'], self.ws.data_ptr(), self.ws.numel(), s)
-            self.native.check(rc, 'gptq_fused_mlp_f16')
+            self._norm_mlp(self.x2, L['ln2'], L['gate'], L['up'], self.cb, s)
             self._gemv(self.cb, L['down'], self.x, s, residual=self.x2)     # x = x2 + down(silu(gate) * up)
         self._norm(self.x, self.final_norm, self.h, s)
         torch.matmul(self.h, self.lm_head.t(), out=self.logits)
@@ -249,10 +279,10 @@ class DecodeEngine:
         return self.logits
 
 
-def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True):
+def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fuse_norm=True, fuse_attn=True):
     """the llama.py:385-438 protocol on the DecodeEngine (hipGraph replay per token)."""
     dev = next(model.parameters()).device
-    eng = DecodeEngine(model, t_max=t_max)
+    eng = DecodeEngine(model, t_max=t_max, fuse_norm=fuse_norm, fuse_attn=fuse_attn)
     if graph:
         eng.capture()
     gen = torch.Generator(device=dev)
@@ -269,5 +299,6 @@ def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True):
     med = float(np.median(times[2:])) if len(times) > 4 else float(np.median(times))
     return {'protocol': 'llama.py:385-438 (one token per step, KV cache, sync per step, median)',
             'mode': 'DecodeEngine, %s' % ('one hipGraph replay per token' if graph else 'eager launches'), 'tokens': tokens,
-            't_max': t_max, 'launches_per_token': 10 * len(eng.layers) + 4, 'median_s_per_token': round(med, 6),
+            't_max': t_max, 'fused_norm': fuse_norm, 'fused_attention': fuse_attn,
+            'launches_per_token': (10 - 2 * int(fuse_norm) - 2 * int(fuse_attn)) * len(eng.layers) + 4, 'median_s_per_token': round(med, 6),
             'tokens_per_s': round(1.0 / med, 1)}

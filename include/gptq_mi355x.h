@@ -165,12 +165,38 @@ int gptq_g_idx_is_trivial(const int32_t *g_idx, int K, int groupsize, int32_t *o
  *             0..position are read by attn.  head_dim must be 128 for gptq_decode_attn_f16.
  *   out       fp16 [heads*head_dim] = softmax(q.K^T * scale) V, fp32 math
  */
+/*
+ * [RMSNorm -> QuantLinear] and [RMSNorm -> fused gate/up] of a decoder layer as ONE launch, M == 1
+ * (TritonLlamaRMSNorm.forward followed by QuantLinear.forward / triton_llama_mlp; reference
+ * quant/triton_norm.py:50-67 + quant/quant_linear.py:373-377 / quant/fused_mlp.py:206-218).
+ * x fp16 [K] is normalised on the fly with the arithmetic of rms_norm_fwd_fused (fp32, one fp16
+ * rounding) and never written back.  Returns GPTQ_E_VARIANT when the shape needs the generic
+ * kernels (act-order, 3-bit, bits != 4, odd groups): call gptq_rmsnorm_f16 + gptq_matmul248_f16.
+ */
+int gptq_rmsnorm_matmul248_f16(const void *x, const void *norm_weight, float eps, const int32_t *qweight,
+                               const void *scales, const int32_t *qzeros, const int32_t *g_idx,
+                               const void *bias, void *y, int K, int N, int bits, int groupsize,
+                               void *workspace, size_t workspace_bytes, gptq_stream_t stream);
+int gptq_rmsnorm_fused_mlp_f16(const void *x, const void *norm_weight, float eps, const int32_t *qweight_gate,
+                               const void *scales_gate, const int32_t *qzeros_gate,
+                               const int32_t *g_idx_gate, const int32_t *qweight_up, const void *scales_up,
+                               const int32_t *qzeros_up, const int32_t *g_idx_up, void *c, int K, int N,
+                               int bits, int groupsize, void *workspace, size_t workspace_bytes,
+                               gptq_stream_t stream);
+
 int gptq_decode_rope_kv_f16(void *qkv, const int64_t *position, void *k_cache, void *v_cache, int heads,
                             int head_dim, int t_max, float base, gptq_stream_t stream);
 size_t gptq_decode_attn_workspace_bytes(int heads, int head_dim, int t_max);
 int gptq_decode_attn_f16(const void *q, const void *k_cache, const void *v_cache, const int64_t *position,
                          void *out, void *workspace, size_t workspace_bytes, int heads, int head_dim,
                          int t_max, float scale, gptq_stream_t stream);
+
+/* gptq_decode_rope_kv_f16 + gptq_decode_attn_f16 as ONE launch (q is rotated internally, the qkv
+ * buffer is left untouched); the workspace (same size query) must be zero on first use -- its
+ * trailing [heads] uint32 arrival tickets are restored to zero by the kernel. */
+int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k_cache, void *v_cache, void *out,
+                               void *workspace, size_t workspace_bytes, int heads, int head_dim, int t_max,
+                               float base, float scale, gptq_stream_t stream);
 
 #ifdef __cplusplus
 }

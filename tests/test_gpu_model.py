@@ -115,15 +115,63 @@ def test_decode_rope_kv_and_attention_vs_torch(pos):
     gotn = out.float().cpu().numpy()
     assert np.abs(gotn - expect).max() / np.abs(expect).max() < 1e-3
 
+    # the one-launch form: same inputs (unrotated qkv, cache without the new row), twice in a row
+    # (the arrival tickets must be back to zero)
+    for _ in range(2):
+        qkv2, kc2, vc2 = d(qkv.copy()), d(kc.copy()), d(vc.copy())
+        out2 = torch.empty(H, dtype=torch.float16, device=DEV)
+        _native.check(lib.gptq_decode_attn_fused_f16(qkv2.data_ptr(), pos_d.data_ptr(), kc2.data_ptr(), vc2.data_ptr(), out2.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), heads, hd, t_max, 10000.0, float(scale), s), 'attn_fused')
+        got2 = out2.float().cpu().numpy()
+        assert np.abs(got2 - expect).max() / np.abs(expect).max() < 1e-3
+        assert np.array_equal(kc2.cpu().numpy().view(np.uint16), kc_d.cpu().numpy().view(np.uint16))
+        assert np.array_equal(vc2.cpu().numpy().view(np.uint16), vc_d.cpu().numpy().view(np.uint16))
 
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_rmsnorm_fused_into_gemv(fused):
+    """gptq_rmsnorm_matmul248_f16 / gptq_rmsnorm_fused_mlp_f16 == RMSNorm kernel followed by the
+    GEMV (same arithmetic, one launch)."""
+    from quant import _native
+    from util import make_random_layer
+    lib = _native.lib()
+    K, N = 4096, 1024
+    rng = np.random.default_rng(11)
+    A, B = make_random_layer(4, 128, K, N, seed=1), make_random_layer(4, 128, K, N, seed=2)
+    x = (rng.standard_normal((1, K)) * 3).astype(np.float16)
+    nw = (1 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    xd, nwd = d(x), d(nw)
+    ws = _native.workspace(torch.device(DEV))
+    s = torch.cuda.current_stream().cuda_stream
+    y = torch.empty((1, N), dtype=torch.float16, device=DEV)
+    a = [d(A[k]) for k in ('qweight', 'scales', 'qzeros')]
+    b = [d(B[k]) for k in ('qweight', 'scales', 'qzeros')]
+    xn = oracle.rmsnorm(x, nw, 1e-6)
+    if fused:
+        _native.check(lib.gptq_rmsnorm_fused_mlp_f16(xd.data_ptr(), nwd.data_ptr(), 1e-6, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                                     None, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), None, y.data_ptr(), K, N, 4,
+                                                     128, ws.data_ptr(), ws.numel(), s), 'norm_mlp')
+        ref = oracle.fused_mlp(xn, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), 4)
+        tol = 2e-3
+    else:
+        _native.check(lib.gptq_rmsnorm_matmul248_f16(xd.data_ptr(), nwd.data_ptr(), 1e-6, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                                     None, None, y.data_ptr(), K, N, 4, 128, ws.data_ptr(), ws.numel(), s), 'norm_mm')
+        ref = oracle.matmul248(xn, A['qweight'], A['scales'], A['qzeros'], A['g_idx'], 4)
+        tol = 1e-3
+    got = y.cpu().numpy()
+    assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / np.abs(ref.astype(np.float64)).max() < tol
+
+
+@pytest.mark.parametrize('fuse', [False, True])
 @pytest.mark.parametrize('graph', [False, True])
-def test_decode_engine_matches_hf_decoder(graph):
+def test_decode_engine_matches_hf_decoder(graph, fuse):
     """the flat C-ABI decode step (eager and as one hipGraph replay per token) reproduces the
     logits of the HF decoder running the same drop-in modules, token by token."""
     q = D.build_random_llama(DEV, seed=3, **HD128)
     ids = torch.randint(0, HD128['vocab_size'], (1, 10), device=DEV)
     expect = run_steps(q, ids, 1)
-    eng = D.DecodeEngine(q, t_max=64)
+    eng = D.DecodeEngine(q, t_max=64, fuse_norm=fuse, fuse_attn=fuse)
     if graph:
         eng.capture()
     got = []
@@ -132,5 +180,5 @@ def test_decode_engine_matches_hf_decoder(graph):
     got = np.stack(got)[:, None, :]
     assert np.abs(got - expect).max() / np.abs(expect).max() < 2e-2
     assert (got.argmax(-1) == expect.argmax(-1)).mean() >= 0.8
-    r = D.benchmark_decode_engine(q, tokens=8, t_max=64, graph=graph)
+    r = D.benchmark_decode_engine(q, tokens=8, t_max=64, graph=graph, fuse_norm=fuse, fuse_attn=fuse)
     assert r['tokens_per_s'] > 0

@@ -48,7 +48,7 @@ def test_argument_validation_needs_no_gpu():
         _native.check(-1, 'x')
     with pytest.raises(RuntimeError):
         _native.check(-7, 'x')
-    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == 32 * 16 * 130 * 4
+    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == 32 * 16 * 130 * 4 + 32 * 4
     assert lib.gptq_decode_attn_workspace_bytes(32, 64, 2048) == 0
 
 

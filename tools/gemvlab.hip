@@ -63,8 +63,6 @@ struct P {
     int K, N, S, nchunk, ntile;
 };
 
-GPTQ_DEV uint32_t vreg_const(uint32_t c) { uint32_t v; asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(c)); return v; }
-GPTQ_DEV uint32_t sreg_const(uint32_t c) { uint32_t v; asm("s_mov_b32 %0, %1" : "=s"(v) : "i"(c)); return v; }
 
 GPTQ_DEV u64_t stamp_dep(uint32_t dep) {
     u64_t t;
@@ -334,6 +332,38 @@ static float time_graph(launch_fn fn, P base, const std::vector<WSet> &sets, hip
     return ms * 1e3f / (reps * sets.size());
 }
 
+// the same launches captured on `nch` forked streams (kernel j on chain j % nch, each chain with its
+// own split-K workspace and output): do independent chains of a hipGraph overlap on this stack?
+static float time_graph_chains(launch_fn fn, P base, const std::vector<WSet> &sets, hipStream_t s, int reps, int nch) {
+    static hipStream_t side[8];
+    static bool init = false;
+    if (!init) { for (auto &x : side) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking)); init = true; }
+    hipGraph_t g; hipGraphExec_t ge;
+    hipEvent_t fork, join[8];
+    CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    for (auto &e : join) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    CK(hipEventRecord(fork, s));
+    for (int c = 1; c < nch; c++) CK(hipStreamWaitEvent(side[c], fork, 0));
+    int j = 0;
+    for (auto &w : sets) {
+        const int c = j++ % nch;
+        P p = base; p.qw = w.qw; p.sc = w.sc; p.qz = w.qz; p.ws = base.ws + (size_t)c * 16384; p.y = base.y + (size_t)c * 0;
+        fn(p, c == 0 ? s : side[c]);
+    }
+    for (int c = 1; c < nch; c++) { CK(hipEventRecord(join[c], side[c])); CK(hipStreamWaitEvent(s, join[c], 0)); }
+    CK(hipStreamEndCapture(s, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; i++) CK(hipGraphLaunch(ge, s));
+    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    return ms * 1e3f / (reps * sets.size());
+}
+
 int main(int argc, char **argv) {
     hipStream_t s; CK(hipStreamCreate(&s));
     int shapes[][2] = {{4096, 4096}, {4096, 12288}, {11008, 4096}, {4096, 11008}};
@@ -422,6 +452,14 @@ int main(int argc, char **argv) {
                     printf("  rowwave U4 S%-3d wgs %5d | full %6.2f us %5.0f GB/s err %.1e | noatomic %6.2f | loadsonly %6.2f | nooutput %6.2f\n", S, p.ntile * S, t0,
                            bytes / t0 / 1e3, e, t1, t2, t3);
                 } while (0);
+            }
+        }
+        if (N % 256 == 0 && rows % 32 == 0) {
+            constexpr int U = 8;
+            P p = base; p.nchunk = rows / 32; p.S = p.nchunk < 32 ? p.nchunk : 32;
+            for (int nch = 1; nch <= 4; nch++) {
+                float t = time_graph_chains(launch_rowwave<U, 0>, p, sets, s, 5, nch);
+                printf("  rowwave U8 S%d on %d parallel graph chain(s): %6.2f us per launch  %5.0f GB/s\n", p.S, nch, t, bytes / t / 1e3);
             }
         }
         if (N % 256 == 0 && rows % 32 == 0) {

@@ -1,0 +1,10 @@
+#!/usr/bin/env python3
+"""run the DecodeEngine for a few tokens (for rocprofv3 --kernel-trace --stats)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'gptq-for-llama_amd')); sys.path.insert(0, ROOT)
+import torch
+from quant.decode import build_random_llama, benchmark_decode_engine
+fuse = '--nofuse' not in sys.argv
+m = build_random_llama('cuda:0')
+print(benchmark_decode_engine(m, tokens=40, graph=True, fuse_norm=fuse, fuse_attn=fuse))

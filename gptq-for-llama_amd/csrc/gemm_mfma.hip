@@ -2,9 +2,10 @@
 // C[M,N] = A[M,K] . deq(B) (+ bias), the large-M regime of the reference's matmul_248_kernel
 // (quant/quant_linear.py:72-137).  Bound: fp16 MFMA (2.5 PFLOP/s dense); flops = 2*M*N*K.
 //
-//  * workgroup tile 256(M) x 256(N) x 64(K), 4 waves in a 2 x 2 grid, each wave owns 128 x 128 =
-//    4 x 4 tiles of v_mfma_f32_32x32x16_f16 (256 fp32 accumulators per lane; one wave per SIMD,
-//    the register file is the occupancy limit by design);
+//  * workgroup tile 256(M) x 256(N) x 64(K), 8 waves in a 2 x 4 grid, each wave owns 128 x 64 =
+//    4 x 2 tiles of v_mfma_f32_32x32x16_f16 (128 fp32 accumulators per lane): TWO waves per SIMD, so
+//    one wave's LDS reads / dequant VALU / barrier waits sit under the other's MFMAs without
+//    hand scheduling (measured: 4 waves x 128x128 reached 0.8 PF);
 //  * B is dequantised ONCE per (workgroup, K slab) on the way into LDS, with the reference's own
 //    numerics -- fp16(q - z) exact (magic-exponent unpack + packed fp16 subtract), times the fp16
 //    scale, one fp16 rounding (quant_linear.py:128) -- so the MFMA consumes exactly the weights
@@ -33,14 +34,18 @@ struct GemmParams {
     half_t *c;
     int64_t ldc;
     int M, K, N, groupsize;
+    int gshift;    // log2(groupsize) or -1
     int ntm, ntn;  // tiles along M and N
+    u64_t *dbg;    // development: per-wave phase stamps of slab 8 ([block][wave][8]) or nullptr
 };
 
 constexpr int GM = 256, GN = 256, GK = 64;
 constexpr int KB = GK / 8;                 // k8-blocks per slab
 constexpr int ROWB = KB * 16 + 16;         // LDS row stride in bytes (144): 16-B pad kills bank conflicts
 constexpr int TILE_BYTES = GM * ROWB;      // one A (or B) buffer: 36 864 B
-constexpr int CROW = 128 * 2 + 16;         // epilogue row stride (bytes) of a wave's 128 x 128 fp16 block
+constexpr int NWAVE = 8, WN = 4;            // waves per workgroup, waves along N (2 along M)
+constexpr int WTN = GN / WN;               // columns per wave (64)
+constexpr int CROW = WTN * 2 + 16;         // epilogue row stride (bytes) of a wave's 128 x 64 fp16 block
 
 // 8 consecutive k (one k8-block) of one column -> 8 halves with the reference's numerics.
 //   words : the packed words covering the block (4-bit: 1, 8-bit: 2; 2-bit handled by the caller)
@@ -70,18 +75,19 @@ GPTQ_DEV half8_t dequant8<8>(const uint32_t *w, half2_t zc, half2_t s2, uint32_t
 }
 
 template <int BITS>
-__global__ void __launch_bounds__(256) gemm_mfma_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
     using UP = Unpack<BITS>;
     constexpr int KPW = UP::KPW;
     constexpr int WPB = 8 / KPW;      // words per k8-block (4-bit: 1, 8-bit: 2)
-    constexpr int NW = KB * WPB;      // words per thread per slab
+    constexpr int KBT = KB / 2;       // k8-blocks per thread per slab (two threads share a column)
+    constexpr int NW = KBT * WPB;     // words per thread per slab
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *As = smem;                       // [2][GM][ROWB]
     char *Bs = smem + 2 * TILE_BYTES;      // [2][GN][ROWB]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware tile order: XCD x (= block % 8) walks M tiles x, x+8, ... and all N tiles of each
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -91,93 +97,145 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const GemmParams p) {
     const int M = p.M, N = p.N, K = p.K;
 
     // ---- global -> register staging maps ------------------------------------------------------
-    // A: chunk c = tid + 256*i (i < 8): row = c / 8, kb = c % 8 -> 8 lanes cover one 128-B row segment
-    const half_t *aptr[8];
-    int aoff[8];
+    // A: chunk c = tid + 512*i (i < 4): row = c / 8, kb = c % 8 -> 8 lanes cover one 128-B row segment
+    constexpr int NA = GM * KB / 512;
+    const half_t *aptr[NA];
+    int aoff[NA];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int c = tid + 256 * i, row = c >> 3, kb = c & 7;
+    for (int i = 0; i < NA; i++) {
+        const int c = tid + 512 * i, row = c >> 3, kb = c & 7;
         const int m = min(m0 + row, M - 1);
         aptr[i] = p.a + (size_t)m * p.lda + kb * 8;
         aoff[i] = row * ROWB + kb * 16;
     }
-    // B: thread = column n0 + tid, all KB blocks of the slab
-    const int nb = min(n0 + tid, N - 1);
+    // B: thread = column n0 + (tid & 255), k8-blocks kb0 .. kb0 + KBT - 1 of the slab
+    const int bcol = tid & 255, kb0 = (tid >> 8) * KBT;
+    const int nb = min(n0 + bcol, N - 1);
     const uint32_t *bptr = p.qw + nb;
-    const int boff = tid * ROWB;
+    const int boff = bcol * ROWB;
     const uint32_t MSK = sreg_const(UP::MSK_C), MAG = vreg_const(UP::MAG_C);
     const int ldz = N / KPW;
 
-    u32x4 areg[8];
+    u32x4 areg[NA];
     uint32_t breg[NW];
+    half_t sreg;      // scale and packed-zero word of the slab's group for this thread's column: prefetched
+    uint32_t zreg;    // with the weights so that their L2 latency is not paid inside the move phase
     auto load_global = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) areg[i] = *(const u32x4 *)(aptr[i] + k0);
+        for (int i = 0; i < NA; i++) areg[i] = *(const u32x4 *)(aptr[i] + k0);
 #pragma unroll
-        for (int w = 0; w < NW; w++) breg[w] = bptr[(size_t)(k0 / KPW + w) * N];
+        for (int w = 0; w < NW; w++) breg[w] = bptr[(size_t)((k0 + kb0 * 8) / KPW + w) * N];
+        const int kfirst = k0 + kb0 * 8;
+        const int g = p.gshift >= 0 ? (kfirst >> p.gshift) : (kfirst / p.groupsize);
+        sreg = p.sc[(size_t)g * N + nb];
+        zreg = (uint32_t)p.qz[(size_t)g * ldz + nb / KPW];
     };
-    int g_cur = -1;
-    half2_t zc = {(half_t)0, (half_t)0}, s2 = {(half_t)0, (half_t)0};
-    auto store_lds = [&](int buf, int k0) {
+    // the thread's KBT k8-blocks (32 consecutive k) lie in ONE group (groupsize % 32 == 0)
+    u64_t tm1 = 0, tm2 = 0;
+    auto store_lds = [&](int buf) {
         char *ad = As + buf * TILE_BYTES, *bd = Bs + buf * TILE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 8; i++) *(u32x4 *)(ad + aoff[i]) = areg[i];
+        for (int i = 0; i < NA; i++) *(u32x4 *)(ad + aoff[i]) = areg[i];
+        if (p.dbg) { __builtin_amdgcn_sched_barrier(0); tm1 = stamp_cycles(0); __builtin_amdgcn_sched_barrier(0); }
+        const float z = (float)(((zreg >> (BITS * (nb % KPW))) & ((1u << BITS) - 1u)) + 1u) + UP::OFF;
+        const half2_t s2 = {sreg, sreg}, zc = {(half_t)z, (half_t)z};
 #pragma unroll
-        for (int kb = 0; kb < KB; kb++) {
-            const int g = (k0 + kb * 8) / p.groupsize;  // uniform over the workgroup
-            if (g != g_cur) {
-                g_cur = g;
-                const half_t s = p.sc[(size_t)g * N + nb];
-                const float z = (float)zero_of<BITS>(p.qz + (size_t)g * ldz, nb) + UP::OFF;
-                s2 = half2_t{s, s};
-                zc = half2_t{(half_t)z, (half_t)z};
-            }
-            const half8_t v = dequant8<BITS>(&breg[kb * WPB], zc, s2, MSK, MAG);
-            *(half8_t *)(bd + boff + kb * 16) = v;
+        for (int kk = 0; kk < KBT; kk++) {
+            const half8_t v = dequant8<BITS>(&breg[kk * WPB], zc, s2, MSK, MAG);
+            *(half8_t *)(bd + boff + (kb0 + kk) * 16) = v;
         }
+        if (p.dbg) { __builtin_amdgcn_sched_barrier(0); tm2 = stamp_cycles(0); __builtin_amdgcn_sched_barrier(0); }
     };
 
-    float16_t acc[4][4];  // [n tile][m tile] (operands swapped: rows of D are n)
+    constexpr int TN = WTN / 32;  // n tiles per wave (2)
+    float16_t acc[TN][4];         // [n tile][m tile] (operands swapped: rows of D are n)
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < TN; i++)
 #pragma unroll
         for (int jj = 0; jj < 4; jj++) acc[i][jj] = (float16_t)0.f;
 
+    // ---- main loop: ping-pong between the two wave sets of every SIMD --------------------------
+    // Waves 0-3 (set 0) and 4-7 (set 1) share the four SIMDs pairwise.  In every phase one set issues
+    // the MFMAs of its K slab while the other moves data for a later slab (wait for its prefetched
+    // global loads, dequantise, write LDS, prefetch again); s_barrier separates the phases, so the
+    // matrix pipe always has a wave feeding it while the partner's VALU / LDS / VMEM work runs in
+    // its shadow (MI355X_MICROARCH.md, "Two waves per SIMD").  Set 1 runs half an iteration late:
+    //   set 0:            compute(0) | move(1) | compute(1) | move(2) | ...
+    //   set 1:  move(1) | compute(0) | move(2) | compute(1) | ...
+    // slab j lives in LDS buffer j & 1; both shares of slab j+1 are stored before anyone computes it.
     const int nslab = K / GK;
-    load_global(0);
-    store_lds(0, 0);
-    __syncthreads();
-
-    // fragment read addresses: lane l -> row (l & 31) of the 32-row tile, k8-block (l >> 5) of the K16 step
+    const int set = wave >> 2;
+    auto phase_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);  // MFMAs are register-only: without this they drift across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto slab_k = [&](int j) { return min(j, nslab - 1) * GK; };
     const int frow = lane & 31, fkb = lane >> 5;
-    for (int it = 0; it < nslab; it++) {
-        const int buf = it & 1;
-        if (it + 1 < nslab) load_global((it + 1) * GK);
+    auto compute = [&](int j) {
+        const int buf = j & 1;
         const char *ab = As + buf * TILE_BYTES + (wm * 128 + frow) * ROWB + fkb * 16;
-        const char *bb = Bs + buf * TILE_BYTES + (wn * 128 + frow) * ROWB + fkb * 16;
+        const char *bb = Bs + buf * TILE_BYTES + (wn * WTN + frow) * ROWB + fkb * 16;
 #pragma unroll
         for (int ks = 0; ks < GK / 16; ks++) {
-            half8_t af[4], bf[4];
+            half8_t af[4], bf[TN];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                af[t] = *(const half8_t *)(ab + t * 32 * ROWB + ks * 32);
-                bf[t] = *(const half8_t *)(bb + t * 32 * ROWB + ks * 32);
-            }
+            for (int t = 0; t < 4; t++) af[t] = *(const half8_t *)(ab + t * 32 * ROWB + ks * 32);
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int t = 0; t < TN; t++) bf[t] = *(const half8_t *)(bb + t * 32 * ROWB + ks * 32);
+#pragma unroll
+            for (int i = 0; i < TN; i++)
 #pragma unroll
                 for (int jj = 0; jj < 4; jj++)
                     acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[i], af[jj], acc[i][jj], 0, 0, 0);
         }
-        if (it + 1 < nslab) store_lds(buf ^ 1, (it + 1) * GK);
-        __syncthreads();
+    };
+    // The mover runs at raised priority: its ~100 VALU / LDS / VMEM instructions only need the issue
+    // slots between the partner's MFMAs (one per 32 cycles); at equal priority the MFMA wave wins the
+    // arbitration and the move phase measured 2100 cycles instead of ~700 (tools/gemm_phases.py).
+    auto move = [&](int j) {            // registers hold slab j's share; afterwards slab j + 1's
+        __builtin_amdgcn_s_setprio(3);
+        store_lds(j & 1);
+        load_global(slab_k(j + 1));
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    load_global(0);
+    store_lds(0);                       // slab 0: every thread stores its share
+    load_global(slab_k(1));
+    __syncthreads();
+    if (set == 1) {
+        move(1);
+        phase_barrier();
     }
+    for (int j = 0; j < nslab; j++) {
+        u64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if (p.dbg && j == 8) t0 = stamp_cycles(0);
+        compute(j);
+        if (p.dbg && j == 8) t1 = stamp_cycles(__builtin_bit_cast(uint32_t, acc[0][0][0]) & 0);
+        phase_barrier();
+        u64_t t2a = 0, t2b = 0;
+        if (p.dbg && j == 8) {
+            t2 = stamp_cycles(0);
+            t2a = stamp_cycles(areg[NA - 1][0] & 0);   // all A loads of this slab have landed
+            t2b = stamp_cycles((breg[NW - 1] & 0) | (zreg & 0));   // ... and the B words / zero word
+        }
+        move(j + 1 + set);
+        if (p.dbg && j == 8) t3 = stamp_cycles(0);
+        phase_barrier();
+        if (p.dbg && j == 8 && lane == 0 && blockIdx.x < 64) {
+            u64_t *d = p.dbg + ((size_t)blockIdx.x * NWAVE + wave) * 8;
+            d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = stamp_cycles(0); d[5] = tm1; d[6] = tm2;
+        }
+    }
+    if (set == 0) phase_barrier();
+    __syncthreads();
 
     // ---- epilogue: fp32 -> fp16, transpose through LDS (wave-private region), 16-B row stores ----
     char *cs = smem + wave * (128 * CROW);
     const int ml = lane & 31, nq = (lane >> 5) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < TN; i++)
 #pragma unroll
         for (int jj = 0; jj < 4; jj++)
 #pragma unroll
@@ -189,11 +247,13 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const GemmParams p) {
             }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the region is private to this wave
     __builtin_amdgcn_wave_barrier();
-    const int c16 = lane & 15, rsub = lane >> 4;
-    const int ncol = n0 + wn * 128 + c16 * 8;
+    constexpr int LPR = WTN / 8;           // lanes per output row (16-B pieces)
+    constexpr int RPI = 64 / LPR;          // rows per store instruction
+    const int c16 = lane % LPR, rsub = lane / LPR;
+    const int ncol = n0 + wn * WTN + c16 * 8;
 #pragma unroll 4
-    for (int r = 0; r < 32; r++) {
-        const int mloc = r * 4 + rsub;
+    for (int r = 0; r < 128 / RPI; r++) {
+        const int mloc = r * RPI + rsub;
         const int m = m0 + wm * 128 + mloc;
         half8_t v = *(const half8_t *)(cs + mloc * CROW + c16 * 16);
         if (m < M && ncol < N) {
@@ -210,7 +270,8 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const GemmParams p) {
 template <int BITS>
 static int launch_gemm(const GemmParams &p, hipStream_t s) {
     auto kern = gemm_mfma_kernel<BITS>;
-    const size_t lds = 4 * (size_t)TILE_BYTES;  // 147 456 B (>= 4 * 128 * CROW for the epilogue)
+    const size_t lds = 4 * (size_t)TILE_BYTES;  // 147 456 B (== NWAVE * 128 * CROW for the epilogue)
+    static_assert(NWAVE * 128 * CROW <= 4 * TILE_BYTES, "epilogue staging must fit");
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -218,18 +279,19 @@ static int launch_gemm(const GemmParams &p, hipStream_t s) {
         configured = true;
     }
     const int groups_of_8 = (p.ntm + 7) / 8;
-    dim3 grid(groups_of_8 * 8 * p.ntn), block(256);
+    dim3 grid(groups_of_8 * 8 * p.ntn), block(512);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     return (int)hipGetLastError();
 }
 
-// Eligibility: bits in {4, 8}, trivial g_idx (checked by the caller), K % 64 == 0, groupsize % 8 == 0,
+// Eligibility: bits in {4, 8}, trivial g_idx (checked by the caller), K % 64 == 0, groupsize % 32 == 0,
 // N % 8 == 0 (always: N % 32 == 0), rows 16-byte aligned.  Everything else -> GPTQ_E_VARIANT and
 // the caller falls back to the weight-streaming kernel.
 int gemm_dispatch(int bits, bool fused2, const GemvParams &q, hipStream_t s) {
+    // q.dbg: development stamps (gptq_set_debug_buffer)
     if (fused2) return GPTQ_E_VARIANT;
     if (bits != 4 && bits != 8) return GPTQ_E_VARIANT;
-    if (q.K % GK != 0 || q.groupsize % 8 != 0 || q.ldx % 8 != 0 || q.ldy % 8 != 0) return GPTQ_E_VARIANT;
+    if (q.K % GK != 0 || q.groupsize % 32 != 0 || q.ldx % 8 != 0 || q.ldy % 8 != 0) return GPTQ_E_VARIANT;
     if (((uintptr_t)q.y % 16) != 0 || (q.bias && ((uintptr_t)q.bias % 16) != 0)) return GPTQ_E_VARIANT;
     GemmParams p;
     p.a = q.x;
@@ -244,6 +306,10 @@ int gemm_dispatch(int bits, bool fused2, const GemvParams &q, hipStream_t s) {
     p.K = q.K;
     p.N = q.N;
     p.groupsize = q.groupsize;
+    p.gshift = -1;
+    for (int i = 0; i < 31; i++)
+        if ((1 << i) == q.groupsize) p.gshift = i;
+    p.dbg = q.dbg;
     p.ntm = (q.M + GM - 1) / GM;
     p.ntn = (q.N + GN - 1) / GN;
     return bits == 4 ? launch_gemm<4>(p, s) : launch_gemm<8>(p, s);

@@ -27,6 +27,7 @@ struct Problem {
     bool fused2;
     void *ws;
     size_t ws_bytes;
+    const int32_t *xperm;  // x gathered through this permutation (re-sorted act-order layer; M == 1 rowwave only)
     const void *norm_w;  // fused RMSNorm prologue (M == 1, rowwave only)
     float norm_eps;
 };
@@ -72,6 +73,7 @@ static void fill_params(const Problem &q, int m0, int mcount, GemvParams &p) {
     p.G = n_groups(q.K, q.groupsize);
     p.groupsize = q.groupsize;
     p.ws = (u64_t *)q.ws;
+    p.xperm = q.xperm;
     p.norm_w = (const half_t *)q.norm_w;
     p.norm_eps = q.norm_eps;
     p.dbg = (u64_t *)g_debug_buffer.load();
@@ -110,6 +112,7 @@ static int run_rowwave(const Problem &q, hipStream_t s) {
         if (!u) return GPTQ_E_VARIANT;
     }
     if (q.norm_w && (u != 8 || q.bits != 4 || q.M != 1)) return GPTQ_E_VARIANT;
+    if (q.xperm && (q.bits != 4 || q.fused2 || q.norm_w)) return GPTQ_E_VARIANT;
     const int ntile = (q.N + 255) / 256;
     const int nchunk = (rows + 4 * u - 1) / (4 * u);
     const int split_max = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
@@ -429,6 +432,26 @@ int gptq_rmsnorm_fused_mlp_f16(const void *x, const void *norm_weight, float eps
     if (int rc = validate(q)) return rc;
     if (!fast_eligible(q, 32 / (bits == 3 ? 4 : bits))) return GPTQ_E_VARIANT;
     return run_rowwave(q, (hipStream_t)stream);
+}
+
+int gptq_act_order_repack(const int32_t *qweight, const int32_t *perm, int K, int N, int bits, int32_t *qweight_sorted,
+                          gptq_stream_t stream) {
+    if (!qweight || !perm || !qweight_sorted) return GPTQ_E_NULL;
+    if (bits != 2 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (K <= 0 || N <= 0 || K % 32 != 0 || N % 32 != 0) return GPTQ_E_SHAPE;
+    return act_order_repack_launch((const uint32_t *)qweight, perm, K, N, bits, (uint32_t *)qweight_sorted, (hipStream_t)stream);
+}
+
+int gptq_matmul248_sorted_f16(const void *x, int64_t ldx, const int32_t *perm, const int32_t *qweight_sorted, const void *scales,
+                              const int32_t *qzeros, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,
+                              int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream) {
+    if (!perm) return GPTQ_E_NULL;
+    Problem q = make_problem(x, ldx, qweight_sorted, scales, qzeros, nullptr, bias, y, ldy, M, K, N, bits, groupsize, workspace,
+                             workspace_bytes);
+    q.xperm = perm;
+    if (int rc = validate(q)) return rc;
+    if (!fast_eligible(q, 32 / (bits == 3 ? 4 : bits))) return GPTQ_E_VARIANT;
+    return run_rowwave(q, (hipStream_t)stream);   // one launch per row of x
 }
 
 int gptq_decode_rope_kv_f16(void *qkv, const int64_t *position, void *k_cache, void *v_cache, int heads, int head_dim, int t_max,

@@ -270,4 +270,36 @@ int pack_launch(const float *weight, const float *scales, const float *zeros, co
     return GPTQ_E_BITS;
 }
 
+// ------------------------------------------------------------------- act-order row sort
+// qweight_out row r', field j  <-  the field of k = perm[r' * f + j] in qweight (f = 32 / bits).
+// With perm = stable argsort(g_idx) every packed row of the output holds f consecutive members of
+// ONE group and the group of sorted position k' is k' / groupsize: the act-order layer becomes a
+// trivial-g_idx layer applied to x[perm] (load-time re-sort).  One-off, at load.
+template <int BITS>
+__global__ void __launch_bounds__(256) act_order_repack_kernel(const uint32_t *__restrict__ qw, const int32_t *__restrict__ perm,
+                                                               int K, int N, uint32_t *__restrict__ out) {
+    constexpr int F = 32 / BITS;
+    const int n = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (n >= N) return;
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < F; j++) {
+        const int k = perm[r * F + j];
+        const uint32_t src = qw[(size_t)(k / F) * N + n];
+        w |= ((src >> (BITS * (k % F))) & ((1u << BITS) - 1u)) << (BITS * j);
+    }
+    out[(size_t)r * N + n] = w;
+}
+
+int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s) {
+    dim3 block(256);
+    switch (bits) {
+        case 2: hipLaunchKernelGGL(act_order_repack_kernel<2>, dim3((N + 255) / 256, K / 16), block, 0, s, qw, perm, K, N, out); break;
+        case 4: hipLaunchKernelGGL(act_order_repack_kernel<4>, dim3((N + 255) / 256, K / 8), block, 0, s, qw, perm, K, N, out); break;
+        case 8: hipLaunchKernelGGL(act_order_repack_kernel<8>, dim3((N + 255) / 256, K / 4), block, 0, s, qw, perm, K, N, out); break;
+        default: return GPTQ_E_BITS;
+    }
+    return (int)hipGetLastError();
+}
+
 }  // namespace gptq

@@ -35,19 +35,25 @@ namespace gptq {
 // rms_norm_fwd_fused (reference quant/triton_norm.py:22-39) -- so that [RMSNorm -> QuantLinear] of a
 // decoder layer is ONE launch.  Every wave computes sum(x^2) redundantly from L2 while its weight
 // loads are in flight (no barrier) and normalises only the U*KPW values it needs (through LDS).
-template <int BITS, int U, bool FUSED2, bool DBG, bool NORM = false>
+// XPERM: x is gathered as x[xperm[k]] (an act-order layer whose rows were sorted by group at load
+// time, so that it is a trivial-g_idx layer of the permuted input).  Lane l fetches perm[k] and then
+// x[perm[k]] for the wave's own U*KPW values BEFORE the weights are requested (one unloaded L2 round
+// trip at kernel start; behind the weights the gather would only land after all of them) and the
+// values are broadcast through LDS like the NORM path.
+template <int BITS, int U, bool FUSED2, bool DBG, bool NORM = false, bool XPERM = false>
 __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
     const uint32_t *__restrict__ qw0, const half_t *__restrict__ x, const half_t *__restrict__ sc0,
     const int32_t *__restrict__ qz0, int N, int rows, int S, int gshift, const uint32_t *__restrict__ qw1,
     const half_t *__restrict__ sc1, const int32_t *__restrict__ qz1, half_t *__restrict__ y, u64_t *__restrict__ ws,
-    const half_t *__restrict__ bias, u64_t *__restrict__ dbg, const half_t *__restrict__ nw, float eps) {
+    const half_t *__restrict__ bias, u64_t *__restrict__ dbg, const half_t *__restrict__ nw, float eps,
+    const int32_t *__restrict__ xperm) {
     using UP = Unpack<BITS>;
     constexpr int KPW = UP::KPW, NP = UP::NP;
     constexpr int XW = KPW / 2;  // dwords of x per packed row
     constexpr int NS = FUSED2 ? 2 : 1;
     typedef uint32_t xrow_t __attribute__((ext_vector_type(XW)));
     __shared__ float red[NS][4][256];
-    __shared__ __attribute__((aligned(16))) half_t xn[NORM ? 4 : 1][NORM ? U * KPW : 8];
+    __shared__ __attribute__((aligned(16))) half_t xn[(NORM || XPERM) ? 4 : 1][(NORM || XPERM) ? U * KPW : 8];
     float rstd = 0.f;
     bool have_rstd = false;
     // NORM: this lane's share of x for sum(x^2) is requested BEFORE the weights (vector loads
@@ -99,8 +105,19 @@ __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
         uint32_t zw[NS];
         const uint32_t g = gshift >= 0 ? (row >> gshift) : 0u;
         // NORM: the raw x / norm-weight values of this wave's own rows, requested ahead of the weights
-        constexpr int XE = NORM ? (U * KPW + 63) / 64 : 1;
+        constexpr int XE = (NORM || XPERM) ? (U * KPW + 63) / 64 : 1;
         half_t xe[XE], nwe[XE];
+        if constexpr (XPERM) {
+            int32_t pk[XE];
+#pragma unroll
+            for (int i = 0; i < XE; i++) {
+                const int e = lane + 64 * i;
+                pk[i] = xperm[(size_t)row * KPW + (e < U * KPW ? e : 0)];
+            }
+#pragma unroll
+            for (int i = 0; i < XE; i++) xe[i] = x[pk[i]];   // dependent gather, still ahead of the weights
+            __builtin_amdgcn_sched_barrier(0);               // (the scheduler would sink it behind them)
+        }
         if constexpr (NORM) {
 #pragma unroll
             for (int i = 0; i < XE; i++) {
@@ -119,13 +136,26 @@ __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
             zw[s] = (uint32_t)qz[s][(size_t)g * ((uint32_t)N / KPW) + nc / KPW];
         }
         xrow_t xr[U];
-        if constexpr (!NORM) {
+        if constexpr (XPERM) {
+            // filled from LDS below
+        } else if constexpr (!NORM) {
             const xrow_t *xq = (const xrow_t *)x + row;  // wave-uniform: scalar loads
 #pragma unroll
             for (int u = 0; u < U; u++) xr[u] = xq[u];
         }
         __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is in flight before any math
         if constexpr (DBG) st[2] = stamp_cycles(0);
+        if constexpr (XPERM) {
+#pragma unroll
+            for (int i = 0; i < XE; i++) {
+                const int e = lane + 64 * i;
+                if (e < U * KPW) xn[wave][e] = xe[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < U; u++) xr[u] = *(const xrow_t *)&xn[wave][u * KPW];
+            __builtin_amdgcn_wave_barrier();
+        }
         if constexpr (NORM) {
             const int K = rows * KPW;
             if (!have_rstd) {  // once per wave: sum(x^2) over all of K (the loads were issued first)
@@ -377,12 +407,31 @@ static int launch_rowwave_norm(const GemvParams &p, hipStream_t stream) {
     const int rows = p.K / KPW;
     dim3 grid((p.N + 255) / 256, p.split_k), block(256);
     hipLaunchKernelGGL((gemv_rowwave_kernel<BITS, U, FUSED2, false, true>), grid, block, 0, stream, p.qw[0], p.x, p.sc[0], p.qz[0], p.N,
-                       rows, p.split_k, p.upg_shift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, (u64_t *)nullptr, p.norm_w, p.norm_eps);
+                       rows, p.split_k, p.upg_shift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, (u64_t *)nullptr, p.norm_w, p.norm_eps, (const int32_t *)nullptr);
+    return (int)hipGetLastError();
+}
+
+template <int BITS, int U, bool FUSED2>
+static int launch_rowwave_xperm(const GemvParams &p, hipStream_t stream) {
+    constexpr int KPW = 32 / BITS;
+    const int rows = p.K / KPW;
+    dim3 grid((p.N + 255) / 256, p.split_k), block(256);
+    hipLaunchKernelGGL((gemv_rowwave_kernel<BITS, U, FUSED2, false, false, true>), grid, block, 0, stream, p.qw[0], p.x, p.sc[0], p.qz[0],
+                       p.N, rows, p.split_k, p.upg_shift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, (u64_t *)nullptr,
+                       (const half_t *)nullptr, 0.f, p.xperm);
     return (int)hipGetLastError();
 }
 
 template <int BITS, int U, bool FUSED2>
 static int launch_rowwave(const GemvParams &p, hipStream_t stream) {
+    if (p.xperm) {
+        if constexpr (BITS == 4 && !FUSED2) {
+            if (p.norm_w) return GPTQ_E_VARIANT;
+            return launch_rowwave_xperm<BITS, U, FUSED2>(p, stream);
+        } else {
+            return GPTQ_E_VARIANT;
+        }
+    }
     if (p.norm_w) {
         if constexpr (BITS == 4 && U == 8) return launch_rowwave_norm<BITS, U, FUSED2>(p, stream);
         else return GPTQ_E_VARIANT;
@@ -395,12 +444,12 @@ static int launch_rowwave(const GemvParams &p, hipStream_t stream) {
     if (p.dbg) {
         if constexpr (BITS == 4 && U == 8) {
             hipLaunchKernelGGL((gemv_rowwave_kernel<BITS, U, FUSED2, true>), grid, block, 0, stream, p.qw[0], p.x, p.sc[0], p.qz[0], p.N,
-                               rows, p.split_k, gshift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, p.dbg, (const half_t *)nullptr, 0.f);
+                               rows, p.split_k, gshift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, p.dbg, (const half_t *)nullptr, 0.f, (const int32_t *)nullptr);
             return (int)hipGetLastError();
         }
     }
     hipLaunchKernelGGL((gemv_rowwave_kernel<BITS, U, FUSED2, false>), grid, block, 0, stream, p.qw[0], p.x, p.sc[0], p.qz[0], p.N, rows,
-                       p.split_k, gshift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, (u64_t *)nullptr, (const half_t *)nullptr, 0.f);
+                       p.split_k, gshift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, (u64_t *)nullptr, (const half_t *)nullptr, 0.f, (const int32_t *)nullptr);
     return (int)hipGetLastError();
 }
 

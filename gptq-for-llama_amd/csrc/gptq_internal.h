@@ -29,6 +29,7 @@ struct GemvParams {
     int ntiles, split_k, nchunks, chunks_per_slice;
     int units_per_group, upg_shift;  // stream kernel: groupsize / unit_k and its log2 (or -1)
     u64_t *ws;
+    const int32_t *xperm;  // non-NULL: x is read as x[xperm[k]] (act-order layer re-sorted at load; M == 1 rowwave only)
     const half_t *norm_w;  // non-NULL: RMS-normalise x on the fly with this weight (M == 1 rowwave only)
     float norm_eps;
     u64_t *dbg;  // optional timeline buffer [blocks][waves][8] (tools/timeline.py), else nullptr
@@ -51,6 +52,7 @@ int rope_launch(half_t *qk, int64_t row_stride, const int64_t *pos, int64_t pos_
 int pack_launch(const float *weight, const float *scales, const float *zeros, const int32_t *g_idx, int K,
                 int N, int G, int bits, int groupsize, int32_t *qweight, int32_t *qzeros, half_t *scales16,
                 hipStream_t s);
+int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 
 int decode_rope_kv_launch(half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, int heads, int head_dim, int t_max, float base,

@@ -169,8 +169,9 @@ class DecodeEngine:
         gi = None
         if g_idx is not None and not quant_linear.g_idx_is_trivial(g_idx, K, groupsize):
             gi = quant_linear._int32c(g_idx[:K])
-        return dict(qw=quant_linear._int32c(qweight), sc=scales, qz=quant_linear._int32c(qzeros), gi=gi, bits=bits, gs=groupsize,
-                    K=K, N=N, bias=bias)
+        qw = quant_linear._int32c(qweight)
+        srt = quant_linear.act_order_sorted(qw, gi, K, groupsize, bits) if (gi is not None and bits == 4) else None
+        return dict(qw=qw, sc=scales, qz=quant_linear._int32c(qzeros), gi=gi, bits=bits, gs=groupsize, K=K, N=N, bias=bias, srt=srt)
 
     def _pack(self, ql):
         return self._pack_raw(ql.qweight, ql.scales, ql.qzeros, ql.g_idx, ql.bits, ql.groupsize, ql.infeatures, ql.outfeatures,
@@ -182,6 +183,13 @@ class DecodeEngine:
             raise NotImplementedError('bias + fused residual')
         b = residual if residual is not None else w['bias']
         ptr = self.native.ptr
+        if w['srt'] is not None:      # act-order layer: group-sorted copy + fused x gather
+            qs, perm = w['srt']
+            rc = self.lib.gptq_matmul248_sorted_f16(x.data_ptr(), w['K'], perm.data_ptr(), qs.data_ptr(), w['sc'].data_ptr(),
+                                                    w['qz'].data_ptr(), ptr(b), y.data_ptr(), w['N'], 1, w['K'], w['N'], w['bits'],
+                                                    w['gs'], self.ws.data_ptr(), self.ws.numel(), s)
+            self.native.check(rc, 'gptq_matmul248_sorted_f16')
+            return
         rc = self.lib.gptq_matmul248_f16(x.data_ptr(), w['K'], w['qw'].data_ptr(), w['sc'].data_ptr(), w['qz'].data_ptr(), ptr(w['gi']),
                                          ptr(b), y.data_ptr(), w['N'], 1, w['K'], w['N'], w['bits'], w['gs'], self.ws.data_ptr(),
                                          self.ws.numel(), s)
@@ -194,7 +202,7 @@ class DecodeEngine:
     def _norm_gemv(self, x, nw, w, y, s):
         """y = QuantLinear(rmsnorm(x)): one launch when the fused kernel serves the shape, else two."""
         ptr = self.native.ptr
-        if self.fuse_norm and w['bias'] is None:
+        if self.fuse_norm and w['bias'] is None and w['srt'] is None:
             rc = self.lib.gptq_rmsnorm_matmul248_f16(x.data_ptr(), nw.data_ptr(), self.eps, w['qw'].data_ptr(), w['sc'].data_ptr(),
                                                      w['qz'].data_ptr(), ptr(w['gi']), None, y.data_ptr(), w['K'], w['N'], w['bits'],
                                                      w['gs'], self.ws.data_ptr(), self.ws.numel(), s)

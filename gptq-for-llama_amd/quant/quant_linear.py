@@ -57,6 +57,47 @@ def g_idx_is_trivial(g_idx, K, groupsize):
     return res
 
 
+# ----------------------------------------------------------------------------------------------
+# Act-order fast path: sort the packed rows by group once (stable argsort of g_idx) so that the
+# layer becomes a trivial-g_idx layer of x[perm].  The re-sorted copy of qweight
+# and perm are cached ON the qweight tensor (keyed by the version counters of qweight and g_idx); the
+# checkpoint buffers themselves are never modified.  Costs one extra copy of qweight per act-order
+# layer; set GPTQ_ACT_ORDER_SORT=0 to keep the generic g_idx-table kernel instead.
+# ----------------------------------------------------------------------------------------------
+import os as _os
+
+ACT_ORDER_SORT = _os.environ.get('GPTQ_ACT_ORDER_SORT', '1') != '0'
+
+
+def act_order_sorted(qweight, g_idx, K, groupsize, bits):
+    """(qweight_sorted, perm int32 [K]) or None when the layer is not a regular act-order layer
+    (every group exactly ``groupsize`` members, as gptq.py:210-216 produces) or bits == 3."""
+    if not ACT_ORDER_SORT or bits not in (2, 4, 8) or not qweight.is_cuda:
+        return None
+    f = 32 // bits
+    if groupsize % f != 0 or K % groupsize != 0:
+        return None
+    memo = getattr(qweight, '_gptq_sorted', None)
+    key = (qweight._version, g_idx._version, K, groupsize)
+    if memo is not None and memo[0] == key:
+        return memo[1]
+    g = g_idx[:K].to(torch.int64)
+    G = K // groupsize
+    res = None
+    if int(g.min()) >= 0 and int(g.max()) < G and bool((torch.bincount(g, minlength=G) == groupsize).all()):
+        perm = torch.argsort(g, stable=True).to(torch.int32).contiguous()
+        qs = torch.empty_like(qweight)
+        rc = _native.lib().gptq_act_order_repack(qweight.data_ptr(), perm.data_ptr(), K, qweight.shape[1], bits, qs.data_ptr(),
+                                                 _native.stream_ptr(qweight.device))
+        _native.check(rc, 'gptq_act_order_repack')
+        res = (qs, perm)
+    try:
+        qweight._gptq_sorted = (key, res)
+    except Exception:  # pragma: no cover
+        pass
+    return res
+
+
 def _as_rows(t):
     """2-D fp16 view whose last dim is contiguous and whose rows are 16-byte aligned."""
     if t.dtype != torch.float16:
@@ -88,6 +129,25 @@ def _prep_weight(input, qweight, scales, qzeros, g_idx, bits):
     return K, N, groupsize, qweight, scales, qzeros, gi
 
 
+def _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family):
+    """act-order layer through its group-sorted copy: fused gather + rowwave GEMV (M == 1, 4-bit), else
+    x[:, perm] with torch and the trivial-g_idx kernels."""
+    qs, perm = srt
+    lib = _native.lib()
+    if M == 1 and bits == 4 and family in (None, 'gemv'):
+        rc = lib.gptq_matmul248_sorted_f16(x.data_ptr(), K, perm.data_ptr(), qs.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
+                                           _native.ptr(bias), out.data_ptr(), N, 1, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
+                                           _native.stream_ptr(x.device))
+        if rc != -6:
+            _native.check(rc, 'gptq_matmul248_sorted_f16')
+            return
+    xp = x.index_select(1, perm.to(torch.int64))
+    rc = getattr(lib, _FAMILIES[family])(xp.data_ptr(), K, qs.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), None, _native.ptr(bias),
+                                         out.data_ptr(), N, M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
+                                         _native.stream_ptr(x.device))
+    _native.check(rc, _FAMILIES[family])
+
+
 _FAMILIES = {None: 'gptq_matmul248_f16', 'gemv': 'gptq_gemv_f16', 'skinny': 'gptq_skinny_f16'}
 
 
@@ -106,6 +166,11 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
         if M == 0:
             return out
         ws = _native.workspace(x.device)
+        if gi is not None:
+            srt = act_order_sorted(qweight, gi, K, groupsize, bits)
+            if srt is not None:
+                _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family)
+                return out
         rc = getattr(_native.lib(), _FAMILIES[family])(
             x.data_ptr(), x.stride(0) if M > 1 else K, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
             _native.ptr(gi), _native.ptr(bias), out.data_ptr(), N, M, K, N, bits, groupsize,

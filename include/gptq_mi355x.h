@@ -166,6 +166,22 @@ int gptq_g_idx_is_trivial(const int32_t *g_idx, int K, int groupsize, int32_t *o
  *   out       fp16 [heads*head_dim] = softmax(q.K^T * scale) V, fp32 math
  */
 /*
+ * Act-order fast path (extension; the reference re-gathers g_idx, scales and zeros for every k row
+ * in the kernel, quant/quant_linear.py:114-118).  With perm = stable argsort(g_idx), the re-sorted
+ * qweight (gptq_act_order_repack, one-off at load; same shape as qweight) is a trivial-g_idx layer
+ * applied to x[perm]: gptq_matmul248_sorted_f16 gathers x through perm on the scalar path and runs
+ * the rowwave GEMV (one launch per row of x; M == 1 is the intended use).  scales / qzeros are the
+ * checkpoint's own.  Valid when every group has exactly `groupsize` members (what gptq.py:210-216
+ * produces) and groupsize % (32/bits) == 0; bits == 4 in this release (else GPTQ_E_VARIANT).
+ */
+int gptq_act_order_repack(const int32_t *qweight, const int32_t *perm, int K, int N, int bits,
+                          int32_t *qweight_sorted, gptq_stream_t stream);
+int gptq_matmul248_sorted_f16(const void *x, int64_t ldx, const int32_t *perm, const int32_t *qweight_sorted,
+                              const void *scales, const int32_t *qzeros, const void *bias, void *y,
+                              int64_t ldy, int M, int K, int N, int bits, int groupsize, void *workspace,
+                              size_t workspace_bytes, gptq_stream_t stream);
+
+/*
  * [RMSNorm -> QuantLinear] and [RMSNorm -> fused gate/up] of a decoder layer as ONE launch, M == 1
  * (TritonLlamaRMSNorm.forward followed by QuantLinear.forward / triton_llama_mlp; reference
  * quant/triton_norm.py:50-67 + quant/quant_linear.py:373-377 / quant/fused_mlp.py:206-218).

@@ -220,6 +220,44 @@ def test_act_order_and_3bit(bits, M):
     check_forward(x, L)
 
 
+@pytest.mark.parametrize('bits,gs', [(4, 128), (4, 32), (8, 64), (2, 128)])
+@pytest.mark.parametrize('M', [1, 2, 70])
+def test_act_order_sorted_fast_path(bits, gs, M):
+    """act-order layers run through their group-sorted copy (one-off repack + x[perm]); the result
+    must agree with the oracle AND with the generic g_idx-table kernel on the checkpoint layout."""
+    K, N = 1024, 512
+    L = make_random_layer(bits, gs, K, N, act_order=True, seed=bits + gs + M)
+    x = np.random.default_rng(M + 5).standard_normal((M, K)).astype(np.float16)
+    qw, gi = dev(L['qweight']), dev(L['g_idx'])
+    srt = QL.act_order_sorted(qw, gi, K, gs, bits)
+    assert srt is not None and srt[0].shape == qw.shape and srt[1].shape == (K, )
+    # the sorted copy really is a trivial-g_idx layer of x[perm]
+    perm = srt[1].cpu().numpy()
+    assert np.array_equal(np.sort(perm), np.arange(K)) and np.array_equal(L['g_idx'][perm], np.arange(K) // gs)
+    ref = oracle.matmul248(x[:, perm], srt[0].cpu().numpy(), L['scales'], L['qzeros'], (np.arange(K) // gs).astype(np.int32), bits)
+    full = oracle_forward(x, L)
+    assert rel_err(ref, full) < TOL
+    y, _ = check_forward(x, L)
+    QL.ACT_ORDER_SORT = False
+    try:
+        y_generic = hip_forward(x, L)
+    finally:
+        QL.ACT_ORDER_SORT = True
+    assert rel_err(y, y_generic) < TOL
+
+
+def test_act_order_irregular_groups_stay_generic():
+    """a g_idx whose groups do not all have `groupsize` members cannot be sorted into the trivial
+    layout: the generic kernel serves it."""
+    K, N = 512, 256
+    L = make_random_layer(4, 128, K, N, act_order=True, seed=3)
+    L['g_idx'] = L['g_idx'].copy()
+    L['g_idx'][:5] = 0
+    assert QL.act_order_sorted(dev(L['qweight']), dev(L['g_idx']), K, 128, 4) is None
+    x = np.random.default_rng(1).standard_normal((1, K)).astype(np.float16)
+    check_forward(x, L)
+
+
 @pytest.mark.parametrize('gs', [-1, 128])
 def test_3bit_no_group(gs):
     L = make_random_layer(3, gs, 1024, 256, seed=33)

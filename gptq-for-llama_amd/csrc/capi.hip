@@ -88,7 +88,54 @@ static int ilog2_exact(int v) {
 // The rowwave GEMV (gemv.hip) serves M == 1; larger M here means M launches (the dispatcher
 // sends M >= 2 to the weight-streaming MFMA kernel instead).  Picks U = packed rows in flight
 // per wave and S = workgroups per 256-column tile (DESIGN.md "dispatch").
+// 3-bit rowwave: units are 32-k blocks (3 packed rows each)
+static int run_rowwave3(const Problem &q, hipStream_t s) {
+    if (q.fused2 || q.norm_w || q.xperm) return GPTQ_E_VARIANT;
+    const int nblocks = q.K / 32;
+    const int G = n_groups(q.K, q.groupsize);
+    int gshift = -1;
+    if (G > 1) {
+        if (q.groupsize % 32 != 0) return GPTQ_E_VARIANT;
+        gshift = ilog2_exact(q.groupsize / 32);
+        if (gshift < 0) return GPTQ_E_VARIANT;
+    }
+    const int bpg = G > 1 ? q.groupsize / 32 : nblocks;
+    int u = 0;
+    const int fv = g_force_variant.load();
+    for (int c = 2; c >= 1 && !u; c >>= 1)
+        if (nblocks % c == 0 && (G == 1 || bpg % c == 0)) u = c;
+    if (fv >= 0) {
+        if (fv > 1) return GPTQ_E_VARIANT;
+        u = 2 >> fv;
+        if (!(nblocks % u == 0 && (G == 1 || bpg % u == 0))) return GPTQ_E_VARIANT;
+    }
+    const int ntile = (q.N + 255) / 256;
+    const int nchunk = (nblocks + 4 * u - 1) / (4 * u);
+    int split_k = nchunk;
+    if (ntile * split_k > 1024) split_k = 1024 / ntile;
+    if (split_k < 1) split_k = 1;
+    const int fs = g_force_split_k.load();
+    if (fs >= 1) split_k = fs;
+    if (split_k > nchunk) split_k = nchunk;
+    if (split_k > SPLITK_MAX_SINGLE) split_k = SPLITK_MAX_SINGLE;
+    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)q.N * 8;
+    if (split_k > 1 && !ws_ok) {
+        if (fs >= 1) return GPTQ_E_WORKSPACE;
+        split_k = 1;
+    }
+    for (int m = 0; m < q.M; m++) {
+        GemvParams p;
+        fill_params(q, m, 1, p);
+        p.split_k = split_k;
+        p.upg_shift = gshift;
+        int rc = gemv_fast_dispatch(3, false, u, p, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 static int run_rowwave(const Problem &q, hipStream_t s) {
+    if (q.bits == 3) return run_rowwave3(q, s);
     const int kpw = 32 / q.bits;
     const int rows = q.K / kpw;
     const int G = n_groups(q.K, q.groupsize);
@@ -167,7 +214,8 @@ static int run_generic(const Problem &q, hipStream_t s) {
 }
 
 static int run_gemv(const Problem &q, hipStream_t s) {
-    if (fast_eligible(q, 32 / (q.bits == 3 ? 4 : q.bits))) {
+    const bool eligible3 = q.bits == 3 && !q.fused2 && !q.gi[0] && q.M <= GEMV_MAX_M;   // one launch per row
+    if (eligible3 || fast_eligible(q, 32 / (q.bits == 3 ? 4 : q.bits))) {
         int rc = run_rowwave(q, s);
         if (rc != GPTQ_E_VARIANT || g_force_variant.load() >= 0) return rc;
     }

@@ -267,6 +267,105 @@ __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// 3-bit rowwave (EXTENSION: the reference rejects bits == 3, quant_linear.py:308-309).
+// A 32-k block of a column is a dense little-endian 96-bit stream over 3 consecutive packed rows;
+// a wave takes UB blocks (3*UB row loads of 1 KiB), x of a block is 16 SGPR dwords, and pair i of
+// the stream (fields 2i, 2i+1 = 6 bits at bit 6i) lines up with x dword i:
+//     t = bfe(stream, 6i, 6);  half2 = ((t << 13 | t) & 0x00070007) | 0x64006400 = {1024+q0, 1024+q1}
+// The 1024 offset is removed per BLOCK (a - 1024 * sum x) before the group accumulator so that a
+// single group over all of K (3-bit "no-group" checkpoints) keeps fp32 accuracy.
+// ---------------------------------------------------------------------------------------
+template <int UB>
+__global__ void __launch_bounds__(256) gemv_rowwave3_kernel(const uint32_t *__restrict__ qw, const half_t *__restrict__ x,
+                                                            const half_t *__restrict__ sc, const int32_t *__restrict__ qz, int N,
+                                                            int nblocks, int S, int gshift, half_t *__restrict__ y,
+                                                            u64_t *__restrict__ ws, const half_t *__restrict__ bias) {
+    typedef uint32_t x16_t __attribute__((ext_vector_type(16)));
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = blockIdx.x, slice = blockIdx.y;
+    const uint32_t n0 = tile * 256 + lane * 4;
+    const uint32_t nc = n0 < (uint32_t)N ? n0 : 0;
+    const uint32_t nchunk = ((uint32_t)nblocks + 4 * UB - 1) / (4 * UB);
+    const half2_t ones = {(half_t)1.0f, (half_t)1.0f};
+    const uint32_t MSK = sreg_const(0x00070007u), MAG = vreg_const(0x64006400u);
+    const int ldz = N / 32 * 3;
+
+    float yv[4] = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t c = slice; c < nchunk; c += (uint32_t)S) {
+        const uint32_t blk0 = c * (4 * UB) + wave * UB;   // first 32-k block of this wave (uniform)
+        if (blk0 >= (uint32_t)nblocks) continue;           // nblocks % UB == 0
+        const uint32_t g = gshift >= 0 ? (blk0 >> gshift) : 0u;
+        u32x4 w[UB][3];
+#pragma unroll
+        for (int b = 0; b < UB; b++)
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+                w[b][r] = __builtin_nontemporal_load((const u32x4 *)(qw + (size_t)((blk0 + b) * 3 + r) * (uint32_t)N + nc));
+        const half4_t s4 = *(const half4_t *)(sc + (size_t)g * (uint32_t)N + nc);
+        const uint32_t *zrow = (const uint32_t *)qz + (size_t)g * ldz + 3 * (nc >> 5);
+        const uint32_t z0 = zrow[0], z1 = zrow[1], z2 = zrow[2];
+        const x16_t *xq = (const x16_t *)x + blk0;
+        x16_t xr[UB];
+#pragma unroll
+        for (int b = 0; b < UB; b++) xr[b] = xq[b];
+        __builtin_amdgcn_sched_barrier(0);
+
+        float gacc[4] = {0.f, 0.f, 0.f, 0.f};
+        float xs_g = 0.f;
+#pragma unroll
+        for (int b = 0; b < UB; b++) {
+            float xs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) xs = __builtin_amdgcn_fdot2(as_half2(xr[b][i]), ones, xs, false);
+            xs_g += xs;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t a0 = w[b][0][j], a1 = w[b][1][j], a2 = w[b][2][j];
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int bit = 6 * i;
+                    uint32_t t;
+                    if (bit + 6 <= 32) t = __builtin_amdgcn_ubfe(a0, bit, 6);
+                    else if (bit < 32) t = __builtin_amdgcn_alignbit(a1, a0, bit) & 0x3Fu;
+                    else if (bit + 6 <= 64) t = __builtin_amdgcn_ubfe(a1, bit - 32, 6);
+                    else if (bit < 64) t = __builtin_amdgcn_alignbit(a2, a1, bit - 32) & 0x3Fu;
+                    else t = __builtin_amdgcn_ubfe(a2, bit - 64, 6);
+                    const uint32_t h = (((t << 13) | t) & MSK) | MAG;
+                    a = __builtin_amdgcn_fdot2(as_half2(h), as_half2(xr[b][i]), a, false);
+                }
+                gacc[j] += a - 1024.0f * xs;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int bit = 3 * ((nc + j) & 31), wi = bit >> 5, o = bit & 31;
+            const uint64_t lo = wi == 0 ? z0 : (wi == 1 ? z1 : z2);
+            const uint64_t hi = wi == 0 ? z1 : (wi == 1 ? z2 : 0u);
+            const float zf = (float)((uint32_t)(((lo | (hi << 32)) >> o) & 7u) + 1u);
+            yv[j] += (float)s4[j] * (gacc[j] - zf * xs_g);
+        }
+    }
+    *(float4_t *)&red[wave][4 * lane] = float4_t{yv[0], yv[1], yv[2], yv[3]};
+    __syncthreads();
+    const int t = threadIdx.x;
+    const uint32_t n = tile * 256 + t;
+    float t0 = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    if (n < (uint32_t)N) {
+        bool mine = true;
+        if (S > 1) mine = splitk_add1(ws + n, t0, S, t0);
+        if (mine) {
+            half_t h = (half_t)t0;
+            if (bias) h = (half_t)((float)h + (float)bias[n]);
+            y[n] = h;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // generic path: any g_idx (act-order), any group size, bits in {2,3,4,8}.  A {scale, zero}
 // table for the tile's columns lives in LDS ([G][TILE] of half2{s, z}) and is indexed by
@@ -487,6 +586,17 @@ static int launch_rowwave_u(int u, const GemvParams &p, hipStream_t s) {
 // in one quantisation group); p.split_k = workgroups per 256-column tile; p.upg_shift = log2 of
 // the packed rows per group or -1 (one group); p.ws zeroed workspace when split_k > 1.
 int gemv_fast_dispatch(int bits, bool fused2, int u, const GemvParams &p, hipStream_t s) {
+    if (bits == 3) {   // u = 32-k blocks in flight per wave (2 or 1); p.upg_shift = log2(blocks per group) or -1
+        if (fused2 || p.norm_w || p.xperm) return GPTQ_E_VARIANT;
+        dim3 grid((p.N + 255) / 256, p.split_k), block(256);
+        const int nblocks = p.K / 32;
+        if (u == 2) hipLaunchKernelGGL(gemv_rowwave3_kernel<2>, grid, block, 0, s, p.qw[0], p.x, p.sc[0], p.qz[0], p.N, nblocks, p.split_k,
+                                       p.upg_shift, p.y, p.ws, p.bias);
+        else if (u == 1) hipLaunchKernelGGL(gemv_rowwave3_kernel<1>, grid, block, 0, s, p.qw[0], p.x, p.sc[0], p.qz[0], p.N, nblocks,
+                                            p.split_k, p.upg_shift, p.y, p.ws, p.bias);
+        else return GPTQ_E_VARIANT;
+        return (int)hipGetLastError();
+    }
     switch (bits) {
         case 2: return fused2 ? launch_rowwave_u<2, true>(u, p, s) : launch_rowwave_u<2, false>(u, p, s);
         case 4: return fused2 ? launch_rowwave_u<4, true>(u, p, s) : launch_rowwave_u<4, false>(u, p, s);

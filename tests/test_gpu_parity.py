@@ -258,6 +258,22 @@ def test_act_order_irregular_groups_stay_generic():
     check_forward(x, L)
 
 
+@pytest.mark.parametrize('gs', [-1, 32, 64, 128])
+@pytest.mark.parametrize('K,N,M', [(4096, 512, 1), (1056, 288, 3), (96, 32, 1), (11008, 256, 1)])
+def test_3bit_rowwave(gs, K, N, M):
+    """the 3-bit rowwave GEMV (EXTENSION, no reference: checked against the oracle's own 3-bit
+    restatement and the float64 exact product); incl. one group over all of K and ragged shapes."""
+    if gs != -1 and K % gs:
+        pytest.skip('K not a multiple of the group')
+    L = make_random_layer(3, gs, K, N, seed=K + N + gs)
+    rng = np.random.default_rng(K)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float16)
+    y, ref = check_forward(x, L, bias=bias)
+    ye = oracle.matmul248_exact(x, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 3) + bias.astype(np.float64)
+    assert rel_err(y, ye) < TOL
+
+
 @pytest.mark.parametrize('gs', [-1, 128])
 def test_3bit_no_group(gs):
     L = make_random_layer(3, gs, 1024, 256, seed=33)

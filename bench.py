@@ -255,7 +255,7 @@ def main():
             'metric': 'int4 g128 matvec GB/s (LLaMA-7B 4-bit batch-1 decode pass over all quantised linears)',
             'value': round(value, 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'int4 weights, fp16 activations, fp32 accumulate', 'data': 'synthetic',
+            'dtype': 'f16 (int4 weights dequantised on the fly, f32 accumulate)', 'data': 'synthetic',
             'config': {'workload': 'LLaMA-7B-shaped 4-bit g128 matvec, batch=1 seq=1 (BASELINE configs[1]): 32 layers x '
                                    '{qkv 4096x12288, o 4096x4096, gate/up+SiLU 2x4096x11008, down 11008x4096}',
                        'launches_per_step': work.launches_per_step, 'algorithmic_bytes_per_step': work.bytes_per_step,

@@ -12,8 +12,10 @@
 //    the reference's tl.dot does; a packed word (8 consecutive k of one column) IS one B fragment
 //    (8 halves of one column per lane), so the LDS layout is [n][k8-block] rows of 16-byte
 //    fragments (row stride 144 B: conflict-free ds_write_b128 and ds_read_b128);
-//  * A goes global -> registers -> LDS in the same [m][k8-block] layout, 128-byte row segments
-//    per 8 lanes; LDS is double buffered: one barrier per K slab;
+//  * A goes global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write): a wave
+//    instruction lands 8 rows x 128 B contiguously; rows are unpadded and the 16-byte chunks of a row
+//    are XOR-swizzled (slot = k8-block ^ ((row >> 1) & 7)) on the GLOBAL side, which makes the
+//    ds_read_b128 of 32 consecutive rows conflict-free; LDS is double buffered;
 //  * operands are swapped in the MFMA (D = Bfrag^T-major) so that each lane ends with 4
 //    consecutive n of one m: the epilogue transposes through LDS and writes 16 B per lane,
 //    256 contiguous bytes per row;
@@ -42,7 +44,9 @@ struct GemmParams {
 constexpr int GM = 256, GN = 256, GK = 64;
 constexpr int KB = GK / 8;                 // k8-blocks per slab
 constexpr int ROWB = KB * 16 + 16;         // LDS row stride in bytes (144): 16-B pad kills bank conflicts
-constexpr int TILE_BYTES = GM * ROWB;      // one A (or B) buffer: 36 864 B
+constexpr int TILE_BYTES = GM * ROWB;      // one B buffer: 36 864 B
+constexpr int AROW = KB * 16;              // A rows are unpadded (LDS-DMA writes 1 KiB contiguously)
+constexpr int ATILE_BYTES = GM * AROW;     // one A buffer: 32 768 B
 constexpr int NWAVE = 8, WN = 4;            // waves per workgroup, waves along N (2 along M)
 constexpr int WTN = GN / WN;               // columns per wave (64)
 constexpr int CROW = WTN * 2 + 16;         // epilogue row stride (bytes) of a wave's 128 x 64 fp16 block
@@ -82,8 +86,8 @@ __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
     constexpr int KBT = KB / 2;       // k8-blocks per thread per slab (two threads share a column)
     constexpr int NW = KBT * WPB;     // words per thread per slab
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *As = smem;                       // [2][GM][ROWB]
-    char *Bs = smem + 2 * TILE_BYTES;      // [2][GN][ROWB]
+    char *As = smem;                       // [2][GM][AROW], swizzled
+    char *Bs = smem + 2 * ATILE_BYTES;     // [2][GN][ROWB]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,47 +100,80 @@ __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
     const int m0 = tm * GM, n0 = tn * GN;
     const int M = p.M, N = p.N, K = p.K;
 
-    // ---- global -> register staging maps ------------------------------------------------------
-    // A: chunk c = tid + 512*i (i < 4): row = c / 8, kb = c % 8 -> 8 lanes cover one 128-B row segment
+    // ---- A: LDS-DMA map ----------------------------------------------------------------------
+    // wave w issues NA instructions per slab; instruction i covers rows 8*(4w+i) .. +7 (1 KiB of LDS);
+    // lane l lands at row 8*(4w+i) + l/8, slot l%8 and therefore FETCHES k8-block (l%8) ^ ((row>>1)&7)
     constexpr int NA = GM * KB / 512;
     const half_t *aptr[NA];
-    int aoff[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
-        const int c = tid + 512 * i, row = c >> 3, kb = c & 7;
+        const int row = 8 * (NA * wave + i) + (lane >> 3);
+        const int kb = (lane & 7) ^ ((row >> 1) & 7);
         const int m = min(m0 + row, M - 1);
         aptr[i] = p.a + (size_t)m * p.lda + kb * 8;
-        aoff[i] = row * ROWB + kb * 16;
     }
-    // B: thread = column n0 + (tid & 255), k8-blocks kb0 .. kb0 + KBT - 1 of the slab
+    auto dma_a = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(aptr[i] + k0),
+                                             (__attribute__((address_space(3))) void *)(As + buf * ATILE_BYTES + (NA * wave + i) * 1024), 16,
+                                             0, 0);
+    };
+    // B: thread = column n0 + (tid & 255), k8-blocks kb0 .. kb0 + KBT - 1 of the slab.  4-bit: the quad
+    // (4 lanes = 4 adjacent columns) fetches its 4 x 4 words as ONE dwordx4 per lane (lane i takes packed
+    // row kb0 + i, columns of the whole quad) and transposes in registers (2 DPP stages): a quarter of
+    // the VMEM instructions -- the move phase is bound by their issue (tools/gemm_phases.py)
     const int bcol = tid & 255, kb0 = (tid >> 8) * KBT;
     const int nb = min(n0 + bcol, N - 1);
     const uint32_t *bptr = p.qw + nb;
+    const int nb4 = min(n0 + (bcol & ~3), N - 4);
+    const uint32_t *bptr4 = p.qw + nb4 + (size_t)(tid & 3) * N;
     const int boff = bcol * ROWB;
     const uint32_t MSK = sreg_const(UP::MSK_C), MAG = vreg_const(UP::MAG_C);
     const int ldz = N / KPW;
 
-    u32x4 areg[NA];
     uint32_t breg[NW];
+    int g_loaded = -1;
     half_t sreg;      // scale and packed-zero word of the slab's group for this thread's column: prefetched
     uint32_t zreg;    // with the weights so that their L2 latency is not paid inside the move phase
     auto load_global = [&](int k0) {
+        if constexpr (BITS == 4) {
+            const u32x4 v = *(const u32x4 *)(bptr4 + (size_t)((k0 + kb0 * 8) / KPW) * N);
+            breg[0] = v[0]; breg[1] = v[1]; breg[2] = v[2]; breg[3] = v[3];
+        } else {
 #pragma unroll
-        for (int i = 0; i < NA; i++) areg[i] = *(const u32x4 *)(aptr[i] + k0);
-#pragma unroll
-        for (int w = 0; w < NW; w++) breg[w] = bptr[(size_t)((k0 + kb0 * 8) / KPW + w) * N];
+            for (int w = 0; w < NW; w++) breg[w] = bptr[(size_t)((k0 + kb0 * 8) / KPW + w) * N];
+        }
         const int kfirst = k0 + kb0 * 8;
         const int g = p.gshift >= 0 ? (kfirst >> p.gshift) : (kfirst / p.groupsize);
-        sreg = p.sc[(size_t)g * N + nb];
-        zreg = (uint32_t)p.qz[(size_t)g * ldz + nb / KPW];
+        if (g != g_loaded) {   // uniform over each half of the workgroup: once per group, not per slab
+            g_loaded = g;
+            sreg = p.sc[(size_t)g * N + nb];
+            zreg = (uint32_t)p.qz[(size_t)g * ldz + nb / KPW];
+        }
+    };
+    // 4 x 4 transpose inside a quad: afterwards lane i holds column i's words of packed rows kb0 .. kb0+3
+    auto quad_transpose = [&]() {
+        const bool odd = tid & 1, hi = tid & 2;
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {   // exchange with lane ^ 1
+            const uint32_t send = odd ? breg[k] : breg[k + 1];
+            const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+            if (odd) breg[k] = recv; else breg[k + 1] = recv;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {      // exchange with lane ^ 2
+            const uint32_t send = hi ? breg[k] : breg[k + 2];
+            const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+            if (hi) breg[k] = recv; else breg[k + 2] = recv;
+        }
     };
     // the thread's KBT k8-blocks (32 consecutive k) lie in ONE group (groupsize % 32 == 0)
     u64_t tm1 = 0, tm2 = 0;
     auto store_lds = [&](int buf) {
-        char *ad = As + buf * TILE_BYTES, *bd = Bs + buf * TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < NA; i++) *(u32x4 *)(ad + aoff[i]) = areg[i];
+        char *bd = Bs + buf * TILE_BYTES;
         if (p.dbg) { __builtin_amdgcn_sched_barrier(0); tm1 = stamp_cycles(0); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (BITS == 4) quad_transpose();
         const float z = (float)(((zreg >> (BITS * (nb % KPW))) & ((1u << BITS) - 1u)) + 1u) + UP::OFF;
         const half2_t s2 = {sreg, sreg}, zc = {(half_t)z, (half_t)z};
 #pragma unroll
@@ -174,13 +211,15 @@ __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
     const int frow = lane & 31, fkb = lane >> 5;
     auto compute = [&](int j) {
         const int buf = j & 1;
-        const char *ab = As + buf * TILE_BYTES + (wm * 128 + frow) * ROWB + fkb * 16;
+        const char *ab = As + buf * ATILE_BYTES + (wm * 128 + frow) * AROW;
         const char *bb = Bs + buf * TILE_BYTES + (wn * WTN + frow) * ROWB + fkb * 16;
+        const int swz = (frow >> 1) & 7;   // rows wm*128 + t*32 + frow: (row >> 1) & 7 depends on frow only
 #pragma unroll
         for (int ks = 0; ks < GK / 16; ks++) {
             half8_t af[4], bf[TN];
+            const int aslot = ((ks * 2 + fkb) ^ swz) * 16;
 #pragma unroll
-            for (int t = 0; t < 4; t++) af[t] = *(const half8_t *)(ab + t * 32 * ROWB + ks * 32);
+            for (int t = 0; t < 4; t++) af[t] = *(const half8_t *)(ab + t * 32 * AROW + aslot);
 #pragma unroll
             for (int t = 0; t < TN; t++) bf[t] = *(const half8_t *)(bb + t * 32 * ROWB + ks * 32);
 #pragma unroll
@@ -190,45 +229,71 @@ __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
                     acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[i], af[jj], acc[i][jj], 0, 0, 0);
         }
     };
-    // The mover runs at raised priority: its ~100 VALU / LDS / VMEM instructions only need the issue
-    // slots between the partner's MFMAs (one per 32 cycles); at equal priority the MFMA wave wins the
-    // arbitration and the move phase measured 2100 cycles instead of ~700 (tools/gemm_phases.py).
-    auto move = [&](int j) {            // registers hold slab j's share; afterwards slab j + 1's
+    // move(j): B of slab j from the prefetch registers into LDS, then prefetch B of slab j + 1
+    auto move_b = [&](int j) {
         __builtin_amdgcn_s_setprio(3);
         store_lds(j & 1);
         load_global(slab_k(j + 1));
         __builtin_amdgcn_s_setprio(0);
     };
+    auto wait_vm = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
+    // A of slab m is requested by LDS-DMA one and a half phases before its first reader and awaited
+    // (vmcnt) by the issuing wave just before the barrier that publishes it:
+    //   set 0:  [dma A(j+1); compute(j)] | [B(j+1) -> LDS; wait; prefetch B(j+2)] | ...
+    //   set 1:  [dma A(j+2); B(j+2) -> LDS; prefetch B(j+3)] | [compute(j+1); wait] | ...
+    // buffer (j+1)&1 is free as soon as set 1 has finished compute(j-1), i.e. exactly when these
+    // phases begin.
+    dma_a(0, 0);
     load_global(0);
-    store_lds(0);                       // slab 0: every thread stores its share
+    store_lds(0);                       // slab 0: every thread stores its B share
     load_global(slab_k(1));
+    wait_vm();
     __syncthreads();
-    if (set == 1) {
-        move(1);
-        phase_barrier();
-    }
-    for (int j = 0; j < nslab; j++) {
-        u64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-        if (p.dbg && j == 8) t0 = stamp_cycles(0);
-        compute(j);
-        if (p.dbg && j == 8) t1 = stamp_cycles(__builtin_bit_cast(uint32_t, acc[0][0][0]) & 0);
-        phase_barrier();
-        u64_t t2a = 0, t2b = 0;
-        if (p.dbg && j == 8) {
-            t2 = stamp_cycles(0);
-            t2a = stamp_cycles(areg[NA - 1][0] & 0);   // all A loads of this slab have landed
-            t2b = stamp_cycles((breg[NW - 1] & 0) | (zreg & 0));   // ... and the B words / zero word
+    if (set == 0) {
+        for (int j = 0; j < nslab; j++) {
+            u64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            if (p.dbg && j == 8) t0 = stamp_cycles(0);
+            dma_a((j + 1) & 1, slab_k(j + 1));
+            compute(j);
+            if (p.dbg && j == 8) t1 = stamp_cycles(__builtin_bit_cast(uint32_t, acc[0][0][0]) & 0);
+            phase_barrier();
+            if (p.dbg && j == 8) t2 = stamp_cycles(0);
+            __builtin_amdgcn_s_setprio(3);
+            store_lds((j + 1) & 1);
+            wait_vm();                   // A(j+1) of this wave has landed (requested a phase and a half ago)
+            load_global(slab_k(j + 2));
+            __builtin_amdgcn_s_setprio(0);
+            if (p.dbg && j == 8) t3 = stamp_cycles(0);
+            phase_barrier();
+            if (p.dbg && j == 8 && lane == 0 && blockIdx.x < 64) {
+                u64_t *d = p.dbg + ((size_t)blockIdx.x * NWAVE + wave) * 8;
+                d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = stamp_cycles(0); d[5] = tm1; d[6] = tm2;
+            }
         }
-        move(j + 1 + set);
-        if (p.dbg && j == 8) t3 = stamp_cycles(0);
         phase_barrier();
-        if (p.dbg && j == 8 && lane == 0 && blockIdx.x < 64) {
-            u64_t *d = p.dbg + ((size_t)blockIdx.x * NWAVE + wave) * 8;
-            d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = stamp_cycles(0); d[5] = tm1; d[6] = tm2;
+    } else {
+        dma_a(1, slab_k(1));
+        move_b(1);
+        phase_barrier();
+        for (int j = 0; j < nslab; j++) {
+            u64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            if (p.dbg && j == 8) t0 = stamp_cycles(0);
+            compute(j);
+            wait_vm();                   // A(j+1) share (requested in the previous phase) + B prefetch
+            if (p.dbg && j == 8) t1 = stamp_cycles(__builtin_bit_cast(uint32_t, acc[0][0][0]) & 0);
+            phase_barrier();
+            if (p.dbg && j == 8) t2 = stamp_cycles(0);
+            dma_a(j & 1, slab_k(j + 2));
+            move_b(j + 2);
+            if (p.dbg && j == 8) t3 = stamp_cycles(0);
+            phase_barrier();
+            if (p.dbg && j == 8 && lane == 0 && blockIdx.x < 64) {
+                u64_t *d = p.dbg + ((size_t)blockIdx.x * NWAVE + wave) * 8;
+                d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = stamp_cycles(0); d[5] = tm1; d[6] = tm2;
+            }
         }
     }
-    if (set == 0) phase_barrier();
     __syncthreads();
 
     // ---- epilogue: fp32 -> fp16, transpose through LDS (wave-private region), 16-B row stores ----
@@ -270,7 +335,7 @@ __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
 template <int BITS>
 static int launch_gemm(const GemmParams &p, hipStream_t s) {
     auto kern = gemm_mfma_kernel<BITS>;
-    const size_t lds = 4 * (size_t)TILE_BYTES;  // 147 456 B (== NWAVE * 128 * CROW for the epilogue)
+    const size_t lds = 4 * (size_t)TILE_BYTES;  // 147 456 B: epilogue staging NWAVE * 128 * CROW (main loop: 2 A + 2 B buffers = 139 264 B)
     static_assert(NWAVE * 128 * CROW <= 4 * TILE_BYTES, "epilogue staging must fit");
     static bool configured = false;
     if (!configured) {

@@ -8,6 +8,9 @@ from . import _native
 from .quant_linear import QuantLinear, _as_rows, _int32c, g_idx_is_trivial
 
 
+PREFILL_SPLIT_M = 64
+
+
 def fused_gate_up(x, gate, up, bits, groupsize):
     """c = silu(x . deq(gate)) * (x . deq(up)); gate/up = (qweight, scales, qzeros, g_idx)."""
     _native.require_device(x, 'fused_gate_up')
@@ -17,6 +20,14 @@ def fused_gate_up(x, gate, up, bits, groupsize):
     gis = []
     for (qw, sc, qz, gi) in (gate, up):
         gis.append(None if (gi is None or g_idx_is_trivial(gi, K, groupsize)) else _int32c(gi[:K]))
+    if M > PREFILL_SPLIT_M and all(gi is None for gi in gis) and bits in (4, 8):
+        # prefill: two MFMA-tile GEMMs + the SiLU*mul epilogue in fp32 (the one-launch fused kernel only
+        # exists for the weight-streaming regime, M <= 64)
+        from .quant_linear import matmul248
+        g = matmul248(x2, gate[0], gate[1], gate[2], None, bits, 2**bits - 1)
+        u = matmul248(x2, up[0], up[1], up[2], None, bits, 2**bits - 1)
+        gf = g.float()
+        return (gf * torch.sigmoid(gf) * u.float()).half()
     with torch.cuda.device(x.device):
         c = torch.empty((M, N), device=x.device, dtype=torch.float16)
         if M:

@@ -343,6 +343,19 @@ def test_fused_mlp_split_k(split_k):
     assert np.array_equal(c.view(np.uint16), c2.view(np.uint16))
 
 
+def test_fused_mlp_prefill_goes_through_the_gemm():
+    """M > 64: gate and up through the MFMA tile GEMM + fp32 SiLU*mul, against the fused oracle."""
+    K, N, M = 512, 256, 200
+    A = make_random_layer(4, 128, K, N, seed=31)
+    B = make_random_layer(4, 128, K, N, seed=32)
+    x = np.random.default_rng(4).standard_normal((M, K)).astype(np.float16)
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 128).cpu().numpy()
+    ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), 4)
+    assert rel_err(c, ref) < 2e-3
+
+
 def test_llama7b_fused_mlp_full_size():
     K, N = 4096, 11008
     A = make_random_layer(4, 128, K, N, seed=1)

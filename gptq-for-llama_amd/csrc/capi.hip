@@ -482,6 +482,15 @@ int gptq_rmsnorm_fused_mlp_f16(const void *x, const void *norm_weight, float eps
     return run_rowwave(q, (hipStream_t)stream);
 }
 
+int gptq_dequant_f16(const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *g_idx, void *w, int K, int N,
+                     int bits, int groupsize, gptq_stream_t stream) {
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0) return GPTQ_E_SHAPE;
+    if (!qweight || !scales || !qzeros || !w) return GPTQ_E_NULL;
+    return dequant_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits,
+                          (half_t *)w, (hipStream_t)stream);
+}
+
 int gptq_act_order_repack(const int32_t *qweight, const int32_t *perm, int K, int N, int bits, int32_t *qweight_sorted,
                           gptq_stream_t stream) {
     if (!qweight || !perm || !qweight_sorted) return GPTQ_E_NULL;

@@ -270,6 +270,50 @@ int pack_launch(const float *weight, const float *scales, const float *zeros, co
     return GPTQ_E_BITS;
 }
 
+// ------------------------------------------------------------------------------ dequantise
+// W[k][n] = fp16(q - z) * fp16 scale (one fp16 rounding), the weight the reference's kernel builds
+// on the fly (quant_linear.py:114-128), materialised as a dense fp16 [K, N] matrix.  Any bits in
+// {2,3,4,8}, any g_idx.  A workgroup converts a 32-k block x 256 columns; writes are row-contiguous.
+template <int BITS>
+__global__ void __launch_bounds__(256) dequant_kernel(const uint32_t *__restrict__ qw, const half_t *__restrict__ sc,
+                                                      const int32_t *__restrict__ qz, const int32_t *__restrict__ gi, int K, int N,
+                                                      int G, int groupsize, half_t *__restrict__ out) {
+    const int blk = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int ldz = N / 32 * BITS;
+    uint32_t col[BITS];
+#pragma unroll
+    for (int i = 0; i < BITS; i++) col[i] = qw[((size_t)blk * BITS + i) * N + n];
+    int g_prev = -1;
+    half_t s = (half_t)0, z = (half_t)0;
+#pragma unroll 8
+    for (int j = 0; j < 32; j++) {
+        const int k = blk * 32 + j;
+        int g = gi ? gi[k] : k / groupsize;
+        g = (g < 0 || g >= G) ? 0 : g;
+        if (g != g_prev) {
+            g_prev = g;
+            s = sc[(size_t)g * N + n];
+            z = (half_t)(float)zero_of<BITS>(qz + (size_t)g * ldz, n);
+        }
+        const int q = field_of_block<BITS>(col, j);
+        out[(size_t)k * N + n] = (half_t)((half_t)(float)q - z) * s;
+    }
+}
+
+int dequant_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, const int32_t *gi, int K, int N, int G, int groupsize,
+                   int bits, half_t *out, hipStream_t s) {
+    dim3 grid((N + 255) / 256, K / 32), block(256);
+    switch (bits) {
+        case 2: hipLaunchKernelGGL(dequant_kernel<2>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out); break;
+        case 3: hipLaunchKernelGGL(dequant_kernel<3>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out); break;
+        case 4: hipLaunchKernelGGL(dequant_kernel<4>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out); break;
+        case 8: hipLaunchKernelGGL(dequant_kernel<8>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out); break;
+        default: return GPTQ_E_BITS;
+    }
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------- act-order row sort
 // qweight_out row r', field j  <-  the field of k = perm[r' * f + j] in qweight (f = 32 / bits).
 // With perm = stable argsort(g_idx) every packed row of the output holds f consecutive members of

@@ -52,6 +52,8 @@ int rope_launch(half_t *qk, int64_t row_stride, const int64_t *pos, int64_t pos_
 int pack_launch(const float *weight, const float *scales, const float *zeros, const int32_t *g_idx, int K,
                 int N, int G, int bits, int groupsize, int32_t *qweight, int32_t *qzeros, half_t *scales16,
                 hipStream_t s);
+int dequant_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, const int32_t *gi, int K, int N, int G, int groupsize,
+                   int bits, half_t *out, hipStream_t s);
 int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 

@@ -148,7 +148,34 @@ def _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, 
     _native.check(rc, _FAMILIES[family])
 
 
-_FAMILIES = {None: 'gptq_matmul248_f16', 'gemv': 'gptq_gemv_f16', 'skinny': 'gptq_skinny_f16'}
+# M regimes of the built-in dispatch (DESIGN.md "dispatch"): the C ABI serves every M, but between the
+# weight-streaming kernels (M <= STREAM_MAX_M) and a prefill big enough to fill the GPU with 256 x 256
+# MFMA tiles the product is a small dense GEMM; there the weight is dequantised once (our kernel,
+# reference numerics) and multiplied with the library GEMM.  family= bypasses this.
+STREAM_MAX_M = 16
+GEMM_MIN_TILES = 192
+
+
+def _mid_m(M, N):
+    return M > STREAM_MAX_M and (-(-M // 256)) * (-(-N // 256)) < GEMM_MIN_TILES
+
+
+def dequantize(qweight, scales, qzeros, g_idx, bits, groupsize=None):
+    """dense fp16 [K, N] weight, bit-identical to what the kernels multiply with."""
+    K, N = qweight.shape[0] * 32 // bits, qweight.shape[1]
+    groupsize = _infer_groupsize(K, scales.shape[0]) if groupsize is None else groupsize
+    gi = None
+    if g_idx is not None and not g_idx_is_trivial(g_idx, K, groupsize):
+        gi = _int32c(g_idx[:K])
+    with torch.cuda.device(qweight.device):
+        W = torch.empty((K, N), dtype=torch.float16, device=qweight.device)
+        rc = _native.lib().gptq_dequant_f16(_int32c(qweight).data_ptr(), scales.data_ptr(), _int32c(qzeros).data_ptr(), _native.ptr(gi),
+                                            W.data_ptr(), K, N, bits, groupsize, _native.stream_ptr(qweight.device))
+    _native.check(rc, 'gptq_dequant_f16')
+    return W
+
+
+_FAMILIES = {None: 'gptq_matmul248_f16', 'abi': 'gptq_matmul248_f16', 'gemv': 'gptq_gemv_f16', 'skinny': 'gptq_skinny_f16'}
 
 
 def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, family=None):
@@ -164,6 +191,12 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
     with torch.cuda.device(x.device):
         out = torch.empty((M, N), device=x.device, dtype=torch.float16)
         if M == 0:
+            return out
+        if family is None and _mid_m(M, N):
+            W = dequantize(qweight, scales, qzeros, gi, bits, groupsize)
+            torch.matmul(x, W, out=out)
+            if bias is not None:
+                out += bias
             return out
         ws = _native.workspace(x.device)
         if gi is not None:

@@ -166,6 +166,15 @@ int gptq_g_idx_is_trivial(const int32_t *g_idx, int K, int groupsize, int32_t *o
  *   out       fp16 [heads*head_dim] = softmax(q.K^T * scale) V, fp32 math
  */
 /*
+ * W[K, N] fp16 = the dequantised weight exactly as the reference's kernel forms it on the fly:
+ * fp16(q - z) * fp16 scale, one rounding (quant/quant_linear.py:114-128).  Any bits / g_idx.
+ * Used by the Python layer for the mid-size M regime (a prompt of tens to a few thousand tokens),
+ * where the product is a plain dense GEMM too small to fill the GPU with 256 x 256 tiles.
+ */
+int gptq_dequant_f16(const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *g_idx,
+                     void *w, int K, int N, int bits, int groupsize, gptq_stream_t stream);
+
+/*
  * Act-order fast path (extension; the reference re-gathers g_idx, scales and zeros for every k row
  * in the kernel, quant/quant_linear.py:114-118).  With perm = stable argsort(g_idx), the re-sorted
  * qweight (gptq_act_order_repack, one-off at load; same shape as qweight) is a trivial-g_idx layer

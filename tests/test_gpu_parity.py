@@ -161,7 +161,31 @@ def test_gemv_split_k(split_k, variant):
 def test_skinny_mfma(bits, gs, M):
     L = make_random_layer(bits, gs, 1024, 256, seed=bits + M)
     x = np.random.default_rng(M).standard_normal((M, 1024)).astype(np.float16)
-    check_forward(x, L)
+    check_forward(x, L, family='skinny')
+    check_forward(x, L)      # built-in dispatch (M > 16: dequantise + dense GEMM, see test_mid_m_route)
+
+
+@pytest.mark.parametrize('bits,gs,act', [(4, 128, False), (4, 128, True), (3, -1, False), (8, 32, False), (2, 64, True)])
+def test_dequantize_is_bit_exact_with_the_reference_weight(bits, gs, act):
+    """gptq_dequant_f16 == the weight the reference kernel forms on the fly (oracle.dequant, faithful)."""
+    K, N = 512, 288 if bits != 3 else 320
+    L = make_random_layer(bits, gs, K, N, act_order=act, seed=bits + K)
+    W = QL.dequantize(dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), bits).cpu().numpy()
+    ref = oracle.dequant(L['qweight'], L['qzeros'], L['scales'], L['g_idx'], bits, faithful=True).astype(np.float16)
+    assert np.array_equal(W.view(np.uint16), ref.view(np.uint16))
+
+
+@pytest.mark.parametrize('M', [17, 100, 700])
+def test_mid_m_route(M):
+    """17 <= M < "GPU full of 256 x 256 tiles": dequantise once + dense GEMM; same answer as the ABI's
+    own kernels for that M."""
+    L = make_random_layer(4, 128, 1024, 512, seed=M)
+    x = np.random.default_rng(M).standard_normal((M, 1024)).astype(np.float16)
+    bias = np.random.default_rng(1).standard_normal(512).astype(np.float16)
+    assert QL._mid_m(M, 512)
+    y, _ = check_forward(x, L, bias=bias)
+    y_abi, _ = check_forward(x, L, bias=bias, family='abi')
+    assert rel_err(y, y_abi) < TOL
 
 
 @pytest.mark.parametrize('split_k', [2, 4])
@@ -171,8 +195,8 @@ def test_skinny_split_k(split_k):
     lib = _native.lib()
     lib.gptq_set_split_k(split_k)
     try:
-        check_forward(x, L)
-        check_forward(x, L)
+        check_forward(x, L, family='skinny')
+        check_forward(x, L, family='skinny')
     finally:
         lib.gptq_set_split_k(-1)
 
@@ -181,7 +205,7 @@ def test_skinny_split_k(split_k):
 def test_large_m(M):
     L = make_random_layer(4, 128, 512, 256, seed=M)
     x = np.random.default_rng(M).standard_normal((M, 512)).astype(np.float16)
-    check_forward(x, L)
+    check_forward(x, L, family='abi')
 
 
 @pytest.mark.parametrize('bits,gs', [(4, 128), (4, 32), (4, -1), (8, 128), (8, 64)])
@@ -196,7 +220,7 @@ def test_prefill_mfma_gemm(bits, gs, M, K, N):
     rng = np.random.default_rng(M)
     x = rng.standard_normal((M, K)).astype(np.float16)
     bias = rng.standard_normal(N).astype(np.float16)
-    check_forward(x, L, bias=bias)
+    check_forward(x, L, bias=bias, family='abi')
 
 
 def test_prefill_gemm_rows_independent():
@@ -205,7 +229,7 @@ def test_prefill_gemm_rows_independent():
     K, N, M = 4096, 4096, 2048
     L = make_random_layer(4, 128, K, N, seed=99)
     x = np.random.default_rng(7).standard_normal((M, K)).astype(np.float16)
-    y = hip_forward(x, L)
+    y = hip_forward(x, L, family='abi')
     for m in (0, 255, 256, 1000, 2047):
         ym = hip_forward(x[m:m + 1], L)
         assert rel_err(y[m:m + 1], ym) < TOL
@@ -237,10 +261,11 @@ def test_act_order_sorted_fast_path(bits, gs, M):
     ref = oracle.matmul248(x[:, perm], srt[0].cpu().numpy(), L['scales'], L['qzeros'], (np.arange(K) // gs).astype(np.int32), bits)
     full = oracle_forward(x, L)
     assert rel_err(ref, full) < TOL
-    y, _ = check_forward(x, L)
+    fam = 'abi' if M > QL.STREAM_MAX_M else None      # keep the C-ABI kernels under test for every M
+    y, _ = check_forward(x, L, family=fam)
     QL.ACT_ORDER_SORT = False
     try:
-        y_generic = hip_forward(x, L)
+        y_generic = hip_forward(x, L, family=fam)
     finally:
         QL.ACT_ORDER_SORT = True
     assert rel_err(y, y_generic) < TOL

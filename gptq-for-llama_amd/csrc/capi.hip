@@ -252,7 +252,9 @@ static int run_skinny(const Problem &q, hipStream_t s) {
             split_k = fs;
             if (split_k > 1 && !ws_ok) return GPTQ_E_WORKSPACE;
         } else if (ws_ok) {
-            split_k = (768 + p.ntiles - 1) / p.ntiles;
+            // the combine costs M*N*S returning atomics (~50 G/s measured): split K less as M grows
+            const int target = mc <= 4 ? 768 : (mc <= 8 ? 256 : 0);
+            split_k = target ? (target + p.ntiles - 1) / p.ntiles : 1;
         }
         if (split_k > split_max) split_k = split_max;
         if (split_k * w > nstages) split_k = nstages / w;

@@ -76,9 +76,9 @@ def main():
 
             fn = mlp if fused else mm
             nbytes = alg_bytes(M, K, N, nsets=2 if fused else 1)
-            variants = range(3) if args.kernel == 'gemv' else [2, 4, 8]
+            variants = range(3) if args.kernel == 'gemv' else [4]
             for v in variants:
-                for sk in ((4, 8, 16) if fused else (8, 16, 22, 32, 43, 64)):
+                for sk in ((4, 8, 16) if fused else ((1, 2, 3, 4, 6, 8, 12) if args.kernel == 'skinny' else (8, 16, 22, 32, 43, 64))):
                     lib.gptq_set_gemv_variant(v)
                     lib.gptq_set_split_k(sk)
                     try:

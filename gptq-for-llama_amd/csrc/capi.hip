@@ -332,6 +332,9 @@ const char *gptq_strerror(int code) {
 int gptq_set_gemv_variant(int variant) { return g_force_variant.exchange(variant); }
 int gptq_set_split_k(int split_k) { return g_force_split_k.exchange(split_k); }
 void *gptq_set_debug_buffer(void *buf) { return g_debug_buffer.exchange(buf); }
+int gptq_set_gemm_kernel(int version) {
+    return (version == 2 || version == 3 || (version >= 100 && version <= 104)) ? gemm_set_version(version) : GPTQ_E_VARIANT;
+}
 
 static Problem make_problem(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
                             const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,

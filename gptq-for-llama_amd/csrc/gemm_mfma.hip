@@ -21,10 +21,15 @@
 //    256 contiguous bytes per row;
 //  * workgroups are numbered so that all N tiles of an M tile run on the same XCD (block b lands
 //    on XCD b % 8): the A slab is fetched from HBM once and shared through that XCD's L2.
+#include <atomic>
+
 #include "gptq_device.h"
 #include "gptq_internal.h"
 
 namespace gptq {
+
+std::atomic<int> g_gemm_version{3};
+std::atomic<int> g_gemm_diag{0};      // timing experiments: see gemm_mfma_v3_kernel<DIAG>   // 2 = force the ping-pong kernel (tests / A-B measurements)
 
 struct GemmParams {
     const half_t *a;
@@ -76,6 +81,46 @@ GPTQ_DEV half8_t dequant8<8>(const uint32_t *w, half2_t zc, half2_t s2, uint32_t
         b[i] = (b[i] - zc) * s2;
     }
     return half8_t{a[0][0], a[1][0], a[0][1], a[1][1], b[0][0], b[1][0], b[0][1], b[1][1]};
+}
+
+// fp32 accumulators -> fp16, transposed through LDS (wave-private region), 16-B row stores (+bias)
+constexpr int TN_ = WTN / 32;
+GPTQ_DEV void gemm_epilogue(const float16_t (&acc)[TN_][4], char *smem, int wave, int lane, int wm, int wn, int m0, int n0, int M, int N,
+                            const GemmParams &p) {
+    constexpr int TN = TN_;
+    char *cs = smem + wave * (128 * CROW);
+    const int ml = lane & 31, nq = (lane >> 5) * 4;
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int nl = i * 32 + 8 * r + nq;  // D row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+                const half4_t h = {(half_t)acc[i][jj][4 * r + 0], (half_t)acc[i][jj][4 * r + 1], (half_t)acc[i][jj][4 * r + 2],
+                                   (half_t)acc[i][jj][4 * r + 3]};
+                *(half4_t *)(cs + (jj * 32 + ml) * CROW + nl * 2) = h;
+            }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the region is private to this wave
+    __builtin_amdgcn_wave_barrier();
+    constexpr int LPR = WTN / 8;           // lanes per output row (16-B pieces)
+    constexpr int RPI = 64 / LPR;          // rows per store instruction
+    const int c16 = lane % LPR, rsub = lane / LPR;
+    const int ncol = n0 + wn * WTN + c16 * 8;
+#pragma unroll 4
+    for (int r = 0; r < 128 / RPI; r++) {
+        const int mloc = r * RPI + rsub;
+        const int m = m0 + wm * 128 + mloc;
+        half8_t v = *(const half8_t *)(cs + mloc * CROW + c16 * 16);
+        if (m < M && ncol < N) {
+            if (p.bias) {
+                const half8_t b = *(const half8_t *)(p.bias + ncol);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = (half_t)((float)v[e] + (float)b[e]);
+            }
+            *(half8_t *)(p.c + (size_t)m * p.ldc + ncol) = v;
+        }
+    }
 }
 
 template <int BITS>
@@ -296,40 +341,168 @@ __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
     }
     __syncthreads();
 
-    // ---- epilogue: fp32 -> fp16, transpose through LDS (wave-private region), 16-B row stores ----
-    char *cs = smem + wave * (128 * CROW);
-    const int ml = lane & 31, nq = (lane >> 5) * 4;
+    gemm_epilogue(acc, smem, wave, lane, wm, wn, m0, n0, M, N, p);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// v3 (4-bit, groupsize % 64 == 0): BOTH operands reach LDS by LDS-DMA and B stays PACKED there.
+//  * per K slab a wave issues 4 A instructions (1 KiB each, swizzled rows as above) and ONE B
+//    instruction: packed row `wave` of the slab, 256 columns x 4 B = 1 KiB -- 40 KiB per slab instead of
+//    64, no VGPR staging, no VALU and no ds_write in the data-movement path at all;
+//  * a B fragment (8 consecutive k of one column) is ONE packed word: the wave reads it with
+//    ds_read_b32 and dequantises it in registers right before the MFMA (19 VALU per fragment, the
+//    reference's fp16 sequence), i.e. in the issue slots the matrix pipe leaves free;
+//  * three LDS stages, prefetch distance two, ONE barrier per slab; no phase split: both waves of a
+//    SIMD stream MFMAs and the LDS pipe sees 144 KiB of reads + 40 KiB of DMA writes per slab
+//    (the v2 ping-pong moved 192 + 64 KiB and was LDS / VMEM-issue bound, tools/gemm_phases.py).
+// ---------------------------------------------------------------------------------------
+constexpr int V3_STAGES = 3;
+constexpr int V3_BBYTES = KB * 1024;                       // packed B of a slab: 8 rows x 256 columns x 4 B
+constexpr int V3_STAGE_BYTES = ATILE_BYTES + V3_BBYTES;    // 40 960
+
+// DIAG (timing experiments only, wrong results): 1 = no MFMA, 2 = no LDS reads / dequant (constant
+// fragments), 3 = LDS reads but no dequant, 4 = no DMA in the loop
+template <int DIAG>
+__global__ void __launch_bounds__(512) gemm_mfma_v3_kernel(const GemmParams p) {
+    using UP = Unpack<4>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3;
+    const int tm = (j0 / p.ntn) * 8 + xcd, tn = j0 % p.ntn;
+    if (tm >= p.ntm) return;
+    const int m0 = tm * GM, n0 = tn * GN;
+    const int M = p.M, N = p.N, K = p.K;
+    constexpr int NA = GM * KB / 512;
+
+    const half_t *aptr[NA];
 #pragma unroll
-    for (int i = 0; i < TN; i++)
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int nl = i * 32 + 8 * r + nq;  // D row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-                const half4_t h = {(half_t)acc[i][jj][4 * r + 0], (half_t)acc[i][jj][4 * r + 1], (half_t)acc[i][jj][4 * r + 2],
-                                   (half_t)acc[i][jj][4 * r + 3]};
-                *(half4_t *)(cs + (jj * 32 + ml) * CROW + nl * 2) = h;
-            }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the region is private to this wave
-    __builtin_amdgcn_wave_barrier();
-    constexpr int LPR = WTN / 8;           // lanes per output row (16-B pieces)
-    constexpr int RPI = 64 / LPR;          // rows per store instruction
-    const int c16 = lane % LPR, rsub = lane / LPR;
-    const int ncol = n0 + wn * WTN + c16 * 8;
-#pragma unroll 4
-    for (int r = 0; r < 128 / RPI; r++) {
-        const int mloc = r * RPI + rsub;
-        const int m = m0 + wm * 128 + mloc;
-        half8_t v = *(const half8_t *)(cs + mloc * CROW + c16 * 16);
-        if (m < M && ncol < N) {
-            if (p.bias) {
-                const half8_t b = *(const half8_t *)(p.bias + ncol);
-#pragma unroll
-                for (int e = 0; e < 8; e++) v[e] = (half_t)((float)v[e] + (float)b[e]);
-            }
-            *(half8_t *)(p.c + (size_t)m * p.ldc + ncol) = v;
-        }
+    for (int i = 0; i < NA; i++) {
+        const int row = 8 * (NA * wave + i) + (lane >> 3);
+        const int kb = (lane & 7) ^ ((row >> 1) & 7);
+        aptr[i] = p.a + (size_t)min(m0 + row, M - 1) * p.lda + kb * 8;
     }
+    // B: this wave moves packed row `wave` of every slab; lane l -> columns n0 + 4l .. 4l + 3 (clamped)
+    const uint32_t *bsrc = p.qw + (size_t)wave * N + min(n0 + 4 * lane, N - 4);
+    auto dma = [&](int stage, int k0) {
+        char *base = smem + stage * V3_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(aptr[i] + k0),
+                                             (__attribute__((address_space(3))) void *)(base + (NA * wave + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + (size_t)(k0 / 8) * N),
+                                         (__attribute__((address_space(3))) void *)(base + ATILE_BYTES + wave * 1024), 16, 0, 0);
+    };
+
+    // per-lane scale / zero of the two fragment columns, reloaded when the slab enters a new group
+    const int frow = lane & 31, fkb = lane >> 5;
+    int colv[TN_];
+#pragma unroll
+    for (int t = 0; t < TN_; t++) colv[t] = min(n0 + wn * WTN + t * 32 + frow, N - 1);
+    const int ldz = N / 8;
+    const uint32_t MSK = sreg_const(UP::MSK_C), MAG = vreg_const(UP::MAG_C);
+    half2_t s2[TN_], zc[TN_];
+    int g_cur = -1;
+    auto load_sz = [&](int k0) {
+        const int g = p.gshift >= 0 ? (k0 >> p.gshift) : (k0 / p.groupsize);
+        if (g != g_cur) {          // uniform
+            g_cur = g;
+#pragma unroll
+            for (int t = 0; t < TN_; t++) {
+                const half_t sv = p.sc[(size_t)g * N + colv[t]];
+                const uint32_t zw = (uint32_t)p.qz[(size_t)g * ldz + colv[t] / 8];
+                const float z = (float)(((zw >> (4 * (colv[t] & 7))) & 15u) + 1u) + UP::OFF;
+                s2[t] = half2_t{sv, sv};
+                zc[t] = half2_t{(half_t)z, (half_t)z};
+            }
+        }
+    };
+
+    float16_t acc[TN_][4];
+#pragma unroll
+    for (int i = 0; i < TN_; i++)
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) acc[i][jj] = (float16_t)0.f;
+
+    const int nslab = K / GK;
+    const int swz = (frow >> 1) & 7;
+    dma(0, 0);
+    dma(1, min(1, nslab - 1) * GK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int j = 0; j < nslab; j++) {
+        load_sz(j * GK);
+        if (DIAG != 4) dma((j + 2) % V3_STAGES, min(j + 2, nslab - 1) * GK);   // stage (j+2)%3 was last read in iteration j-1
+        const char *st = smem + (j % V3_STAGES) * V3_STAGE_BYTES;
+        const char *ab = st + (wm * 128 + frow) * AROW;
+        const char *bw = st + ATILE_BYTES + (wn * WTN + frow) * 4;
+        // Software pipeline over the four K16 steps of the slab: the LDS reads and the dequantisation of
+        // step ks+1 are issued between the MFMAs of step ks (an in-order wave can only hide ~5 VALU in
+        // the 32-cycle issue gap of each MFMA, so they must sit BETWEEN the MFMAs in program order).
+        half8_t af[2][4], bf[2][TN_];
+        uint32_t wq[TN_];
+        auto read_step = [&](int ks, half8_t (&a4)[4]) {
+            const int kb = ks * 2 + fkb;
+            const int aslot = (kb ^ swz) * 16;
+            if constexpr (DIAG == 2) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) a4[t] = (half8_t)(half_t)(float)(ks + t);
+#pragma unroll
+                for (int t = 0; t < TN_; t++) wq[t] = (uint32_t)(j + t);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++) a4[t] = *(const half8_t *)(ab + t * 32 * AROW + aslot);
+#pragma unroll
+                for (int t = 0; t < TN_; t++) wq[t] = *(const uint32_t *)(bw + kb * 1024 + t * 128);
+            }
+        };
+        auto dequant_step = [&](half8_t (&b2)[TN_]) {
+#pragma unroll
+            for (int t = 0; t < TN_; t++) {
+                if constexpr (DIAG == 2 || DIAG == 3) b2[t] = (half8_t)(half_t)(float)(wq[t] & 3u);
+                else b2[t] = dequant8<4>(&wq[t], zc[t], s2[t], MSK, MAG);
+            }
+        };
+        read_step(0, af[0]);
+        dequant_step(bf[0]);
+#pragma unroll
+        for (int ks = 0; ks < GK / 16; ks++) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < GK / 16) read_step(ks + 1, af[nxt]);
+            if constexpr (DIAG == 1) {
+#pragma unroll
+                for (int i = 0; i < TN_; i++)
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++)
+                        acc[i][jj][0] += (float)bf[cur][i][0] * (float)af[cur][jj][0] + (float)bf[cur][i][7] * (float)af[cur][jj][7];
+            } else {
+#pragma unroll
+                for (int i = 0; i < TN_; i++)
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cur][i], af[cur][jj], acc[i][jj], 0, 0, 0);
+            }
+            if (ks + 1 < GK / 16) dequant_step(bf[nxt]);
+            if (ks + 1 < GK / 16) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4 + TN_, 0);   // the next step's LDS reads go out first
+#pragma unroll
+                for (int q = 0; q < 4 * TN_; q++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);     // five VALU of the next step's dequant
+                }
+            }
+        }
+        // slab j+1 (requested one iteration ago) must have landed; slab j+2's 5 instructions may stay in flight
+        if (DIAG != 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gemm_epilogue(acc, smem, wave, lane, wm, wn, m0, n0, M, N, p);
 }
 
 template <int BITS>
@@ -347,6 +520,11 @@ static int launch_gemm(const GemmParams &p, hipStream_t s) {
     dim3 grid(groups_of_8 * 8 * p.ntn), block(512);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     return (int)hipGetLastError();
+}
+
+int gemm_set_version(int v) {
+    if (v >= 100) return g_gemm_diag.exchange(v - 100);   // 100 + DIAG: development timing variants of v3
+    return g_gemm_version.exchange(v);
 }
 
 // Eligibility: bits in {4, 8}, trivial g_idx (checked by the caller), K % 64 == 0, groupsize % 32 == 0,
@@ -377,6 +555,28 @@ int gemm_dispatch(int bits, bool fused2, const GemvParams &q, hipStream_t s) {
     p.dbg = q.dbg;
     p.ntm = (q.M + GM - 1) / GM;
     p.ntn = (q.N + GN - 1) / GN;
+    if (bits == 4 && q.groupsize % GK == 0 && q.N >= 4 && g_gemm_version.load() == 3) {
+        const size_t lds = 4 * (size_t)TILE_BYTES;
+        static bool configured = false;
+        if (!configured) {
+            for (const void *f : {(const void *)gemm_mfma_v3_kernel<0>, (const void *)gemm_mfma_v3_kernel<1>, (const void *)gemm_mfma_v3_kernel<2>,
+                                  (const void *)gemm_mfma_v3_kernel<3>, (const void *)gemm_mfma_v3_kernel<4>}) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return (int)e;
+            }
+            configured = true;
+        }
+        const int groups_of_8 = (p.ntm + 7) / 8;
+        dim3 grid(groups_of_8 * 8 * p.ntn), block(512);
+        switch (g_gemm_diag.load()) {
+            case 1: hipLaunchKernelGGL(gemm_mfma_v3_kernel<1>, grid, block, lds, s, p); break;
+            case 2: hipLaunchKernelGGL(gemm_mfma_v3_kernel<2>, grid, block, lds, s, p); break;
+            case 3: hipLaunchKernelGGL(gemm_mfma_v3_kernel<3>, grid, block, lds, s, p); break;
+            case 4: hipLaunchKernelGGL(gemm_mfma_v3_kernel<4>, grid, block, lds, s, p); break;
+            default: hipLaunchKernelGGL(gemm_mfma_v3_kernel<0>, grid, block, lds, s, p); break;
+        }
+        return (int)hipGetLastError();
+    }
     return bits == 4 ? launch_gemm<4>(p, s) : launch_gemm<8>(p, s);
 }
 

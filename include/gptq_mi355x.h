@@ -70,6 +70,9 @@ const char *gptq_strerror(int code);
  * previous value. */
 int gptq_set_gemv_variant(int variant);
 int gptq_set_split_k(int split_k);
+/* Prefill GEMM kernel selection (tests / A-B measurements): 2 = ping-pong kernel (default), 3 = all-LDS-DMA
+ * kernel with packed B in LDS (4-bit, groupsize % 64 == 0; measured 2-4 % slower).  Returns the previous value. */
+int gptq_set_gemm_kernel(int version);
 /* Development aid: when non-NULL, the decode kernels write per-wave s_memtime checkpoints
  * ([block][wave][8] uint64) into this device buffer.  Returns the previous pointer. */
 void *gptq_set_debug_buffer(void *device_buffer);

@@ -208,9 +208,10 @@ def test_large_m(M):
     check_forward(x, L, family='abi')
 
 
-@pytest.mark.parametrize('bits,gs', [(4, 128), (4, 32), (4, -1), (8, 128), (8, 64)])
+@pytest.mark.parametrize('kernel', [3, 2])
+@pytest.mark.parametrize('bits,gs', [(4, 128), (4, 32), (4, -1), (4, 64), (8, 128), (8, 64)])
 @pytest.mark.parametrize('M,K,N', [(300, 256, 288), (513, 1024, 512), (1024, 4096, 256), (65, 192, 32)])
-def test_prefill_mfma_gemm(bits, gs, M, K, N):
+def test_prefill_mfma_gemm(bits, gs, M, K, N, kernel):
     """the 256x256x64 MFMA tile kernel (M > 64): ragged M / N, several K slabs and group changes,
     bias; it dequantises with the reference's fp16 sequence so it sits very close to the
     faithful oracle."""
@@ -220,7 +221,12 @@ def test_prefill_mfma_gemm(bits, gs, M, K, N):
     rng = np.random.default_rng(M)
     x = rng.standard_normal((M, K)).astype(np.float16)
     bias = rng.standard_normal(N).astype(np.float16)
-    check_forward(x, L, bias=bias, family='abi')
+    lib = _native.lib()
+    prev = lib.gptq_set_gemm_kernel(kernel)
+    try:
+        check_forward(x, L, bias=bias, family='abi')
+    finally:
+        lib.gptq_set_gemm_kernel(prev)
 
 
 def test_prefill_gemm_rows_independent():

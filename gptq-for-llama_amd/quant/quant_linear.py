@@ -149,10 +149,10 @@ def _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, 
 
 
 # M regimes of the built-in dispatch (DESIGN.md "dispatch"): the C ABI serves every M, but between the
-# weight-streaming kernels (M <= STREAM_MAX_M) and a prefill big enough to fill the GPU with 256 x 256
+# weight-streaming kernels (M <= STREAM_MAX_M = 64) and a prefill big enough to fill the GPU with 256 x 256
 # MFMA tiles the product is a small dense GEMM; there the weight is dequantised once (our kernel,
 # reference numerics) and multiplied with the library GEMM.  family= bypasses this.
-STREAM_MAX_M = 16
+STREAM_MAX_M = 64
 GEMM_MIN_TILES = 192
 
 

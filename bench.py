@@ -265,11 +265,12 @@ def main():
                          'kernel': 'gptq::gemv_rowwave_kernel<4,8,*> (all 128 launches/step: 96 single-set + 32 fused gate/up)',
                          'avg_launch_us': round(us_per_launch, 3), 'algorithmic_bytes_per_launch': int(bytes_per_launch)},
         }
-        if not args.no_per_shape:
+        # the side legs run at N = 1 only (the other ranks would sit in the final barrier meanwhile)
+        if not args.no_per_shape and world == 1:
             out['per_shape'] = work.per_shape()
-        if not args.no_decode:
+        if not args.no_decode and world == 1:
             out['decode'] = decode_tokens_per_s(dev)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     if distributed:

@@ -189,12 +189,12 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
         kpre[it] = (tl < nact && tl != tnew) ? *(const half8_t *)(kc + (size_t)(t0 + tl) * hd + (size_t)h * ATT_HD + d8 * 8)
                                               : (half8_t)(half_t)0;
     }
-    half2_t vpre[ATT_TS / 4];
+    half8_t vpre[ATT_TS / 16];   // same (timestep, 8-dim slice) map as K: 16-byte loads, 4 rows per wave instruction
 #pragma unroll
-    for (int it = 0; it < ATT_TS / 4; it++) {
-        const int tl = it * 4 + wave;
-        vpre[it] = (tl < nact && tl != tnew) ? *(const half2_t *)(vc + (size_t)(t0 + tl) * hd + (size_t)h * ATT_HD + 2 * lane)
-                                              : half2_t{(half_t)0, (half_t)0};
+    for (int it = 0; it < ATT_TS / 16; it++) {
+        const int tl = it * 16 + tsub;
+        vpre[it] = (tl < nact && tl != tnew) ? *(const half8_t *)(vc + (size_t)(t0 + tl) * hd + (size_t)h * ATT_HD + d8 * 8)
+                                              : (half8_t)(half_t)0;
     }
 
     if (tid < ATT_HD / 2) {
@@ -260,20 +260,30 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     __syncthreads();
     l = red[4] + red[5] + red[6] + red[7];
 
-    float a0 = 0.f, a1 = 0.f;
+    float av[8];
 #pragma unroll
-    for (int it = 0; it < ATT_TS / 4; it++) {
-        const int tl = it * 4 + wave;
+    for (int j = 0; j < 8; j++) av[j] = 0.f;
+#pragma unroll
+    for (int it = 0; it < ATT_TS / 16; it++) {
+        const int tl = it * 16 + tsub;
         if (tl < nact) {
-            half2_t v2 = vpre[it];
-            if (tl == tnew) v2 = *(const half2_t *)(vnew + 2 * lane);
+            half8_t v8 = vpre[it];
+            if (tl == tnew) v8 = *(const half8_t *)(vnew + d8 * 8);
             const float pt = sc[tl];
-            a0 += pt * (float)v2[0];
-            a1 += pt * (float)v2[1];
+#pragma unroll
+            for (int j = 0; j < 8; j++) av[j] += pt * (float)v8[j];
         }
     }
-    accs[wave][2 * lane] = a0;
-    accs[wave][2 * lane + 1] = a1;
+    // the 4 timestep groups of a wave (lane >> 4), then the 4 waves through LDS
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        av[j] += __shfl_xor(av[j], 16, 64);
+        av[j] += __shfl_xor(av[j], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) accs[wave][lane * 8 + j] = av[j];
+    }
     __syncthreads();
     float acc = 0.f;
     if (tid < ATT_HD) acc = accs[0][tid] + accs[1][tid] + accs[2][tid] + accs[3][tid];

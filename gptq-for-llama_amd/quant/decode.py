@@ -287,7 +287,7 @@ class DecodeEngine:
         return self.logits
 
 
-def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fuse_norm=True, fuse_attn=True):
+def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fuse_norm=True, fuse_attn=True, start_pos=0):
     """the llama.py:385-438 protocol on the DecodeEngine (hipGraph replay per token)."""
     dev = next(model.parameters()).device
     eng = DecodeEngine(model, t_max=t_max, fuse_norm=fuse_norm, fuse_attn=fuse_attn)
@@ -298,6 +298,10 @@ def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fu
     input_ids = torch.randint(0, model.config.vocab_size, (1, tokens), device=dev, generator=gen)
     times = []
     eng.reset()
+    if start_pos:      # decode at depth: pretend start_pos tokens are already cached (random K/V rows)
+        eng.kc.normal_(0, 0.5)
+        eng.vc.normal_(0, 0.5)
+        eng.pos.fill_(int(start_pos))
     for i in range(tokens):
         torch.cuda.synchronize(dev)
         tick = time.perf_counter()
@@ -307,6 +311,6 @@ def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fu
     med = float(np.median(times[2:])) if len(times) > 4 else float(np.median(times))
     return {'protocol': 'llama.py:385-438 (one token per step, KV cache, sync per step, median)',
             'mode': 'DecodeEngine, %s' % ('one hipGraph replay per token' if graph else 'eager launches'), 'tokens': tokens,
-            't_max': t_max, 'fused_norm': fuse_norm, 'fused_attention': fuse_attn,
+            't_max': t_max, 'start_pos': start_pos, 'fused_norm': fuse_norm, 'fused_attention': fuse_attn,
             'launches_per_token': (10 - 2 * int(fuse_norm) - 2 * int(fuse_attn)) * len(eng.layers) + 4, 'median_s_per_token': round(med, 6),
             'tokens_per_s': round(1.0 / med, 1)}

@@ -7,4 +7,5 @@ import torch
 from quant.decode import build_random_llama, benchmark_decode_engine
 fuse = '--nofuse' not in sys.argv
 m = build_random_llama('cuda:0')
-print(benchmark_decode_engine(m, tokens=40, graph=True, fuse_norm=fuse, fuse_attn=fuse))
+sp = int(sys.argv[sys.argv.index('--start') + 1]) if '--start' in sys.argv else 0
+print(benchmark_decode_engine(m, tokens=40, graph=True, fuse_norm=fuse, fuse_attn=fuse, start_pos=sp))

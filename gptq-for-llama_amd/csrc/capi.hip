@@ -229,7 +229,7 @@ static int run_skinny(const Problem &q, hipStream_t s) {
     const int upg = q.groupsize / unit_k;
     const int nunits = q.K / unit_k;
     const int mmax = q.fused2 ? 32 : SKINNY_MAX_M;
-    const int split_max = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
+    const int split_max = 32;
     int waves = 4;
     const int fv = g_force_variant.load();
     if (fv == 2 || fv == 4 || fv == 8) waves = fv;
@@ -244,17 +244,19 @@ static int run_skinny(const Problem &q, hipStream_t s) {
         int stg = (upg % 4 == 0) ? 4 : ((upg % 2 == 0 && xlds) ? 2 : 1);
         const int nstages = nunits / stg;
         const int w = (xlds && stg == 4) ? waves : 4;
-        const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)mc * q.N * 8;
-        // K split: ~3 workgroups per CU, every wave of a workgroup gets at least one stage
+        // K slices publish partial tiles [tile][slice][sets][rows][64] fp32 behind the ticket words
+        const size_t part_per_slice = (size_t)p.ntiles * (q.fused2 ? 2 : 1) * (mc < 64 ? mc : 64) * 64 * 4;
+        const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes > SPLITK_PART_OFFSET + 2 * part_per_slice && p.ntiles <= 1024;
+        const int split_fit = ws_ok ? (int)((q.ws_bytes - SPLITK_PART_OFFSET) / part_per_slice) : 1;
+        // K split: ~2 workgroups per CU, every wave of a workgroup gets at least one stage
         int split_k = 1;
         const int fs = g_force_split_k.load();
         if (fs >= 1) {
             split_k = fs;
-            if (split_k > 1 && !ws_ok) return GPTQ_E_WORKSPACE;
+            if (split_k > 1 && (!ws_ok || split_k > split_fit)) return GPTQ_E_WORKSPACE;
         } else if (ws_ok) {
-            // the combine costs M*N*S returning atomics (~50 G/s measured): split K less as M grows
-            const int target = mc <= 4 ? 768 : (mc <= 8 ? 256 : 0);
-            split_k = target ? (target + p.ntiles - 1) / p.ntiles : 1;
+            split_k = (512 + p.ntiles - 1) / p.ntiles;
+            if (split_k > split_fit) split_k = split_fit;
         }
         if (split_k > split_max) split_k = split_max;
         if (split_k * w > nstages) split_k = nstages / w;
@@ -274,6 +276,7 @@ static int run_skinny(const Problem &q, hipStream_t s) {
         }
         if (!xlds && stg == 2) return run_gemv(q, s);
         split_k = (nstages + sps - 1) / sps;
+        if (split_k > 1 && split_k > split_fit) return GPTQ_E_WORKSPACE;
         p.split_k = split_k;
         p.nchunks = nunits;
         p.chunks_per_slice = sps * stg;
@@ -285,7 +288,7 @@ static int run_skinny(const Problem &q, hipStream_t s) {
 
 static int run_auto(const Problem &q, hipStream_t s) {
     if (q.M == 0) return 0;
-    if (q.M == 1) return run_gemv(q, s);               // rowwave GEMV (generic kernel for act-order / 3-bit)
+    if (q.M <= 2) return run_gemv(q, s);               // rowwave GEMV, one launch per row (generic kernel for act-order)
     if (q.M <= SKINNY_MAX_M) return run_skinny(q, s);  // falls back to the GEMV for act-order / 3-bit
     const int unit_k = (q.bits == 2) ? 64 : 32;
     if (!q.fused2 && fast_eligible(q, unit_k)) {

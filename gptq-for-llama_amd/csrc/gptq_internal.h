@@ -14,6 +14,10 @@ constexpr int SKINNY_MAX_M = 64;      // rows served by the weight-streaming MFM
 constexpr int GEMV_NUM_VARIANTS = 3;   // packed rows in flight per wave: variant v -> U = 8 >> v
 // split-K workspace: one 64-bit word per output element ([M][N]), all-zero between launches
 constexpr size_t WS_BYTES = (size_t)SKINNY_MAX_M * 32768 * 8;
+// workspace layout: [0, 256 KiB) one u64 word per output column of the M = 1 GEMV combine | 4 KiB of per-tile
+// arrival tickets of the stream kernel (u32, zero between launches) | the stream kernel's partial tiles
+constexpr size_t SPLITK_TICKET_OFFSET = 32768 * 8;
+constexpr size_t SPLITK_PART_OFFSET = SPLITK_TICKET_OFFSET + 4096;
 
 struct GemvParams {
     const half_t *x;

@@ -422,6 +422,40 @@ __global__ void __launch_bounds__(WAVES * 64) stream_kernel(const GemvParams p) 
     stamp(5);
 
     const int nq = mrows * (TILE / 4);
+    // K slices are combined through per-slice partial tiles in the workspace + ONE arrival ticket per
+    // tile (not per-element atomics: M*N*S returning atomics saturate at ~50 G/s, tools/timeline_stream.py).
+    // Publication follows MI355X_MICROARCH.md "Valid forms": system-scope (write-through) stores, vmcnt(0),
+    // agent-scope ticket; the last slice reads every partial with system-scope loads, in slice order
+    // (bit-reproducible), and applies the epilogue.
+    __shared__ int last_slice;
+    const int S = p.split_k;
+    float *part_base = (float *)((char *)p.ws + SPLITK_PART_OFFSET) + (size_t)tile * S * NS * mrows * TILE;
+    if (S > 1) {
+        float *mine = part_base + (size_t)slice * NS * mrows * TILE;
+        for (int e = tid; e < nq; e += T) {
+            const int m = e >> 4, c4 = e & 15;
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                float4_t tot = (float4_t)0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES; w++) tot += *(const float4_t *)(red + (((size_t)w * NS + s) * mrows + m) * TILE + 4 * c4);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    __hip_atomic_store(mine + ((size_t)s * mrows + m) * TILE + 4 * c4 + j, tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned *ticket = (unsigned *)((char *)p.ws + SPLITK_TICKET_OFFSET) + tile;
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == (unsigned)(S - 1));
+            if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_slice = last;
+        }
+        __syncthreads();
+        if (!last_slice) return;
+    }
     for (int e = tid; e < nq; e += T) {
         const int m = e >> 4, c4 = e & 15;
         const int n = tile * TILE + 4 * c4;
@@ -429,29 +463,29 @@ __global__ void __launch_bounds__(WAVES * 64) stream_kernel(const GemvParams p) 
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             tot[s] = (float4_t)0.f;
+            if (S > 1) {
+                for (int sl = 0; sl < S; sl++) {
+                    const float *src = part_base + ((size_t)sl * NS + s) * mrows * TILE + (size_t)m * TILE + 4 * c4;
 #pragma unroll
-            for (int w = 0; w < WAVES; w++) tot[s] += *(const float4_t *)(red + (((size_t)w * NS + s) * mrows + m) * TILE + 4 * c4);
+                    for (int j = 0; j < 4; j++) tot[s][j] += __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            } else {
+#pragma unroll
+                for (int w = 0; w < WAVES; w++) tot[s] += *(const float4_t *)(red + (((size_t)w * NS + s) * mrows + m) * TILE + 4 * c4);
+            }
         }
         if (n < N) {
             half4_t h;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                float t0 = tot[0][j], t1 = 0.f;
-                if constexpr (FUSED2) t1 = tot[1][j];
-                bool ok = true;
-                if (p.split_k > 1) {
-                    u64_t *word = p.ws + (size_t)m * N + n + j;
-                    if constexpr (FUSED2) ok = splitk_add2(word, t0, t1, p.split_k, t0, t1);
-                    else ok = splitk_add1(word, t0, p.split_k, t0);
-                }
+                const float t0 = tot[0][j];
                 float v = t0;
-                if constexpr (FUSED2) v = t0 * (1.0f / (1.0f + __expf(-t0))) * t1;  // silu on the fp32 sum
+                if constexpr (FUSED2) v = t0 * (1.0f / (1.0f + __expf(-t0))) * tot[1][j];  // silu on the fp32 sum
                 half_t hv = (half_t)v;
                 if (p.bias) hv = (half_t)((float)hv + (float)p.bias[n + j]);
                 h[j] = hv;
-                if (p.split_k > 1 && ok) p.y[(size_t)m * p.ldy + n + j] = hv;  // completion is per word
             }
-            if (p.split_k <= 1) *(half4_t *)(p.y + (size_t)m * p.ldy + n) = h;
+            *(half4_t *)(p.y + (size_t)m * p.ldy + n) = h;
         }
     }
     stamp(6);

@@ -269,9 +269,15 @@ def main():
         if not args.no_per_shape and world == 1:
             out['per_shape'] = work.per_shape()
         if not args.no_decode and world == 1:
-            out['decode'] = decode_tokens_per_s(dev)
+            try:
+                out['decode'] = decode_tokens_per_s(dev)
+            except Exception as e:   # the headline line must survive a failure of a side leg
+                out['decode'] = {'error': repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline()
+            try:
+                out['cpu_baseline'] = cpu_baseline()
+            except Exception as e:
+                out['cpu_baseline'] = {'error': repr(e)[:200]}
         print(json.dumps(out))
     if distributed:
         dist.barrier()

@@ -118,7 +118,9 @@ static int run_rowwave3(const Problem &q, hipStream_t s) {
     if (fs >= 1) split_k = fs;
     if (split_k > nchunk) split_k = nchunk;
     if (split_k > SPLITK_MAX_SINGLE) split_k = SPLITK_MAX_SINGLE;
-    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)q.N * 8;
+    // the per-column combine words live in the first SPLITK_TICKET_OFFSET bytes of the workspace (the rest belongs
+    // to the stream kernel's tickets / partial tiles and is not zero): wider layers run without a K split
+    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)q.N * 8 && (size_t)q.N * 8 <= SPLITK_TICKET_OFFSET;
     if (split_k > 1 && !ws_ok) {
         if (fs >= 1) return GPTQ_E_WORKSPACE;
         split_k = 1;
@@ -170,7 +172,9 @@ static int run_rowwave(const Problem &q, hipStream_t s) {
     if (fs >= 1) split_k = fs;
     if (split_k > nchunk) split_k = nchunk;
     if (split_k > split_max) split_k = split_max;
-    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)q.N * 8;
+    // the per-column combine words live in the first SPLITK_TICKET_OFFSET bytes of the workspace (the rest belongs
+    // to the stream kernel's tickets / partial tiles and is not zero): wider layers run without a K split
+    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)q.N * 8 && (size_t)q.N * 8 <= SPLITK_TICKET_OFFSET;
     if (split_k > 1 && !ws_ok) {
         if (fs >= 1) return GPTQ_E_WORKSPACE;
         split_k = 1;

@@ -318,6 +318,18 @@ def test_odd_groupsize_goes_generic():
     check_forward(x, L)
 
 
+def test_very_wide_layer_runs_without_k_split():
+    """N > 32768: the split-K words would not fit their workspace region; the GEMV must stay correct."""
+    K, N = 256, 32768 + 256
+    L = make_random_layer(4, 128, K, N, seed=5)
+    x = np.random.default_rng(2).standard_normal((1, K)).astype(np.float16)
+    check_forward(x, L)
+    L2 = make_random_layer(4, 128, 1024, 512, seed=6)        # and the next split-K launch still finds zeros
+    x2 = np.random.default_rng(3).standard_normal((1, 1024)).astype(np.float16)
+    check_forward(np.repeat(x2, 40, 0), L2, family='skinny')
+    check_forward(x2, L2)
+
+
 def test_zero_rows_and_empty():
     L = make_random_layer(4, 128, 256, 128, seed=1)
     y = QL.matmul248(torch.empty(0, 256, dtype=torch.float16, device=DEV), dev(L['qweight']), dev(L['scales']),

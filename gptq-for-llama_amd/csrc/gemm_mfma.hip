@@ -62,7 +62,7 @@ template <int BITS>
 GPTQ_DEV half8_t dequant8(const uint32_t *w, half2_t zc, half2_t s2, uint32_t msk, uint32_t mag);
 
 template <>
-GPTQ_DEV half8_t dequant8<4>(const uint32_t *w, half2_t zc, half2_t s2, uint32_t msk, uint32_t mag) {
+__device__ __forceinline__ half8_t dequant8<4>(const uint32_t *w, half2_t zc, half2_t s2, uint32_t msk, uint32_t mag) {
     half2_t t[4];
     Unpack<4>::pairs_rc(w[0], t, msk, mag);  // {OFF+q_i, OFF+q_{i+4}}
 #pragma unroll
@@ -71,7 +71,7 @@ GPTQ_DEV half8_t dequant8<4>(const uint32_t *w, half2_t zc, half2_t s2, uint32_t
 }
 
 template <>
-GPTQ_DEV half8_t dequant8<8>(const uint32_t *w, half2_t zc, half2_t s2, uint32_t msk, uint32_t mag) {
+__device__ __forceinline__ half8_t dequant8<8>(const uint32_t *w, half2_t zc, half2_t s2, uint32_t msk, uint32_t mag) {
     half2_t a[2], b[2];
     Unpack<8>::pairs_rc(w[0], a, msk, mag);  // bytes (0,2), (1,3)
     Unpack<8>::pairs_rc(w[1], b, msk, mag);

@@ -206,6 +206,20 @@ GPTQ_DEV uint32_t sreg_const(uint32_t c) {
     return v;
 }
 
+// 16-byte system-scope (sc0 sc1: write-through / cache-bypassing) accesses for hand-offs between
+// workgroups (MI355X_MICROARCH.md "Valid forms").  The loads are issued without a wait; call
+// wait_sys_loads() on the whole batch before using any of them.
+GPTQ_DEV void store_sys16(float *p, float4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+GPTQ_DEV void load_sys16_issue(float4_t &v, const float *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+}
+template <int NB>
+GPTQ_DEV void wait_sys_loads(float4_t (&v)[NB]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NB; i++) asm volatile("" : "+v"(v[i]));   // no use of v[i] may move above the wait
+}
+
 // Development-only s_memtime / s_memrealtime checkpoints (tools/timeline.py).
 GPTQ_DEV u64_t stamp_cycles(uint32_t dep) {
     u64_t t;

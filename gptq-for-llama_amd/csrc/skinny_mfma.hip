@@ -439,9 +439,7 @@ __global__ void __launch_bounds__(WAVES * 64) stream_kernel(const GemvParams p) 
                 float4_t tot = (float4_t)0.f;
 #pragma unroll
                 for (int w = 0; w < WAVES; w++) tot += *(const float4_t *)(red + (((size_t)w * NS + s) * mrows + m) * TILE + 4 * c4);
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    __hip_atomic_store(mine + ((size_t)s * mrows + m) * TILE + 4 * c4 + j, tot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                store_sys16(mine + ((size_t)s * mrows + m) * TILE + 4 * c4, tot);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -464,10 +462,17 @@ __global__ void __launch_bounds__(WAVES * 64) stream_kernel(const GemvParams p) 
         for (int s = 0; s < NS; s++) {
             tot[s] = (float4_t)0.f;
             if (S > 1) {
-                for (int sl = 0; sl < S; sl++) {
-                    const float *src = part_base + ((size_t)sl * NS + s) * mrows * TILE + (size_t)m * TILE + 4 * c4;
+                for (int sl0 = 0; sl0 < S; sl0 += 8) {   // 8 slices in flight per wait, summed in slice order
+                    float4_t v[8];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) tot[s][j] += __hip_atomic_load(src + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    for (int i = 0; i < 8; i++) {
+                        const int sl = min(sl0 + i, S - 1);
+                        load_sys16_issue(v[i], part_base + ((size_t)sl * NS + s) * mrows * TILE + (size_t)m * TILE + 4 * c4);
+                    }
+                    wait_sys_loads(v);
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (sl0 + i < S) tot[s] += v[i];
                 }
             } else {
 #pragma unroll

@@ -244,7 +244,9 @@ static int run_skinny(const Problem &q, hipStream_t s) {
         p.ntiles = (q.N + 63) / 64;
         p.units_per_group = upg;
         p.upg_shift = ilog2_exact(upg);
-        bool xlds = mc <= 16;
+        // x rows staged in LDS: M <= 16 always, M <= 32 with the 4-unit-stage kernel (M = 64 measured slower than
+        // re-reading x from L2: four A fragments per unit make the wave LDS-bound)
+        bool xlds = mc <= 16 || (mc <= 32 && upg % 4 == 0);
         int stg = (upg % 4 == 0) ? 4 : ((upg % 2 == 0 && xlds) ? 2 : 1);
         const int nstages = nunits / stg;
         const int w = (xlds && stg == 4) ? waves : 4;
@@ -267,7 +269,7 @@ static int run_skinny(const Problem &q, hipStream_t s) {
         if (split_k < 1) split_k = 1;
         int sps = (nstages + split_k - 1) / split_k;  // stages per slice
         // staged x must fit: rows * (units * unit_k + 8) halves
-        const int xrows = mc < 16 ? mc : 16;
+        const int xrows = mc;
         auto x_bytes = [&](int sps_) { return (size_t)xrows * ((size_t)sps_ * stg * unit_k + 8) * 2 + 16; };
         if (xlds && x_bytes(sps) > 64 * 1024) {
             if (ws_ok && fs < 1) {

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(WAVES * 64) stream_kernel(const GemvParams p) 
     const int nk = (ue_s - ub_s) * UK;
     const int xstride = nk + 8;  // +16 B so that rows start on different bank groups
     half_t *lx = (half_t *)smem;
-    const int xrows = XLDS ? min(p.M, 16) : 0;
+    const int xrows = XLDS ? min(p.M, MT * 16) : 0;
     half_t *zero_chunk = lx + (size_t)xrows * xstride;
 
     using Stage = StreamStage<BITS, STG, MT, XLDS, FUSED2>;
@@ -304,18 +304,27 @@ __global__ void __launch_bounds__(WAVES * 64) stream_kernel(const GemvParams p) 
     }
 
     // LDS address of this lane's A fragment: row cl of the staged x, or the zero chunk
-    const bool arow_live = XLDS && cl < xrows;
-    const half_t *arow = arow_live ? (lx + (size_t)cl * xstride + kg * (UK / 4)) : zero_chunk;
-    const int astep = arow_live ? UK : 0, tstep = arow_live ? 8 : 0;
+    const half_t *arow[MT];
+    int astep[MT], tstep[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const bool live = XLDS && (mt * 16 + cl) < xrows;
+        arow[mt] = live ? (lx + (size_t)(mt * 16 + cl) * xstride + kg * (UK / 4)) : zero_chunk;
+        astep[mt] = live ? UK : 0;
+        tstep[mt] = live ? 8 : 0;
+    }
 
     auto compute_stage = [&](const Stage &st, int u0) {
 #pragma unroll
         for (int i = 0; i < STG; i++) {
             half8_t a[MT][STEPS];
             if constexpr (XLDS) {
-                const half_t *ap = arow + (size_t)(u0 + i - ub_s) * astep;
 #pragma unroll
-                for (int t = 0; t < STEPS; t++) a[0][t] = *(const half8_t *)(ap + t * tstep);
+                for (int mt = 0; mt < MT; mt++) {
+                    const half_t *ap = arow[mt] + (size_t)(u0 + i - ub_s) * astep[mt];
+#pragma unroll
+                    for (int t = 0; t < STEPS; t++) a[mt][t] = *(const half8_t *)(ap + t * tstep[mt]);
+                }
             } else {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) permute_a<BITS>(st.x[i][mt], a[mt]);
@@ -502,7 +511,7 @@ static int launch_stream(const GemvParams &p, hipStream_t stream) {
     constexpr int UK = Stream<BITS>::UK;
     const int mrows = p.M < MT * 16 ? p.M : MT * 16;
     const size_t red = (size_t)WAVES * NS * mrows * 64 * 4;
-    const size_t xb = XLDS ? ((size_t)(p.M < 16 ? p.M : 16) * ((size_t)p.chunks_per_slice * UK + 8) * 2 + 16) : 0;
+    const size_t xb = XLDS ? ((size_t)mrows * ((size_t)p.chunks_per_slice * UK + 8) * 2 + 16) : 0;
     const size_t lds = ((red > xb ? red : xb) + 15) & ~(size_t)15;
     if (lds > 160 * 1024 - 64) return GPTQ_E_SHAPE;
     auto kern = stream_kernel<BITS, STG, MT, WAVES, XLDS, FUSED2>;
@@ -535,13 +544,13 @@ static int stream_m(const GemvParams &p, int stg, int waves, bool xlds, hipStrea
         return launch_stream<BITS, 1, 1, 4, false, FUSED2>(p, s);
     }
     if (p.M <= 32) {
-        if (stg == 4) return launch_stream<BITS, 4, 2, 4, false, FUSED2>(p, s);
+        if (stg == 4) return xlds ? launch_stream<BITS, 4, 2, 4, true, FUSED2>(p, s) : launch_stream<BITS, 4, 2, 4, false, FUSED2>(p, s);
         return launch_stream<BITS, 1, 2, 4, false, FUSED2>(p, s);
     }
     if constexpr (FUSED2) {
         return GPTQ_E_VARIANT;  // fused: two accumulator sets; capi.hip feeds it 32 rows at a time
     } else {
-        if (stg == 4) return launch_stream<BITS, 2, 4, 4, false, FUSED2>(p, s);
+        if (stg == 4) return xlds ? launch_stream<BITS, 2, 4, 4, true, FUSED2>(p, s) : launch_stream<BITS, 2, 4, 4, false, FUSED2>(p, s);
         return launch_stream<BITS, 1, 4, 4, false, FUSED2>(p, s);
     }
 }

@@ -418,7 +418,15 @@ int main(int argc, char **argv) {
         };
 
         if (N % 256 == 0) {
-            int Ss[] = {8, 16, 32, 43};
+            if (rows % 64 == 0) {
+                constexpr int U = 16;
+                P p = base; p.nchunk = rows / (4 * U); p.S = p.nchunk;
+                double e = check(launch_rowwave<U, 0>, p);
+                float t0 = time_graph(launch_rowwave<U, 0>, p, sets, s, 5);
+                float t2 = time_graph(launch_rowwave<U, 2>, p, sets, s, 5);
+                printf("  rowwave U16 S%-3d wgs %5d | full %6.2f us %5.0f GB/s err %.1e | loadsonly %6.2f\n", p.S, p.ntile * p.S, t0, bytes / t0 / 1e3, e, t2);
+            }
+            int Ss[] = {16};
             for (int S : Ss) {
                 do {
                     constexpr int U = 8;

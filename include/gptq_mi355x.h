@@ -54,7 +54,7 @@ enum {
 /* gptq_query(what) */
 enum {
     GPTQ_Q_ABI_VERSION = 0,
-    GPTQ_Q_GEMV_MAX_M = 1,        /* largest M served by the wavefront-reduction GEMV        */
+    GPTQ_Q_GEMV_MAX_M = 1,        /* largest M gptq_gemv_f16 serves with one launch per row   */
     GPTQ_Q_SKINNY_MAX_M = 2,      /* largest M served by the weight-streaming MFMA kernel    */
     GPTQ_Q_WORKSPACE_BYTES = 3,   /* bytes of zero-initialised workspace split-K needs       */
     GPTQ_Q_NUM_GEMV_VARIANTS = 4
@@ -63,11 +63,11 @@ enum {
 int gptq_query(int what);
 const char *gptq_strerror(int code);
 
-/* Dispatch override used by autotune_warmup_* and the benchmarks: variant < 0 restores the
- * built-in shape table.  For gptq_gemv_f16 the value indexes the (tile, threads) table of
- * gemv.hip; for the weight-streaming MFMA kernel the values 2, 4, 8 select the waves per
- * workgroup.  gptq_set_split_k forces the number of K slices (>= 1).  Both return the
- * previous value. */
+/* Dispatch override used by the tests and the sweeps: variant < 0 restores the built-in choice.
+ * For the rowwave GEMV variant v selects U = 8 >> v packed rows in flight per wave (v in 0..2; 3-bit:
+ * 2 >> v 32-k blocks, v in 0..1) and is refused (GPTQ_E_VARIANT) when U does not divide the group;
+ * for the weight-streaming MFMA kernel the values 2, 4, 8 select the waves per workgroup.
+ * gptq_set_split_k forces the number of K slices (>= 1).  Both return the previous value. */
 int gptq_set_gemv_variant(int variant);
 int gptq_set_split_k(int split_k);
 /* Prefill GEMM kernel selection (tests / A-B measurements): 2 = ping-pong kernel (default), 3 = all-LDS-DMA
@@ -80,8 +80,8 @@ void *gptq_set_debug_buffer(void *device_buffer);
 /*
  * y = x . deq(B) (+ bias)  -- reference matmul248() + matmul_248_kernel + the bias add in
  * QuantLinear.forward (quant/quant_linear.py:263-269, :72-137, :373-377).
- * Chooses the GEMV (M small), the weight-streaming MFMA kernel (M <= 64) or the tiled MFMA
- * GEMM (prefill).  workspace: >= gptq_query(GPTQ_Q_WORKSPACE_BYTES) bytes, zero on first use
+  * Chooses the rowwave GEMV (M <= 2, one launch per row), the weight-streaming MFMA kernel (M <= 64)
+ * or the tiled MFMA GEMM (prefill).  workspace: >= gptq_query(GPTQ_Q_WORKSPACE_BYTES) bytes, zero on first use
  * (the kernels restore it to zero); may be NULL, which disables split-K variants.
  */
 int gptq_matmul248_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales,

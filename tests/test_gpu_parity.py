@@ -500,3 +500,33 @@ def test_autograd_backward_matches_oracle():
     y.backward(dev(dy))
     ref = oracle.transpose_matmul248(dy, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)
     assert rel_err(x.grad.cpu().numpy(), ref) < TOL
+
+
+def _fuzz_cases(n=96, seed=2024):
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        bits = int(rng.choice([2, 3, 4, 8]))
+        gs = int(rng.choice([-1, 32, 64, 128]))
+        K = 32 * int(rng.integers(1, 65))
+        if gs != -1 and K % gs:
+            continue
+        N = 32 * int(rng.integers(1, 33))
+        M = int(rng.choice([1, 1, 1, 2, 3, 5, 16, 17, 40, 70, 130, 300]))
+        act = bool(rng.integers(0, 4) == 0) and gs != -1
+        fam = [None, 'abi'][int(rng.integers(0, 2))]
+        cases.append((bits, gs, K, N, M, act, bool(rng.integers(0, 2)), fam))
+    return cases
+
+
+@pytest.mark.parametrize('case', _fuzz_cases(), ids=lambda c: 'w%dg%d_K%d_N%d_M%d%s%s_%s' % (c[0], c[1], c[2], c[3], c[4], '_act' if c[5] else '',
+                                                                                      '_bias' if c[6] else '', c[7] or 'py'))
+def test_fuzz_shapes_vs_oracle(case):
+    """seeded random sweep over bits / group / act-order / ragged shapes / M regimes through both the
+    Python dispatch and the bare C-ABI dispatch: every kernel family against the oracle."""
+    bits, gs, K, N, M, act, with_bias, fam = case
+    L = make_random_layer(bits, gs, K, N, act_order=act, seed=K + N + M + bits)
+    rng = np.random.default_rng(K * 7 + N)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float16) if with_bias else None
+    check_forward(x, L, bias=bias, family=fam)

@@ -209,15 +209,31 @@ GPTQ_DEV uint32_t sreg_const(uint32_t c) {
 // 16-byte system-scope (sc0 sc1: write-through / cache-bypassing) accesses for hand-offs between
 // workgroups (MI355X_MICROARCH.md "Valid forms").  The loads are issued without a wait; call
 // wait_sys_loads() on the whole batch before using any of them.
-GPTQ_DEV void store_sys16(float *p, float4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-GPTQ_DEV void load_sys16_issue(float4_t &v, const float *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+// The s_nop is REQUIRED: a global store of more than 8 bytes reads its data VGPRs one wait state after
+// issue ("12-dword store" hazard).  The compiler's hazard recogniser does not look inside inline asm, so
+// without it the next VALU write to v's first register was stored instead of v (found by the fused-MLP
+// fuzz test: zeros at every 4th column of the partial tiles).
+GPTQ_DEV void store_sys16(float *p, float4_t v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
-template <int NB>
-GPTQ_DEV void wait_sys_loads(float4_t (&v)[NB]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < NB; i++) asm volatile("" : "+v"(v[i]));   // no use of v[i] may move above the wait
+// Eight independent 16-byte system-scope loads and their wait as ONE asm statement: the compiler
+// cannot see that the destination registers are not valid until the s_waitcnt, so issue and wait
+// must not be separable (a register move scheduled in between would copy stale data).  Early-clobber outputs: the data
+// lands asynchronously, so no destination may share registers with any of the address operands.
+GPTQ_DEV void load_sys16_x8(float4_t (&v)[8], const float *const (&p)[8]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+        "global_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+        "global_load_dwordx4 %2, %10, off sc0 sc1\n\t"
+        "global_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+        "global_load_dwordx4 %4, %12, off sc0 sc1\n\t"
+        "global_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+        "global_load_dwordx4 %6, %14, off sc0 sc1\n\t"
+        "global_load_dwordx4 %7, %15, off sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+        : "memory");
 }
 
 // Development-only s_memtime / s_memrealtime checkpoints (tools/timeline.py).

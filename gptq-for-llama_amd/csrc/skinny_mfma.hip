@@ -473,12 +473,13 @@ __global__ void __launch_bounds__(WAVES * 64) stream_kernel(const GemvParams p) 
             if (S > 1) {
                 for (int sl0 = 0; sl0 < S; sl0 += 8) {   // 8 slices in flight per wait, summed in slice order
                     float4_t v[8];
+                    const float *src[8];
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         const int sl = min(sl0 + i, S - 1);
-                        load_sys16_issue(v[i], part_base + ((size_t)sl * NS + s) * mrows * TILE + (size_t)m * TILE + 4 * c4);
+                        src[i] = part_base + ((size_t)sl * NS + s) * mrows * TILE + (size_t)m * TILE + 4 * c4;
                     }
-                    wait_sys_loads(v);
+                    load_sys16_x8(v, src);
 #pragma unroll
                     for (int i = 0; i < 8; i++)
                         if (sl0 + i < S) tot[s] += v[i];

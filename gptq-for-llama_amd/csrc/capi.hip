@@ -1,7 +1,9 @@
 // capi.hip -- extern "C" entry points of libgptq_mi355x.so (declared in include/gptq_mi355x.h)
 // and the static shape -> kernel dispatch that replaces the reference's Triton autotuner
 // (quant/custom_autotune.py:14-127, pruner :167-193) behind the same warm-up surface.
+#include <algorithm>
 #include <atomic>
+#include <cstring>
 
 #include "gptq_internal.h"
 
@@ -319,6 +321,12 @@ int gptq_query(int what) {
         case GPTQ_Q_SKINNY_MAX_M: return SKINNY_MAX_M;
         case GPTQ_Q_WORKSPACE_BYTES: return (int)WS_BYTES;
         case GPTQ_Q_NUM_GEMV_VARIANTS: return GEMV_NUM_VARIANTS;
+        case GPTQ_Q_CHAIN_WORKGROUPS: {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess) return -1;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+            return cus;
+        }
     }
     return -1;
 }
@@ -557,6 +565,76 @@ int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k
     if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
     return decode_attn_fused_launch((const half_t *)qkv, position, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out,
                                     (float *)workspace, heads, t_max, base, scale, (hipStream_t)stream);
+}
+
+// ---- persistent matvec chain ----
+static size_t chain_off_counters(int n) { return (size_t)n * sizeof(ChainOpDev); }
+static size_t chain_off_status(int n) { return chain_off_counters(n) + (size_t)n * CHAIN_NCNT * CHAIN_CNT_STRIDE * 4; }
+static size_t chain_off_end(int n) { return chain_off_status(n) + 128; }
+
+size_t gptq_chain_state_bytes(int n_ops) { return n_ops > 0 ? chain_off_end(n_ops) : 0; }
+size_t gptq_chain_status_offset(int n_ops) { return n_ops > 0 ? chain_off_status(n_ops) : 0; }
+
+int gptq_chain_encode(const gptq_chain_op *ops, int n_ops, int bits, int num_workgroups, void *state_host, size_t state_bytes) {
+    if (!ops || !state_host) return GPTQ_E_NULL;
+    if (bits != 4) return bits == 2 || bits == 3 || bits == 8 ? GPTQ_E_VARIANT : GPTQ_E_BITS;
+    if (n_ops <= 0 || num_workgroups <= 0) return GPTQ_E_SHAPE;
+    if (state_bytes < gptq_chain_state_bytes(n_ops)) return GPTQ_E_WORKSPACE;
+    memset(state_host, 0, gptq_chain_state_bytes(n_ops));
+    ChainOpDev *d = (ChainOpDev *)state_host;
+    const int G = num_workgroups;
+    for (int i = 0; i < n_ops; i++) {
+        const gptq_chain_op &o = ops[i];
+        const bool fused = o.qweight_up != nullptr;
+        if (!o.x || !o.y || !o.qweight || !o.scales || !o.qzeros) return GPTQ_E_NULL;
+        if (fused && (!o.scales_up || !o.qzeros_up)) return GPTQ_E_NULL;
+        if (o.K <= 0 || o.N <= 0 || o.groupsize <= 0 || o.K % 32 != 0 || o.N % 32 != 0) return GPTQ_E_SHAPE;   // the library-wide contract
+        if (o.K % 256 != 0 || o.K > CHAIN_MAX_K || o.N > CHAIN_MAX_N) return GPTQ_E_VARIANT;
+        int gshift = -1;
+        if (o.groupsize < o.K) {
+            if (o.groupsize < 64 || (o.groupsize & (o.groupsize - 1))) return GPTQ_E_VARIANT;
+            gshift = 0;
+            while ((8 << gshift) < o.groupsize) gshift++;
+        }
+        if (!aligned(o.x, 16) || !aligned(o.y, 2) || !aligned(o.qweight, 16) || !aligned(o.scales, 8) || !aligned(o.qzeros, 4)) return GPTQ_E_ALIGN;
+        if (fused && (!aligned(o.qweight_up, 16) || !aligned(o.scales_up, 8) || !aligned(o.qzeros_up, 4))) return GPTQ_E_ALIGN;
+        if (o.norm_weight && !aligned(o.norm_weight, 16)) return GPTQ_E_ALIGN;
+        ChainOpDev &e = d[i];
+        e.qw[0] = (const uint32_t *)o.qweight; e.sc[0] = (const half_t *)o.scales; e.qz[0] = o.qzeros;
+        e.qw[1] = (const uint32_t *)o.qweight_up; e.sc[1] = (const half_t *)o.scales_up; e.qz[1] = o.qzeros_up;
+        e.x = (const half_t *)o.x; e.y = (half_t *)o.y; e.resid = (const half_t *)o.residual; e.nw = (const half_t *)o.norm_weight;
+        e.eps = o.norm_eps;
+        e.K = o.K; e.N = o.N; e.rows = o.K / 8; e.tiles = (o.N + 255) / 256; e.nchunk = e.rows / 32; e.gshift = gshift;
+        e.ns = fused ? 2 : 1; e.rows_per_wave = 8;
+        // K slices per tile: minimise (rounds of jobs over the G workgroups) x (chunks per job); ties -> fewer atomics
+        const int smax = std::min(e.nchunk, fused ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE);
+        long best = -1;
+        for (int S = 1; S <= smax; S++) {
+            const long rounds = ((long)e.tiles * S + G - 1) / G, cpj = (e.nchunk + S - 1) / S;
+            if (best < 0 || rounds * cpj < best) { best = rounds * cpj; e.S = S; }
+        }
+        e.jobs = e.tiles * e.S;
+        e.dep_count = i > 0 ? d[i - 1].N : 0;
+    }
+    return 0;
+}
+
+int gptq_chain_run_f16(void *state_dev, int n_ops, int bits, int max_k, int num_workgroups, int flags, void *workspace,
+                       size_t workspace_bytes, gptq_stream_t stream) {
+    if (!state_dev || !workspace) return GPTQ_E_NULL;
+    if (bits != 4) return GPTQ_E_VARIANT;
+    if (n_ops <= 0 || num_workgroups <= 0 || max_k <= 0 || max_k > CHAIN_MAX_K) return GPTQ_E_SHAPE;
+    if (workspace_bytes < (size_t)2 * CHAIN_MAX_N * sizeof(u64_t)) return GPTQ_E_WORKSPACE;
+    if (!aligned(state_dev, 128) || !aligned(workspace, 8)) return GPTQ_E_ALIGN;
+    u64_t *dbg = (flags & 1) ? (u64_t *)g_debug_buffer.load() : nullptr;
+    if ((flags & 1) && !dbg) return GPTQ_E_NULL;
+    char *st = (char *)state_dev;
+    // one memset covers the arrival counters and the status line behind them
+    hipError_t e = hipMemsetAsync(st + chain_off_counters(n_ops), 0, chain_off_end(n_ops) - chain_off_counters(n_ops), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return chain_launch(bits, (const ChainOpDev *)st, n_ops, max_k, (uint32_t *)(st + chain_off_counters(n_ops)), (u64_t *)workspace,
+                        (uint32_t *)(st + chain_off_status(n_ops)), dbg,
+                        num_workgroups, (hipStream_t)stream);
 }
 
 }  // extern "C"

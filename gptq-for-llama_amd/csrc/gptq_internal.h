@@ -62,6 +62,26 @@ int dequant_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, cons
 int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 
+// ---- persistent matvec chain (chain.hip) ----
+constexpr int CHAIN_NCNT = 16;         // striped arrival counters per op
+constexpr int CHAIN_CNT_STRIDE = 32;   // uint32 per counter (128-byte lines)
+constexpr int CHAIN_MAX_N = 16384;     // two alternating combine-word regions inside the first 256 KiB of the workspace
+constexpr int CHAIN_MAX_K = 16384;     // x of one op staged in LDS (32 KiB)
+struct ChainOpDev {                    // device-side op descriptor, 128 bytes
+    const uint32_t *qw[2];
+    const half_t *sc[2];
+    const int32_t *qz[2];
+    const half_t *x;
+    half_t *y;
+    const half_t *resid;
+    const half_t *nw;
+    float eps;
+    int32_t K, N, rows, tiles, S, nchunk, gshift, ns, jobs, dep_count, rows_per_wave;
+};
+static_assert(sizeof(ChainOpDev) == 128, "ChainOpDev layout");
+int chain_launch(int bits, const ChainOpDev *ops_dev, int n_ops, int max_k, uint32_t *counters, u64_t *ws, uint32_t *status, u64_t *dbg,
+                 int nwg, hipStream_t s);
+
 int decode_rope_kv_launch(half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, int heads, int head_dim, int t_max, float base,
                           hipStream_t s);
 int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, const int64_t *pos, half_t *out, float *ws, int heads,

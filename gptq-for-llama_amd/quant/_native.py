@@ -61,7 +61,20 @@ _SIGNATURES = {
                                    c_float, c_float, c_void_p],
     'gptq_decode_attn_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
                              c_float, c_void_p],
+    'gptq_chain_state_bytes': [c_int],
+    'gptq_chain_status_offset': [c_int],
+    'gptq_chain_encode': [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t],
+    'gptq_chain_run_f16': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
 }
+
+
+class ChainOp(ctypes.Structure):
+    """struct gptq_chain_op (include/gptq_mi355x.h)"""
+    _fields_ = [('x', c_void_p), ('qweight', c_void_p), ('scales', c_void_p), ('qzeros', c_void_p),
+                ('qweight_up', c_void_p), ('scales_up', c_void_p), ('qzeros_up', c_void_p), ('y', c_void_p),
+                ('residual', c_void_p), ('norm_weight', c_void_p), ('norm_eps', c_float), ('K', c_int), ('N', c_int),
+                ('groupsize', c_int)]
+
 EXPORTS = sorted(list(_SIGNATURES) + ['gptq_strerror'])
 
 
@@ -87,6 +100,8 @@ def lib():
                 fn.restype = c_int
             L.gptq_set_debug_buffer.restype = c_void_p
             L.gptq_decode_attn_workspace_bytes.restype = c_size_t
+            for name in ('gptq_chain_state_bytes', 'gptq_chain_status_offset'):
+                getattr(L, name).restype = c_size_t
             L.gptq_strerror.argtypes = [c_int]
             L.gptq_strerror.restype = ctypes.c_char_p
             _lib = L

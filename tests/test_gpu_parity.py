@@ -561,3 +561,60 @@ def test_fuzz_fused_mlp_vs_oracle(case):
     ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits)
     assert np.isfinite(c.astype(np.float32)).all()
     assert rel_err(c, ref) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------
+# persistent matvec chain (csrc/chain.hip): n dependent ops in one launch vs the oracle run op by op
+# ---------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('K,I,gs', [(1024, 2816, 128), (2048, 1536, 64), (512, 1024, 512)])
+def test_chain_matches_oracle_op_by_op(K, I, gs):
+    """[RMSNorm + qkv] -> [o + residual] -> [RMSNorm + gate/up + SiLU] -> [down + residual] as ONE launch
+    (decoder-layer call order of reference fused_attn.py:117-161 / fused_mlp.py:203-218) against the oracle's
+    rmsnorm / matmul248 / fused_mlp applied one after the other; ragged tiles (N % 256 != 0) and a single group."""
+    from quant.chain import MatvecChain
+    import torch
+    bits = 4
+    assert I % 256 == 0                           # I is the K of down_proj
+    rng = np.random.default_rng(K + I)
+    Lq, Lo, Lg, Lu, Ld = (make_random_layer(bits, gs, a, b, seed=i) for i, (a, b) in enumerate(
+        [(K, 3 * K + 32), (K, K), (K, I), (K, I), (I, K)]))
+    h0 = rng.standard_normal(K).astype(np.float16)
+    attn = (rng.standard_normal(K) * 0.5).astype(np.float16)
+    ln1 = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+    ln2 = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+    eps = 1e-6
+
+    def mm(x, L, bias=None):
+        return oracle.matmul248(x[None, :], L['qweight'], L['scales'], L['qzeros'], L['g_idx'], bits, bias=bias)[0]
+    qkv_ref = mm(oracle.rmsnorm(h0[None, :], ln1, eps)[0], Lq)
+    h1 = mm(attn, Lo, bias=h0)
+    act_ref = oracle.fused_mlp(oracle.rmsnorm(h1[None, :], ln2, eps), (Lg['qweight'], Lg['scales'], Lg['qzeros'], Lg['g_idx']),
+                               (Lu['qweight'], Lu['scales'], Lu['qzeros'], Lu['g_idx']), bits)[0]
+    h2 = mm(act_ref, Ld, bias=h1)
+
+    dev = 'cuda:0'
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    W = {n: {k: t(L[k]) for k in ('qweight', 'scales', 'qzeros')} for n, L in (('q', Lq), ('o', Lo), ('g', Lg), ('u', Lu), ('d', Ld))}
+    h, a_in = t(h0), t(attn)
+    qkv = torch.zeros(3 * K + 32, dtype=torch.float16, device=dev)
+    act = torch.zeros(I, dtype=torch.float16, device=dev)
+    ch = MatvecChain(bits, gs, dev)
+    ch.add(h, W['q']['qweight'], W['q']['scales'], W['q']['qzeros'], qkv, norm_weight=t(ln1), norm_eps=eps)
+    ch.add(a_in, W['o']['qweight'], W['o']['scales'], W['o']['qzeros'], h, residual=h)
+    ch.add(h, W['g']['qweight'], W['g']['scales'], W['g']['qzeros'], act, up=(W['u']['qweight'], W['u']['scales'], W['u']['qzeros']),
+           norm_weight=t(ln2), norm_eps=eps)
+    ch.add(act, W['d']['qweight'], W['d']['scales'], W['d']['qzeros'], h, residual=h)
+    ch.run()
+    torch.cuda.synchronize()
+    assert ch.status() == 0
+    assert rel_err(qkv.cpu().numpy(), qkv_ref) < TOL
+    assert rel_err(act.cpu().numpy(), act_ref) < 2 * TOL      # behind two matvecs and an RMSNorm
+    assert rel_err(h.cpu().numpy(), h2) < 2 * TOL
+    first = (qkv.clone(), act.clone(), h.clone())
+    # replay: same inputs -> bit-identical outputs (fixed-point combine), workspace back to zero
+    h.copy_(t(h0))
+    ch.run()
+    torch.cuda.synchronize()
+    assert torch.equal(first[0], qkv) and torch.equal(first[1], act) and torch.equal(first[2], h)
+    assert int(ch.ws[:262144].view(torch.int64).ne(0).sum()) == 0

@@ -186,3 +186,50 @@ def test_row_and_col_sharded_linear_gloo_world2(act_order):
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(timeout=5) == 1
+
+
+def test_chain_encode_validates_and_picks_slices_without_a_gpu():
+    """gptq_chain_encode is pure host code: shape limits, error codes and the K-slice choice per op."""
+    import ctypes
+    import struct
+    lib = _native.lib()
+
+    def encode(ops, bits=4, nwg=256):
+        arr = (_native.ChainOp * len(ops))(*ops)
+        nbytes = lib.gptq_chain_state_bytes(len(ops))
+        buf = (ctypes.c_ubyte * nbytes)()
+        rc = lib.gptq_chain_encode(ctypes.cast(arr, ctypes.c_void_p), len(ops), bits, nwg, ctypes.cast(buf, ctypes.c_void_p), nbytes)
+        return rc, bytes(buf)
+
+    def op(K, N, gs=128, fused=False, **kw):
+        o = _native.ChainOp()
+        o.x = o.qweight = o.scales = o.qzeros = o.y = 4096
+        if fused:
+            o.qweight_up = o.scales_up = o.qzeros_up = 4096
+        o.K, o.N, o.groupsize = K, N, gs
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+    # the four ops of a LLaMA-7B decoder layer on 256 workgroups
+    rc, img = encode([op(4096, 12288), op(4096, 4096), op(4096, 11008, fused=True), op(11008, 4096)])
+    assert rc == 0
+    fields = [struct.unpack('<f11i', img[i * 128 + 80:(i + 1) * 128]) for i in range(4)]
+    #            eps  K      N      rows  tiles S   nchunk gshift ns jobs dep   rows/wave
+    assert fields[0][1:] == (4096, 12288, 512, 48, 16, 16, 4, 1, 768, 0, 8)
+    assert fields[1][1:] == (4096, 4096, 512, 16, 16, 16, 4, 1, 256, 12288, 8)
+    assert fields[2][1:] == (4096, 11008, 512, 43, 16, 16, 4, 2, 688, 4096, 8)
+    assert fields[3][1:] == (11008, 4096, 1376, 16, 15, 43, 4, 1, 240, 11008, 8)   # 15 and 16 slices both need 3 chunks per job: fewer atomics wins
+    assert lib.gptq_chain_status_offset(4) == 4 * 128 + 4 * 16 * 128
+    assert lib.gptq_chain_state_bytes(4) == lib.gptq_chain_status_offset(4) + 128
+    # refusals: nothing is written / launched
+    assert encode([op(4096, 4096)], bits=8)[0] == -6          # only 4-bit in this release
+    assert encode([op(4096, 4096)], bits=5)[0] == -1
+    assert encode([op(4000, 4096)])[0] == -6                  # K % 256
+    assert encode([op(32768, 4096)])[0] == -6                 # K > 16384 (x is staged in LDS)
+    assert encode([op(4096, 4104)])[0] == -2                  # N % 32 (library-wide shape contract)
+    assert encode([op(4096, 4096, gs=96)])[0] == -6           # group must be a power of two >= 64
+    assert encode([op(4096, 4096, gs=4096)])[0] == 0          # one group over all of K
+    assert encode([op(4096, 4096, x=None)])[0] == -4
+    assert encode([op(4096, 4096, x=4098)])[0] == -3
+    assert lib.gptq_chain_run_f16(None, 1, 4, 4096, 256, 0, None, 0, None) == -4

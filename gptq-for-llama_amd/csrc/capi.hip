@@ -348,6 +348,7 @@ const char *gptq_strerror(int code) {
 
 int gptq_set_gemv_variant(int variant) { return g_force_variant.exchange(variant); }
 int gptq_set_split_k(int split_k) { return g_force_split_k.exchange(split_k); }
+int gptq_set_chain_depth(int depth) { return chain_set_depth(depth); }
 void *gptq_set_debug_buffer(void *buf) { return g_debug_buffer.exchange(buf); }
 int gptq_set_gemm_kernel(int version) {
     return (version == 2 || version == 3 || (version >= 100 && version <= 104)) ? gemm_set_version(version) : GPTQ_E_VARIANT;

@@ -31,7 +31,7 @@
 
 namespace gptq {
 
-constexpr int CH_D = 4;            // tasks (8 KiB per wave each) in flight per compute wave
+constexpr int CH_D_DEFAULT = 4;    // tasks (8 KiB per wave each) in flight per compute wave (template parameter CH_D)
 constexpr int CH_R = 4;            // LDS ring slots for per-job partial sums
 constexpr uint32_t CH_SPIN_LIMIT = 1u << 19;
 
@@ -242,7 +242,7 @@ GPTQ_DEV void chain_math(const ChainTask &t, const u32x4 (&w)[8], const u32x2 &s
 //  service wave 4: 0 dependency seen | 1 x staged | 2 first job: partials arrived | 3 first job: combine atomic returned |
 //                  9 first job: y stored and acknowledged | 4 last job published
 //  compute wave 0: 5 x ready seen | 6 first task's weights landed | 8 first task's math done | 7 last job handed over
-template <int BITS, bool DBG>
+template <int BITS, bool DBG, int CH_D>
 __global__ void __launch_bounds__(512) chain_kernel(const ChainOpDev *__restrict__ ops, int n_ops, uint32_t *__restrict__ counters,
                                                     u64_t *__restrict__ ws, uint32_t *__restrict__ status, u64_t *__restrict__ dbg) {
     static_assert(BITS == 4, "chain kernel: 4-bit only (the decode headline); other widths use the per-op kernels");
@@ -448,17 +448,27 @@ __global__ void __launch_bounds__(512) chain_kernel(const ChainOpDev *__restrict
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
+static int g_chain_depth = CH_D_DEFAULT;
+int chain_set_depth(int d) {
+    const int prev = g_chain_depth;
+    if (d >= 2 && d <= CH_D_DEFAULT) g_chain_depth = d;
+    return prev;
+}
+
 int chain_launch(int bits, const ChainOpDev *ops_dev, int n_ops, int max_k, uint32_t *counters, u64_t *ws, uint32_t *status, u64_t *dbg,
                  int nwg, hipStream_t s) {
     if (bits != 4) return GPTQ_E_BITS;
     if (n_ops <= 0 || max_k <= 0 || max_k > CHAIN_MAX_K || nwg <= 0) return GPTQ_E_SHAPE;
     const size_t lds = sizeof(ChainLds) + (size_t)max_k * sizeof(half_t);
-    auto kern = dbg ? chain_kernel<4, true> : chain_kernel<4, false>;
-    static size_t configured = 0;
-    if (lds > 48 * 1024 && lds > configured) {
+    const int depth = g_chain_depth;
+    auto kern = dbg ? chain_kernel<4, true, CH_D_DEFAULT>
+                    : depth == 2 ? chain_kernel<4, false, 2> : depth == 3 ? chain_kernel<4, false, 3> : chain_kernel<4, false, CH_D_DEFAULT>;
+    static size_t configured[8] = {0};
+    size_t &conf = configured[(dbg ? 4 : 0) + (depth & 3)];
+    if (lds > 48 * 1024 && lds > conf) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        configured = lds;
+        conf = lds;
     }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, s, ops_dev, n_ops, counters, ws, status, dbg);
     return (int)hipGetLastError();

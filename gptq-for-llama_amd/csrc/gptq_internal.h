@@ -79,6 +79,7 @@ struct ChainOpDev {                    // device-side op descriptor, 128 bytes
     int32_t K, N, rows, tiles, S, nchunk, gshift, ns, jobs, dep_count, rows_per_wave;
 };
 static_assert(sizeof(ChainOpDev) == 128, "ChainOpDev layout");
+int chain_set_depth(int d);  // development: weight tasks in flight per compute wave (2..4); returns the previous value
 int chain_launch(int bits, const ChainOpDev *ops_dev, int n_ops, int max_k, uint32_t *counters, u64_t *ws, uint32_t *status, u64_t *dbg,
                  int nwg, hipStream_t s);
 

@@ -27,6 +27,7 @@ _SIGNATURES = {
     'gptq_query': [c_int],
     'gptq_set_gemv_variant': [c_int],
     'gptq_set_split_k': [c_int],
+    'gptq_set_chain_depth': [c_int],
     'gptq_set_debug_buffer': [c_void_p],
     'gptq_set_gemm_kernel': [c_int],
     'gptq_matmul248_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

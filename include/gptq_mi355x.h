@@ -71,6 +71,7 @@ const char *gptq_strerror(int code);
  * gptq_set_split_k forces the number of K slices (>= 1).  Both return the previous value. */
 int gptq_set_gemv_variant(int variant);
 int gptq_set_split_k(int split_k);
+int gptq_set_chain_depth(int depth);   /* development: 8-KiB weight tasks in flight per wave of the chain kernel (2..4) */
 /* Prefill GEMM kernel selection (tests / A-B measurements): 2 = ping-pong kernel (default), 3 = all-LDS-DMA
  * kernel with packed B in LDS (4-bit, groupsize % 64 == 0; measured 2-4 % slower).  Returns the previous value. */
 int gptq_set_gemm_kernel(int version);

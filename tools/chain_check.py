@@ -118,6 +118,11 @@ def main():
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / args.reps
     us_ops = time_graph(D.step)
+    for depth in (2, 3):
+        lib.gptq_set_chain_depth(depth)
+        us = time_graph(big.run)
+        print('chain depth %d   : %8.1f us/pass  %7.1f GB/s' % (depth, us, D.bytes_per_step / us / 1e3), flush=True)
+    lib.gptq_set_chain_depth(4)
     us_chain = time_graph(big.run)
     nb = D.bytes_per_step
     print('per-op launches: %8.1f us/pass  %7.1f GB/s (%.1f%% of 8 TB/s)' % (us_ops, nb / us_ops / 1e3, nb / us_ops / 1e3 / 80), flush=True)
@@ -128,7 +133,8 @@ def main():
     slots = [(0, 'dep seen'), (1, 'x staged'), (5, 'cw: x seen'), (6, 'cw: w landed'), (8, 'cw: math1 done'), (7, 'cw: last job handed'),
              (2, 'sw: job1 arrived'), (3, 'sw: job1 atomic back'), (9, 'sw: job1 y acked'), (4, 'sw: last job published')]
     for i in range(8, min(12, len(big.ops))):
-        t0 = tl[i, :, 0].min()
+        seen = tl[i, :, 0]
+        t0 = seen[seen > 0].min()           # workgroups without a job in this op leave no stamps
         print('  op %2d %-7s (t0 = first workgroup sees the dependency; min / median / max over workgroups, us)' % (i, names[i % 4]))
         for k, nm in slots:
             v = tl[i, :, k] - t0

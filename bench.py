@@ -175,6 +175,56 @@ def cpu_baseline(budget_s=20.0):
                       (n, nbytes / 1e6), 'seconds': round(t_total, 2)}
 
 
+def gptq_loop_baseline(dev):
+    """north_star: "the GPTQ column-wise Hessian loop in gptq.py is left to the CPU reference and timed on the host
+    cores of the GPU box in the same run as the reported-only baseline".  /root/reference does not travel, so the timed
+    code is its restatement oracle/gptq_solver.py (numpy + LAPACK, pinned to the reference's own GPTQ class by
+    tests/golden/gptq_*.npz): one 4096x4096 layer, 4-bit g128, Hessian from 2 x 2048 random tokens.
+    The MI355X solver (gptq-for-llama_amd/gptq.py, one HIP launch per 128-column block) runs on the same data for
+    scale.  Reported only -- not part of `value`."""
+    import numpy as np
+    from oracle import gptq_solver as G
+    rng = np.random.default_rng(0)
+    K = N = HIDDEN
+    W = (rng.standard_normal((N, K)) * 0.02).astype(np.float32)
+    X = [rng.standard_normal((1, 2048, K)).astype(np.float32) for _ in range(2)]
+    t0 = time.perf_counter()
+    H, n = np.zeros((K, K), np.float32), 0
+    for b in X:
+        H, n = G.hessian_add_batch(H, n, b)
+    t1 = time.perf_counter()
+    _, _, _, _, err_cpu = G.fasterquant(W, H, BITS, 128, 0.01, GS, False, False)
+    t2 = time.perf_counter()
+    out = {'layer': '4096x4096 nn.Linear -> 4-bit g128, Hessian from 2 x 2048 tokens', 'kind': 'port',
+           'cpu_add_batch_s': round(t1 - t0, 3), 'cpu_fasterquant_s': round(t2 - t1, 3), 'cpu_loss': round(err_cpu, 2),
+           'cores': os.cpu_count()}
+    try:
+        import gptq as product_gptq
+        layer = torch.nn.Linear(K, N, bias=False)
+        layer.weight.data = torch.from_numpy(W)
+        layer = layer.to(dev)
+        xs = [torch.from_numpy(b).to(dev) for b in X]
+        for timed in (False, True):         # first pass warms rocSOLVER / hipBLASLt up
+            layer.weight.data = torch.from_numpy(W).to(dev)
+            g = product_gptq.GPTQ(layer)
+            g.quantizer.configure(BITS, perchannel=True, sym=False, mse=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for b in xs:
+                g.add_batch(b, None)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                _, _, _, err_gpu = g.fasterquant(blocksize=128, percdamp=0.01, groupsize=GS, actorder=False, name='bench')
+            t2 = time.perf_counter()
+            g.free()
+        out.update({'gpu_add_batch_s': round(t1 - t0, 4), 'gpu_fasterquant_s': round(t2 - t1, 4), 'gpu_loss': round(err_gpu, 2)})
+    except Exception as e:
+        out['gpu_error'] = repr(e)[:200]
+    return out
+
+
 def decode_tokens_per_s(dev, tokens=64):
     """full decode step (norms, fused qkv + RoPE, KV cache, SDPA, o_proj, fused MLP, lm_head) on a
     random-init LLaMA-7B-shaped model built from the drop-in modules; protocol of the reference's
@@ -278,6 +328,10 @@ def main():
                 out['cpu_baseline'] = cpu_baseline()
             except Exception as e:
                 out['cpu_baseline'] = {'error': repr(e)[:200]}
+            try:
+                out['gptq_loop_reported_only'] = gptq_loop_baseline(dev)
+            except Exception as e:
+                out['gptq_loop_reported_only'] = {'error': repr(e)[:200]}
         print(json.dumps(out))
     if distributed:
         dist.barrier()

@@ -638,4 +638,16 @@ int gptq_chain_run_f16(void *state_dev, int n_ops, int bits, int max_k, int num_
                         num_workgroups, (hipStream_t)stream);
 }
 
+// ---- GPTQ solver: the sequential loop of one column block (gptq_solver.hip) ----
+int gptq_solver_block_f32(const float *W, int64_t ldw, const float *Hinv, int64_t ldh, int rows, int cols, int i1, int count, int groupsize,
+                          int maxq, const float *scale, const float *zero, int64_t ldg, float *Q, int64_t ldq, float *Err, int64_t lde,
+                          float *loss_rows, gptq_stream_t stream) {
+    if (!W || !Hinv || !scale || !zero || !Q || !Err || !loss_rows) return GPTQ_E_NULL;
+    if (rows <= 0 || cols <= 0 || i1 < 0 || count <= 0 || i1 + count > cols || groupsize <= 0 || maxq <= 0) return GPTQ_E_SHAPE;
+    if (count > 128) return GPTQ_E_VARIANT;   // two columns per lane
+    if (ldw < cols || ldh < cols || ldq < cols || lde < count || ldg < (cols + groupsize - 1) / groupsize) return GPTQ_E_SHAPE;
+    return gptq_block_launch(W, ldw, Hinv, ldh, rows, i1, count, groupsize, maxq, scale, zero, ldg, Q, ldq, Err, lde, loss_rows,
+                             (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -83,6 +83,10 @@ int chain_set_depth(int d);  // development: weight tasks in flight per compute 
 int chain_launch(int bits, const ChainOpDev *ops_dev, int n_ops, int max_k, uint32_t *counters, u64_t *ws, uint32_t *status, u64_t *dbg,
                  int nwg, hipStream_t s);
 
+int gptq_block_launch(const float *W, int64_t ldw, const float *Hinv, int64_t ldh, int rows, int i1, int count, int groupsize, int maxq,
+                      const float *scale, const float *zero, int64_t ldg, float *Q, int64_t ldq, float *Err, int64_t lde, float *loss_rows,
+                      hipStream_t s);
+
 int decode_rope_kv_launch(half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, int heads, int head_dim, int t_max, float base,
                           hipStream_t s);
 int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, const int64_t *pos, half_t *out, float *ws, int heads,

@@ -62,6 +62,8 @@ _SIGNATURES = {
                                    c_float, c_float, c_void_p],
     'gptq_decode_attn_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
                              c_float, c_void_p],
+    'gptq_solver_block_f32': [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
+                              c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
     'gptq_chain_state_bytes': [c_int],
     'gptq_chain_status_offset': [c_int],
     'gptq_chain_encode': [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t],

@@ -272,6 +272,21 @@ int gptq_chain_encode(const gptq_chain_op *ops, int n_ops, int bits, int num_wor
 int gptq_chain_run_f16(void *state_dev, int n_ops, int bits, int max_k, int num_workgroups, int flags, void *workspace,
                        size_t workspace_bytes, gptq_stream_t stream);
 
+/* ---- GPTQ solver (the caller that PRODUCES the weights; reference gptq.py:128-228) -------------------------------
+ * One column block [i1, i1 + count), count <= 128, of the sequential quantise / error-feedback loop (gptq.py:177-199)
+ * for all rows at once, in the reference's own fp32 arithmetic (IEEE division, round-half-even, no contraction).
+ *   W [rows, cols] (ldw)    current weights, read only (the block's columns; as the reference, the in-block updates
+ *                           live in registers -- its W1 clone -- and W itself changes only through the trailing update)
+ *   Hinv [cols, cols] (ldh) upper Cholesky factor of the inverse damped Hessian (gptq.py:160-163)
+ *   scale, zero [rows, ldg] grid of row r, group g = column / groupsize (pass groupsize = cols for "no groups");
+ *                           the host fits them from W before the block (gptq.py:181-183 -> quantizer.py:32-76)
+ *   Q [rows, cols] (ldq)    out: quantised (de-quantised, fp32) weights of the block's columns
+ *   Err [rows, count] (lde) out: Err1, for the trailing update W[:, i2:] -= Err1 . Hinv[i1:i2, i2:] (gptq.py:204)
+ *   loss_rows [rows]        in/out: += sum over the block's columns of (w - q)^2 / d^2 / 2 (gptq.py:194,202) */
+int gptq_solver_block_f32(const float *W, int64_t ldw, const float *Hinv, int64_t ldh, int rows, int cols, int i1, int count,
+                          int groupsize, int maxq, const float *scale, const float *zero, int64_t ldg, float *Q, int64_t ldq,
+                          float *Err, int64_t lde, float *loss_rows, gptq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

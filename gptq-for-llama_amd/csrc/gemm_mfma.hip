@@ -28,8 +28,8 @@
 
 namespace gptq {
 
-std::atomic<int> g_gemm_version{3};
-std::atomic<int> g_gemm_diag{0};      // timing experiments: see gemm_mfma_v3_kernel<DIAG>   // 2 = force the ping-pong kernel (tests / A-B measurements)
+std::atomic<int> g_gemm_version{2};   // 2 = ping-pong kernel (default), 3 = all-LDS-DMA kernel with packed B in LDS
+std::atomic<int> g_gemm_diag{0};      // timing experiments: see gemm_mfma_v3_kernel<DIAG>
 
 struct GemmParams {
     const half_t *a;

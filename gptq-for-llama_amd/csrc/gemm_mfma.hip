@@ -83,12 +83,15 @@ __device__ __forceinline__ half8_t dequant8<8>(const uint32_t *w, half2_t zc, ha
     return half8_t{a[0][0], a[1][0], a[0][1], a[1][1], b[0][0], b[1][0], b[0][1], b[1][1]};
 }
 
-// fp32 accumulators -> fp16, transposed through LDS (wave-private region), 16-B row stores (+bias)
+// fp32 accumulators -> fp16, transposed through LDS (wave-private region), 16-B row stores (+bias).
+// TN = 32-column tiles per wave (wave tile = 128 rows x 32*TN columns), wn = the wave's column index.
 constexpr int TN_ = WTN / 32;
-GPTQ_DEV void gemm_epilogue(const float16_t (&acc)[TN_][4], char *smem, int wave, int lane, int wm, int wn, int m0, int n0, int M, int N,
-                            const GemmParams &p) {
-    constexpr int TN = TN_;
-    char *cs = smem + wave * (128 * CROW);
+template <int TN>
+GPTQ_DEV void gemm_epilogue_t(const float16_t (&acc)[TN][4], char *smem, int wave, int lane, int wm, int wn, int m0, int n0, int M, int N,
+                              const GemmParams &p) {
+    constexpr int WCOLS = 32 * TN;         // columns per wave
+    constexpr int CR = WCOLS * 2 + 16;     // row stride (bytes) of the wave's 128 x WCOLS fp16 block
+    char *cs = smem + wave * (128 * CR);
     const int ml = lane & 31, nq = (lane >> 5) * 4;
 #pragma unroll
     for (int i = 0; i < TN; i++)
@@ -99,19 +102,19 @@ GPTQ_DEV void gemm_epilogue(const float16_t (&acc)[TN_][4], char *smem, int wave
                 const int nl = i * 32 + 8 * r + nq;  // D row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
                 const half4_t h = {(half_t)acc[i][jj][4 * r + 0], (half_t)acc[i][jj][4 * r + 1], (half_t)acc[i][jj][4 * r + 2],
                                    (half_t)acc[i][jj][4 * r + 3]};
-                *(half4_t *)(cs + (jj * 32 + ml) * CROW + nl * 2) = h;
+                *(half4_t *)(cs + (jj * 32 + ml) * CR + nl * 2) = h;
             }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the region is private to this wave
     __builtin_amdgcn_wave_barrier();
-    constexpr int LPR = WTN / 8;           // lanes per output row (16-B pieces)
+    constexpr int LPR = WCOLS / 8;         // lanes per output row (16-B pieces)
     constexpr int RPI = 64 / LPR;          // rows per store instruction
     const int c16 = lane % LPR, rsub = lane / LPR;
-    const int ncol = n0 + wn * WTN + c16 * 8;
+    const int ncol = n0 + wn * WCOLS + c16 * 8;
 #pragma unroll 4
     for (int r = 0; r < 128 / RPI; r++) {
         const int mloc = r * RPI + rsub;
         const int m = m0 + wm * 128 + mloc;
-        half8_t v = *(const half8_t *)(cs + mloc * CROW + c16 * 16);
+        half8_t v = *(const half8_t *)(cs + mloc * CR + c16 * 16);
         if (m < M && ncol < N) {
             if (p.bias) {
                 const half8_t b = *(const half8_t *)(p.bias + ncol);
@@ -121,6 +124,10 @@ GPTQ_DEV void gemm_epilogue(const float16_t (&acc)[TN_][4], char *smem, int wave
             *(half8_t *)(p.c + (size_t)m * p.ldc + ncol) = v;
         }
     }
+}
+GPTQ_DEV void gemm_epilogue(const float16_t (&acc)[TN_][4], char *smem, int wave, int lane, int wm, int wn, int m0, int n0, int M, int N,
+                            const GemmParams &p) {
+    gemm_epilogue_t<TN_>(acc, smem, wave, lane, wm, wn, m0, n0, M, N, p);
 }
 
 template <int BITS>
@@ -504,6 +511,7 @@ __global__ void __launch_bounds__(512) gemm_mfma_v3_kernel(const GemmParams p) {
     __syncthreads();
     gemm_epilogue(acc, smem, wave, lane, wm, wn, m0, n0, M, N, p);
 }
+
 
 template <int BITS>
 static int launch_gemm(const GemmParams &p, hipStream_t s) {

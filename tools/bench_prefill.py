@@ -13,7 +13,10 @@ from quant import _native, quant_linear as QL
 ap = argparse.ArgumentParser()
 ap.add_argument('--m', type=int, default=65536); ap.add_argument('--reps', type=int, default=5)
 ap.add_argument('--no-dense', action='store_true')
+ap.add_argument('--kernel', type=int, default=0, help='gptq_set_gemm_kernel: 2 ping-pong (default), 3 packed-B in LDS')
 a = ap.parse_args()
+if a.kernel:
+    _native.lib().gptq_set_gemm_kernel(a.kernel)
 dev = 'cuda:0'
 gen = torch.Generator(device=dev); gen.manual_seed(0)
 PEAK = 2500.0
@@ -30,7 +33,7 @@ for K, N in [(4096, 4096), (4096, 12288), (4096, 11008), (11008, 4096)]:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     tf = 2.0 * a.m * N * K / ms / 1e9
-    rec = {'shape': '%dx%d' % (K, N), 'M': a.m, 'ms': round(ms, 3), 'TFLOPs': round(tf, 1), 'frac_of_2.5PF': round(tf / PEAK, 4)}
+    rec = {'kernel': a.kernel or 2, 'shape': '%dx%d' % (K, N), 'M': a.m, 'ms': round(ms, 3), 'TFLOPs': round(tf, 1), 'frac_of_2.5PF': round(tf / PEAK, 4)}
     if not a.no_dense:
         # dense ceiling: the same product with the weight dequantised once (fp16) through hipBLASLt
         eye = torch.eye(K, device=dev, dtype=torch.float16)

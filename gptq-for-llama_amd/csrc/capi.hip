@@ -219,7 +219,49 @@ static int run_generic(const Problem &q, hipStream_t s) {
     return 0;
 }
 
+// 2 <= M <= 4, 4-bit, trivial g_idx: ONE rowwave launch for all rows (gemv_rowwave_mr_kernel)
+static int run_rowwave_mr(const Problem &q, hipStream_t s) {
+    if (q.bits != 4 || q.M < 2 || q.M > 4 || q.norm_w || q.xperm || g_force_variant.load() >= 0) return GPTQ_E_VARIANT;
+    if (!fast_eligible(q, 8)) return GPTQ_E_VARIANT;
+    const int rows = q.K / 8;
+    const int G = n_groups(q.K, q.groupsize);
+    const int rpg = q.groupsize / 8;
+    int gshift = -1;
+    if (G > 1) {
+        if (q.groupsize % 8 != 0) return GPTQ_E_VARIANT;
+        gshift = ilog2_exact(rpg);
+        if (gshift < 0) return GPTQ_E_VARIANT;
+    }
+    auto u_ok = [&](int u) { return rows % u == 0 && (G == 1 || rpg % u == 0); };
+    int u = 0;
+    for (int c = (q.M == 2 ? 8 : 4); c >= (q.M == 2 ? 4 : 2) && !u; c >>= 1)   // x rows live in SGPRs: MR * u * 4 dwords
+        if (u_ok(c)) u = c;
+    if (!u) return GPTQ_E_VARIANT;
+    const int ntile = (q.N + 255) / 256;
+    const int nchunk = (rows + 4 * u - 1) / (4 * u);
+    int split_k = nchunk;
+    if (ntile * split_k > 1024) split_k = 1024 / ntile;
+    if (split_k < 1) split_k = 1;
+    const int fs = g_force_split_k.load();
+    if (fs >= 1) split_k = fs;
+    if (split_k > nchunk) split_k = nchunk;
+    const int split_max = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
+    if (split_k > split_max) split_k = split_max;
+    const size_t words = (size_t)q.M * q.N * 8;
+    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= words && words <= SPLITK_TICKET_OFFSET;
+    if (split_k > 1 && !ws_ok) return GPTQ_E_VARIANT;   // the per-row / stream paths handle it
+    GemvParams p;
+    fill_params(q, 0, q.M, p);
+    p.split_k = split_k;
+    p.upg_shift = gshift;
+    return gemv_rowwave_mr_dispatch(q.fused2, u, p, s);
+}
+
 static int run_gemv(const Problem &q, hipStream_t s) {
+    if (q.M >= 2 && q.M <= 4) {
+        const int rc = run_rowwave_mr(q, s);
+        if (rc != GPTQ_E_VARIANT) return rc;
+    }
     const bool eligible3 = q.bits == 3 && !q.fused2 && !q.gi[0] && q.M <= GEMV_MAX_M;   // one launch per row
     if (eligible3 || fast_eligible(q, 32 / (q.bits == 3 ? 4 : q.bits))) {
         int rc = run_rowwave(q, s);
@@ -296,7 +338,11 @@ static int run_skinny(const Problem &q, hipStream_t s) {
 
 static int run_auto(const Problem &q, hipStream_t s) {
     if (q.M == 0) return 0;
-    if (q.M <= 2) return run_gemv(q, s);               // rowwave GEMV, one launch per row (generic kernel for act-order)
+    if (q.M <= 2) return run_gemv(q, s);               // rowwave GEMV (M = 2: both rows in one launch; generic kernel for act-order)
+    if (q.M <= 4) {                                    // small decode batch: rowwave with 4 x rows per weight pass
+        const int rc = run_rowwave_mr(q, s);
+        if (rc != GPTQ_E_VARIANT) return rc;
+    }
     if (q.M <= SKINNY_MAX_M) return run_skinny(q, s);  // falls back to the GEMV for act-order / 3-bit
     const int unit_k = (q.bits == 2) ? 64 : 32;
     if (!q.fused2 && fast_eligible(q, unit_k)) {

@@ -582,6 +582,165 @@ static int launch_rowwave_u(int u, const GemvParams &p, hipStream_t s) {
     return GPTQ_E_VARIANT;
 }
 
+// ---------------------------------------------------------------------------------------
+// rowwave for 2 <= M <= 4 (small decode batches): the same weight stream, each unpacked word multiplied with MR
+// rows of x.  The unpack (7 of the 11 VALU per word at M = 1) is shared, so MR = 2 costs 15 and MR = 4 costs 23
+// VALU per word: still under the stream at M = 2, about level with it at M = 4 -- and one launch instead of M
+// launches (M = 2) or the MFMA stream kernel's three-round-trip combine (M = 3, 4).  4-bit, trivial g_idx.
+// x rows are MR scalar streams (x + m * ldx); rows past M re-read row M-1 and are not written.
+// Combine words: ws[m * N + n].
+// ---------------------------------------------------------------------------------------
+template <int U, bool FUSED2, int MR>
+__global__ void __launch_bounds__(256) gemv_rowwave_mr_kernel(const uint32_t *__restrict__ qw0, const half_t *__restrict__ x, int ldx,
+                                                              const half_t *__restrict__ sc0, const int32_t *__restrict__ qz0, int N, int rows,
+                                                              int S, int gshift, const uint32_t *__restrict__ qw1,
+                                                              const half_t *__restrict__ sc1, const int32_t *__restrict__ qz1,
+                                                              half_t *__restrict__ y, int ldy, u64_t *__restrict__ ws,
+                                                              const half_t *__restrict__ bias, int M) {
+    constexpr int BITS = 4;
+    using UP = Unpack<BITS>;
+    constexpr int KPW = UP::KPW, NP = UP::NP, XW = KPW / 2;
+    constexpr int NS = FUSED2 ? 2 : 1;
+    typedef uint32_t xrow_t __attribute__((ext_vector_type(XW)));
+    __shared__ float red[MR][NS][4][256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = blockIdx.x, slice = blockIdx.y;
+    const uint32_t n0 = tile * 256 + lane * 4;
+    const uint32_t nc = n0 < (uint32_t)N ? n0 : 0;
+    const uint32_t nchunk = ((uint32_t)rows + 4 * U - 1) / (4 * U);
+    const uint32_t *qw[2] = {qw0, qw1};
+    const half_t *sc[2] = {sc0, sc1};
+    const int32_t *qz[2] = {qz0, qz1};
+    const half2_t ones = {(half_t)1.0f, (half_t)1.0f};
+    const uint32_t MSK = sreg_const(UP::MSK_C), MAG = vreg_const(UP::MAG_C);
+    const xrow_t *xq[MR];
+#pragma unroll
+    for (int m = 0; m < MR; m++) xq[m] = (const xrow_t *)(x + (size_t)(m < M ? m : M - 1) * ldx);
+
+    float yv[MR][NS][4];
+#pragma unroll
+    for (int m = 0; m < MR; m++)
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) yv[m][s][j] = 0.f;
+
+    for (uint32_t c = slice; c < nchunk; c += (uint32_t)S) {
+        const uint32_t row = c * (4 * U) + wave * U;
+        if (row >= (uint32_t)rows) continue;
+        u32x4 w[NS][U];
+        half4_t s4[NS];
+        uint32_t zw[NS];
+        const uint32_t g = gshift >= 0 ? (row >> gshift) : 0u;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                w[s][u] = __builtin_nontemporal_load((const u32x4 *)(qw[s] + (size_t)(row + u) * (uint32_t)N + nc));
+            s4[s] = *(const half4_t *)(sc[s] + (size_t)g * (uint32_t)N + nc);
+            zw[s] = (uint32_t)qz[s][(size_t)g * ((uint32_t)N / KPW) + nc / KPW];
+        }
+        xrow_t xr[MR][U];
+#pragma unroll
+        for (int m = 0; m < MR; m++)
+#pragma unroll
+            for (int u = 0; u < U; u++) xr[m][u] = xq[m][row + u];   // wave-uniform: scalar loads
+        __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is in flight before any math
+
+        float acc[MR][NS][4];
+        float xs[MR];
+#pragma unroll
+        for (int m = 0; m < MR; m++) {
+            xs[m] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[m][s][j] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            half2_t X[MR][NP];
+#pragma unroll
+            for (int m = 0; m < MR; m++)
+#pragma unroll
+                for (int q = 0; q < NP; q++) {
+                    const uint32_t a = xr[m][u][q / 2], b = xr[m][u][(q + NP) / 2];
+                    X[m][q] = as_half2((q & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16)));
+                    xs[m] = __builtin_amdgcn_fdot2(X[m][q], ones, xs[m], false);
+                }
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    half2_t t[NP];
+                    UP::pairs_rc(w[s][u][j], t, MSK, MAG);
+#pragma unroll
+                    for (int m = 0; m < MR; m++)
+#pragma unroll
+                        for (int q = 0; q < NP; q++) acc[m][s][j] = __builtin_amdgcn_fdot2(t[q], X[m][q], acc[m][s][j], false);
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float zf = (float)(((zw[s] >> (BITS * ((nc + j) % KPW))) & ((1u << BITS) - 1u)) + 1u) + UP::OFF;
+#pragma unroll
+                for (int m = 0; m < MR; m++) yv[m][s][j] += (float)s4[s][j] * (acc[m][s][j] - zf * xs[m]);
+            }
+    }
+
+#pragma unroll
+    for (int m = 0; m < MR; m++)
+#pragma unroll
+        for (int s = 0; s < NS; s++) *(float4_t *)&red[m][s][wave][4 * lane] = float4_t{yv[m][s][0], yv[m][s][1], yv[m][s][2], yv[m][s][3]};
+    __syncthreads();
+    const int t = threadIdx.x;
+    const uint32_t n = tile * 256 + t;
+    if (n >= (uint32_t)N) return;
+#pragma unroll
+    for (int m = 0; m < MR; m++) {
+        if (m >= M) break;
+        float t0 = red[m][0][0][t] + red[m][0][1][t] + red[m][0][2][t] + red[m][0][3][t], t1 = 0.f;
+        if constexpr (FUSED2) t1 = red[m][1][0][t] + red[m][1][1][t] + red[m][1][2][t] + red[m][1][3][t];
+        bool mine = true;
+        if (S > 1) {
+            u64_t *word = ws + (size_t)m * (uint32_t)N + n;
+            if constexpr (FUSED2) mine = splitk_add2(word, t0, t1, S, t0, t1);
+            else mine = splitk_add1(word, t0, S, t0);
+        }
+        if (mine) {
+            float v = t0;
+            if constexpr (FUSED2) v = t0 * (1.0f / (1.0f + __expf(-t0))) * t1;
+            half_t h = (half_t)v;
+            if (bias) h = (half_t)((float)h + (float)bias[n]);
+            y[(size_t)m * ldy + n] = h;
+        }
+    }
+}
+
+// 2 <= p.M <= 4, 4-bit: u = rows in flight per wave (MR = 2: 8 or 4; MR = 4: 4 or 2 -- x rows live in SGPRs)
+int gemv_rowwave_mr_dispatch(bool fused2, int u, const GemvParams &p, hipStream_t s) {
+    if (p.M < 2 || p.M > 4 || p.xperm || p.norm_w) return GPTQ_E_VARIANT;
+    const int rows = p.K / 8;
+    dim3 grid((p.N + 255) / 256, p.split_k), block(256);
+#define GPTQ_MR_LAUNCH(U_, F_, MR_)                                                                                                         \
+    hipLaunchKernelGGL((gemv_rowwave_mr_kernel<U_, F_, MR_>), grid, block, 0, s, p.qw[0], p.x, (int)p.ldx, p.sc[0], p.qz[0], p.N, rows,      \
+                       p.split_k, p.upg_shift, p.qw[1], p.sc[1], p.qz[1], p.y, (int)p.ldy, p.ws, p.bias, p.M)
+    if (p.M == 2) {
+        if (u == 8) { if (fused2) GPTQ_MR_LAUNCH(8, true, 2); else GPTQ_MR_LAUNCH(8, false, 2); }
+        else if (u == 4) { if (fused2) GPTQ_MR_LAUNCH(4, true, 2); else GPTQ_MR_LAUNCH(4, false, 2); }
+        else return GPTQ_E_VARIANT;
+    } else {
+        if (u == 4) { if (fused2) GPTQ_MR_LAUNCH(4, true, 4); else GPTQ_MR_LAUNCH(4, false, 4); }
+        else if (u == 2) { if (fused2) GPTQ_MR_LAUNCH(2, true, 4); else GPTQ_MR_LAUNCH(2, false, 4); }
+        else return GPTQ_E_VARIANT;
+    }
+#undef GPTQ_MR_LAUNCH
+    return (int)hipGetLastError();
+}
+
 // M == 1.  u = packed rows in flight per wave (8, 4 or 2; rows % u == 0 and a wave's u rows lie
 // in one quantisation group); p.split_k = workgroups per 256-column tile; p.upg_shift = log2 of
 // the packed rows per group or -1 (one group); p.ws zeroed workspace when split_k > 1.

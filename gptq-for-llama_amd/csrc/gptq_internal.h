@@ -14,9 +14,9 @@ constexpr int SKINNY_MAX_M = 64;      // rows served by the weight-streaming MFM
 constexpr int GEMV_NUM_VARIANTS = 3;   // packed rows in flight per wave: variant v -> U = 8 >> v
 // split-K workspace: one 64-bit word per output element ([M][N]), all-zero between launches
 constexpr size_t WS_BYTES = (size_t)SKINNY_MAX_M * 32768 * 8;
-// workspace layout: [0, 256 KiB) one u64 word per output column of the M = 1 GEMV combine | 4 KiB of per-tile
+// workspace layout: [0, 512 KiB) one u64 word per output element of the rowwave GEMV combine ([M <= 4][N]) | 4 KiB of per-tile
 // arrival tickets of the stream kernel (u32, zero between launches) | the stream kernel's partial tiles
-constexpr size_t SPLITK_TICKET_OFFSET = 32768 * 8;
+constexpr size_t SPLITK_TICKET_OFFSET = 65536 * 8;   // 512 KiB of combine words: [M <= 4][N] for the small-batch rowwave
 constexpr size_t SPLITK_PART_OFFSET = SPLITK_TICKET_OFFSET + 4096;
 
 struct GemvParams {
@@ -40,6 +40,7 @@ struct GemvParams {
 };
 
 int gemv_fast_dispatch(int bits, bool fused2, int u, const GemvParams &p, hipStream_t s);
+int gemv_rowwave_mr_dispatch(bool fused2, int u, const GemvParams &p, hipStream_t s);   // 2 <= M <= 4, 4-bit, one launch
 int gemv_generic_dispatch(int bits, bool fused2, int nl, const GemvParams &p, hipStream_t s);
 
 // skinny MFMA (weight streaming, M <= 64) and tiled MFMA GEMM (prefill)

@@ -82,9 +82,9 @@ void *gptq_set_debug_buffer(void *device_buffer);
 /*
  * y = x . deq(B) (+ bias)  -- reference matmul248() + matmul_248_kernel + the bias add in
  * QuantLinear.forward (quant/quant_linear.py:263-269, :72-137, :373-377).
- * Chooses the rowwave GEMV (M <= 2, one launch per row), the weight-streaming MFMA kernel (M <= 64)
- * or the tiled MFMA GEMM (prefill).  workspace: >= gptq_query(GPTQ_Q_WORKSPACE_BYTES) bytes, zero on first
- * use, one per device and per stream of execution (its first 260 KiB -- combine words and arrival tickets --
+ * Chooses the rowwave GEMV (M = 1; 2 <= M <= 4 at 4 bits: all rows in one launch), the weight-streaming MFMA
+ * kernel (M <= 64) or the tiled MFMA GEMM (prefill).  workspace: >= gptq_query(GPTQ_Q_WORKSPACE_BYTES) bytes, zero on first
+ * use, one per device and per stream of execution (its first 516 KiB -- combine words and arrival tickets --
  * are restored to zero by every launch, the rest is scratch); may be NULL, which disables the K split.
  */
 int gptq_matmul248_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales,

@@ -618,3 +618,33 @@ def test_chain_matches_oracle_op_by_op(K, I, gs):
     torch.cuda.synchronize()
     assert torch.equal(first[0], qkv) and torch.equal(first[1], act) and torch.equal(first[2], h)
     assert int(ch.ws[:262144].view(torch.int64).ne(0).sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M', [2, 3, 4])
+@pytest.mark.parametrize('gs,K,N', [(128, 4096, 4096), (128, 1024, 2816), (64, 512, 288), (-1, 256, 1024), (32, 256, 512)])
+def test_small_batch_rowwave(gs, K, N, M):
+    """2 <= M <= 4 at 4 bits: all rows in ONE rowwave launch (gemv_rowwave_mr_kernel), plain and fused gate/up, bias,
+    strided x rows; split-K words are [M][N] and must be back to zero."""
+    import torch
+    L = make_random_layer(4, gs, K, N, seed=M + K)
+    U = make_random_layer(4, gs, K, N, seed=M + K + 1)
+    rng = np.random.default_rng(M * K + N)
+    x = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float16)
+    check_forward(x, L, bias=bias)
+    check_forward(x, L, family='gemv')
+    # strided rows
+    wide = torch.zeros((M, K + 64), dtype=torch.float16, device='cuda:0')
+    wide[:, :K] = torch.from_numpy(x).cuda()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to('cuda:0')
+    y = QL.matmul248(wide[:, :K], dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15)
+    assert rel_err(y.cpu().numpy(), oracle_forward(x, L)) < TOL
+    gate = tuple(dev(L[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(U[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, gs if gs != -1 else K)
+    ref = oracle.fused_mlp(x, (L['qweight'], L['scales'], L['qzeros'], L['g_idx']), (U['qweight'], U['scales'], U['qzeros'], U['g_idx']), 4)
+    assert rel_err(c.cpu().numpy(), ref) < TOL
+    ws = _native.workspace(torch.device('cuda:0'))
+    torch.cuda.synchronize()
+    assert int(ws[:4 * 12288 * 8].view(torch.int64).ne(0).sum()) == 0

@@ -38,6 +38,7 @@ struct GemmParams {
     const half_t *sc;
     const int32_t *qz;
     const half_t *bias;
+    int silu_gate;  // 1: c holds gate = x.Wg; store c = silu(gate) * acc instead (fused gate/up, reference fused_mlp.py:160-168)
     half_t *c;
     int64_t ldc;
     int M, K, N, groupsize;
@@ -120,6 +121,14 @@ GPTQ_DEV void gemm_epilogue_t(const float16_t (&acc)[TN][4], char *smem, int wav
                 const half8_t b = *(const half8_t *)(p.bias + ncol);
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = (half_t)((float)v[e] + (float)b[e]);
+            }
+            if (p.silu_gate) {   // in place: this thread is the only one that touches these 8 outputs
+                const half8_t g = *(const half8_t *)(p.c + (size_t)m * p.ldc + ncol);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float gf = (float)g[e];
+                    v[e] = (half_t)(gf * (1.0f / (1.0f + __expf(-gf))) * (float)v[e]);
+                }
             }
             *(half8_t *)(p.c + (size_t)m * p.ldc + ncol) = v;
         }
@@ -538,19 +547,22 @@ int gemm_set_version(int v) {
 // Eligibility: bits in {4, 8}, trivial g_idx (checked by the caller), K % 64 == 0, groupsize % 32 == 0,
 // N % 8 == 0 (always: N % 32 == 0), rows 16-byte aligned.  Everything else -> GPTQ_E_VARIANT and
 // the caller falls back to the weight-streaming kernel.
-int gemm_dispatch(int bits, bool fused2, const GemvParams &q, hipStream_t s) {
+// set: which weight set of q to multiply with (0, or 1 = the "up" set of a fused gate/up problem);
+// silu_gate: the output buffer already holds gate = x.W0 and receives silu(gate) * (x.W_set) in place.
+int gemm_dispatch(int bits, int set, bool silu_gate, const GemvParams &q, hipStream_t s) {
     // q.dbg: development stamps (gptq_set_debug_buffer)
-    if (fused2) return GPTQ_E_VARIANT;
+    if (set < 0 || set > 1 || (silu_gate && q.bias)) return GPTQ_E_VARIANT;
     if (bits != 4 && bits != 8) return GPTQ_E_VARIANT;
     if (q.K % GK != 0 || q.groupsize % 32 != 0 || q.ldx % 8 != 0 || q.ldy % 8 != 0) return GPTQ_E_VARIANT;
     if (((uintptr_t)q.y % 16) != 0 || (q.bias && ((uintptr_t)q.bias % 16) != 0)) return GPTQ_E_VARIANT;
     GemmParams p;
     p.a = q.x;
     p.lda = q.ldx;
-    p.qw = q.qw[0];
-    p.sc = q.sc[0];
-    p.qz = q.qz[0];
+    p.qw = q.qw[set];
+    p.sc = q.sc[set];
+    p.qz = q.qz[set];
     p.bias = q.bias;
+    p.silu_gate = silu_gate ? 1 : 0;
     p.c = q.y;
     p.ldc = q.ldy;
     p.M = q.M;

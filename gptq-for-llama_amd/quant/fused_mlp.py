@@ -21,13 +21,16 @@ def fused_gate_up(x, gate, up, bits, groupsize):
     for (qw, sc, qz, gi) in (gate, up):
         gis.append(None if (gi is None or g_idx_is_trivial(gi, K, groupsize)) else _int32c(gi[:K]))
     if M > PREFILL_SPLIT_M and all(gi is None for gi in gis) and bits in (4, 8):
-        # prefill: two MFMA-tile GEMMs + the SiLU*mul epilogue in fp32 (the one-launch fused kernel only
-        # exists for the weight-streaming regime, M <= 64)
-        from .quant_linear import matmul248
-        g = matmul248(x2, gate[0], gate[1], gate[2], None, bits, 2**bits - 1)
-        u = matmul248(x2, up[0], up[1], up[2], None, bits, 2**bits - 1)
-        gf = g.float()
-        return (gf * torch.sigmoid(gf) * u.float()).half()
+        from .quant_linear import _mid_m, matmul248
+        if _mid_m(M, N):
+            # a prompt of tens to a few thousand tokens: too few 256x256 tiles to fill the GPU -> both products through the
+            # dequantise-once + dense GEMM route of matmul248, SiLU*mul in fp32 (small tensors)
+            g = matmul248(x2, gate[0], gate[1], gate[2], None, bits, 2**bits - 1)
+            u = matmul248(x2, up[0], up[1], up[2], None, bits, 2**bits - 1)
+            gf = g.float()
+            return (gf * torch.sigmoid(gf) * u.float()).half()
+        # large prefill: gptq_fused_mlp_f16 runs two MFMA-tile GEMMs, the second applies silu(gate) * up in place in its
+        # epilogue -- no fp32 intermediates, no extra pass over the [M, N] activations (falls through to the call below)
     with torch.cuda.device(x.device):
         c = torch.empty((M, N), device=x.device, dtype=torch.float16)
         if M:

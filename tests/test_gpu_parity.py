@@ -648,3 +648,29 @@ def test_small_batch_rowwave(gs, K, N, M):
     ws = _native.workspace(torch.device('cuda:0'))
     torch.cuda.synchronize()
     assert int(ws[:4 * 12288 * 8].view(torch.int64).ne(0).sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('bits,gs,M,K,N', [(4, 128, 700, 1024, 768), (8, 64, 300, 512, 288), (4, 64, 3300, 256, 4096)])
+def test_fused_mlp_prefill_in_place_epilogue(bits, gs, M, K, N):
+    """M > 64 through gptq_fused_mlp_f16: two MFMA-tile GEMMs, the second writes silu(gate) * up over gate in its
+    epilogue (ragged M / N tiles; the last case also goes that way from Python: enough tiles to fill the GPU)."""
+    import torch
+    A = make_random_layer(bits, gs, K, N, seed=M)
+    B = make_random_layer(bits, gs, K, N, seed=M + 1)
+    x = (np.random.default_rng(M).standard_normal((M, K)) * 0.5).astype(np.float16)
+    ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits)
+    dx = dev(x)
+    a = [dev(A[k]) for k in ('qweight', 'scales', 'qzeros')]
+    b = [dev(B[k]) for k in ('qweight', 'scales', 'qzeros')]
+    c = torch.full((M, N), float('nan'), dtype=torch.float16, device='cuda:0')
+    ws = _native.workspace(torch.device('cuda:0'))
+    rc = _native.lib().gptq_fused_mlp_f16(dx.data_ptr(), K, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), None, b[0].data_ptr(), b[1].data_ptr(),
+                                          b[2].data_ptr(), None, c.data_ptr(), N, M, K, N, bits, gs, ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert rel_err(c.cpu().numpy(), ref) < 2e-3      # gate and up are rounded to fp16 before SiLU * mul on this path
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c2 = quant.fused_mlp.fused_gate_up(dx, gate, up, bits, gs)
+    assert rel_err(c2.cpu().numpy(), ref) < 2e-3

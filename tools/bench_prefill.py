@@ -51,3 +51,18 @@ for K, N in [(4096, 4096), (4096, 12288), (4096, 11008), (11008, 4096)]:
     print(json.dumps(rec)); out.append(rec)
     del x, y, w
     torch.cuda.empty_cache()
+
+# fused gate/up + SiLU at prefill size (quant.fused_mlp.fused_gate_up -> gptq_fused_mlp_f16: two tile GEMMs, in-place epilogue)
+from quant import fused_mlp as FM
+K, N = 4096, 11008
+wg, wu = PackedSet(K, N, dev, gen), PackedSet(K, N, dev, gen)
+x = torch.randn((a.m, K), device=dev, generator=gen).half()
+gi = (torch.arange(K, device=dev) // GS).to(torch.int32)
+f = lambda: FM.fused_gate_up(x, (wg.qweight, wg.scales, wg.qzeros, gi), (wu.qweight, wu.scales, wu.qzeros, gi), BITS, GS)
+y = f(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.reps): y = f()
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.reps
+print(json.dumps({'fused_gate_up_silu': '2x%dx%d' % (K, N), 'M': a.m, 'ms': round(ms, 3), 'TFLOPs': round(4.0 * a.m * N * K / ms / 1e9, 1)}))

@@ -364,6 +364,64 @@ static float time_graph_chains(launch_fn fn, P base, const std::vector<WSet> &se
     return ms * 1e3f / (reps * sets.size());
 }
 
+// ------------------------------------------------------------------------------------------
+// L2 prefetch of the NEXT launch's weights by a concurrent kernel on a forked graph branch: same grid and the same
+// block -> (tile, slice) -> address mapping as k_rowwave, so block b (XCD b % 8) pulls exactly the lines block b of
+// the next GEMV will read into the L2 of that XCD.  Cached (not nt) loads, results discarded.  `limit` = chunks per
+// slice to prefetch (L2 is 4 MiB per XCD).
+template <int U>
+__global__ void __launch_bounds__(256) k_prefetch(const P p, int limit) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x % p.ntile, slice = blockIdx.x / p.ntile;
+    const int N = p.N;
+    const int n0 = tile * 256 + lane * 4;
+    uint32_t xo = 0;
+    int done = 0;
+    for (int c = slice; c < p.nchunk && done < limit; c += p.S, done++) {
+        const int row = c * (4 * U) + wave * U;
+        u32x4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) w[u] = *(const u32x4 *)(p.qw + (size_t)(row + u) * N + n0);
+#pragma unroll
+        for (int u = 0; u < U; u++) xo ^= w[u][0] ^ w[u][1] ^ w[u][2] ^ w[u][3];
+    }
+    if (xo == 0x9e3779b9u && p.part) p.part[blockIdx.x] = 1.f;
+}
+
+// G_0 -> G_1 -> ... on the main stream; P_i (prefetch of set i+1) on a side stream, released together with G_i
+template <int U>
+static float time_graph_prefetch(launch_fn fn, P base, const std::vector<WSet> &sets, hipStream_t s, int reps, int limit) {
+    static hipStream_t side = nullptr;
+    if (!side) CK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    hipGraph_t g; hipGraphExec_t ge;
+    std::vector<hipEvent_t> ev(sets.size());
+    for (auto &e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t join; CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    for (size_t i = 0; i < sets.size(); i++) {
+        CK(hipEventRecord(ev[i], s));                      // G_{i-1} has finished
+        CK(hipStreamWaitEvent(side, ev[i], 0));
+        if (i + 1 < sets.size()) {
+            P q = base; q.qw = sets[i + 1].qw;
+            hipLaunchKernelGGL((k_prefetch<U>), dim3(q.ntile * q.S), dim3(256), 0, side, q, limit);
+        }
+        P p = base; p.qw = sets[i].qw; p.sc = sets[i].sc; p.qz = sets[i].qz;
+        fn(p, s);
+    }
+    CK(hipEventRecord(join, side)); CK(hipStreamWaitEvent(s, join, 0));
+    CK(hipStreamEndCapture(s, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; i++) CK(hipGraphLaunch(ge, s));
+    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    return ms * 1e3f / (reps * sets.size());
+}
+
 int main(int argc, char **argv) {
     hipStream_t s; CK(hipStreamCreate(&s));
     int shapes[][2] = {{4096, 4096}, {4096, 12288}, {11008, 4096}, {4096, 11008}};
@@ -468,6 +526,17 @@ int main(int argc, char **argv) {
             for (int nch = 1; nch <= 4; nch++) {
                 float t = time_graph_chains(launch_rowwave<U, 0>, p, sets, s, 5, nch);
                 printf("  rowwave U8 S%d on %d parallel graph chain(s): %6.2f us per launch  %5.0f GB/s\n", p.S, nch, t, bytes / t / 1e3);
+            }
+        }
+        if (N % 256 == 0 && rows % 32 == 0 && getenv("LAB_PREFETCH")) {
+            constexpr int U = 8;
+            P p = base; p.nchunk = rows / 32; p.S = p.nchunk < 16 ? p.nchunk : 16;
+            if (p.ntile * p.S > 1024) p.S = 1024 / p.ntile;
+            const float t0 = time_graph(launch_rowwave<U, 0>, p, sets, s, 5);
+            printf("  rowwave U8 S%d: plain chain %6.2f us  %5.0f GB/s\n", p.S, t0, bytes / t0 / 1e3);
+            for (int limit : {1, 2, 100}) {
+                const float t = time_graph_prefetch<U>(launch_rowwave<U, 0>, p, sets, s, 5, limit);
+                printf("  rowwave U8 S%d + L2 prefetch branch (limit %3d chunks/slice): %6.2f us  %5.0f GB/s\n", p.S, limit, t, bytes / t / 1e3);
             }
         }
         if (N % 256 == 0 && rows % 32 == 0) {

@@ -365,6 +365,15 @@ def test_llama7b_shapes_vs_oracle(K, N):
     assert rel_err(y, ye) <= rel_err(ref, ye) + 5e-4
 
 
+# the other LLaMA sizes (13B / 30B / 65B: BASELINE config 5 shapes), decode batch 1 and 3
+@pytest.mark.parametrize('M', [1, 3])
+@pytest.mark.parametrize('K,N', [(5120, 13824), (13824, 5120), (6656, 17920), (17920, 6656), (8192, 8192), (8192, 22016), (22016, 8192)])
+def test_larger_llama_shapes_vs_oracle(K, N, M):
+    L = make_random_layer(4, 128, K, N, seed=K + N)
+    x = (np.random.default_rng(M).standard_normal((M, K)) * 0.5).astype(np.float16)
+    check_forward(x, L)
+
+
 @pytest.mark.parametrize('split_k', [1, 4, 16])
 def test_fused_mlp_split_k(split_k):
     K, N = 1024, 512

@@ -130,6 +130,57 @@ class DecodeLinears:
         return out
 
 
+def larger_model_shapes(dev, reps=5):
+    """side leg (reported only): the same two kernels on LLaMA-65B-shaped layers (BASELINE config 5 shapes on ONE GPU),
+    cold weights (rotation over > 256 MiB of distinct sets inside one hipGraph).  Shows how the fixed cost per launch
+    amortises: per launch ~ 4 us + bytes / 6.9 TB/s on both model sizes."""
+    from quant import _native
+    lib, ws = _native.lib(), _native.workspace(torch.device(dev))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    H65, I65 = 8192, 22016
+    out = {}
+    for name, K, N, fused in [('qkv_8192x24576', H65, 3 * H65, False), ('o_8192x8192', H65, H65, False),
+                              ('gate_up_silu_2x8192x22016', H65, I65, True), ('down_22016x8192', I65, H65, False)]:
+        nb = alg_bytes(1, K, N, nsets=2 if fused else 1)
+        nsets = int(300e6 // nb) + 1
+        sets = [(PackedSet(K, N, dev, gen), PackedSet(K, N, dev, gen) if fused else None) for _ in range(nsets)]
+        x = torch.randn((1, K), device=dev, generator=gen).half()
+        y = torch.empty((1, N), dtype=torch.float16, device=dev)
+
+        def launch(i):
+            w, u = sets[i]
+            st = torch.cuda.current_stream().cuda_stream
+            if fused:
+                rc = lib.gptq_fused_mlp_f16(x.data_ptr(), K, w.qweight.data_ptr(), w.scales.data_ptr(), w.qzeros.data_ptr(), None,
+                                            u.qweight.data_ptr(), u.scales.data_ptr(), u.qzeros.data_ptr(), None, y.data_ptr(), N, 1, K, N,
+                                            BITS, GS, ws.data_ptr(), ws.numel(), st)
+            else:
+                rc = lib.gptq_matmul248_f16(x.data_ptr(), K, w.qweight.data_ptr(), w.scales.data_ptr(), w.qzeros.data_ptr(), None, None,
+                                            y.data_ptr(), N, 1, K, N, BITS, GS, ws.data_ptr(), ws.numel(), st)
+            _native.check(rc, name)
+        for i in range(nsets):
+            launch(i)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(nsets):
+                launch(i)
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (reps * nsets)
+        out[name] = {'us_per_launch': round(us, 3), 'GBps': round(nb / us / 1e3, 1), 'frac_of_8TBps': round(nb / us / 1e3 / HBM_PEAK_GBS, 4)}
+        del sets, g
+        torch.cuda.empty_cache()
+    return out
+
+
 def pmc_traffic():
     """HBM bytes per launch from the newest committed PMC pass (profiles/*/traffic.json, produced by
     tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` on this same command; counters cannot be
@@ -318,6 +369,10 @@ def main():
         # the side legs run at N = 1 only (the other ranks would sit in the final barrier meanwhile)
         if not args.no_per_shape and world == 1:
             out['per_shape'] = work.per_shape()
+            try:
+                out['per_shape_llama65b_reported_only'] = larger_model_shapes(dev)
+            except Exception as e:
+                out['per_shape_llama65b_reported_only'] = {'error': repr(e)[:200]}
         if not args.no_decode and world == 1:
             try:
                 out['decode'] = decode_tokens_per_s(dev)

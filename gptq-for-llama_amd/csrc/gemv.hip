@@ -524,7 +524,7 @@ static int launch_rowwave_xperm(const GemvParams &p, hipStream_t stream) {
 template <int BITS, int U, bool FUSED2>
 static int launch_rowwave(const GemvParams &p, hipStream_t stream) {
     if (p.xperm) {
-        if constexpr (BITS == 4 && !FUSED2) {
+        if constexpr (BITS == 4) {
             if (p.norm_w) return GPTQ_E_VARIANT;
             return launch_rowwave_xperm<BITS, U, FUSED2>(p, stream);
         } else {

@@ -40,9 +40,12 @@ def fill_random_quant_(layer, gen):
         layer.bias.zero_()
 
 
-def build_random_llama(dev='cuda:0', bits=4, groupsize=128, seed=0, fused=True, **overrides):
+def build_random_llama(dev='cuda:0', bits=4, groupsize=128, seed=0, fused=True, act_order=False, **overrides):
     """random-init LLaMA (7B shape by default) with every decoder linear replaced by a QuantLinear
-    holding random packed weights, then fused attention / norm / MLP like load_quant()."""
+    holding random packed weights, then fused attention / norm / MLP like load_quant().
+    act_order: every linear gets a non-trivial g_idx of the shape gptq.py:210-216 produces (exactly `groupsize`
+    members per group); linears that share their input (q/k/v, gate/up) share the permutation, as in a real
+    --act-order checkpoint (same input => same Hessian diagonal)."""
     from transformers import LlamaConfig, LlamaForCausalLM
     from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding
 
@@ -64,6 +67,19 @@ def build_random_llama(dev='cuda:0', bits=4, groupsize=128, seed=0, fused=True, 
         for _, m in model.named_modules():
             if isinstance(m, quant_linear.QuantLinear):
                 fill_random_quant_(m, gen)
+        if act_order:
+            for layer in model.model.layers:
+                K = layer.self_attn.q_proj.infeatures
+                gs = groupsize if groupsize != -1 else K
+
+                def random_g_idx(k):
+                    inv = torch.argsort(torch.randperm(k, device=dev, generator=gen))
+                    return (torch.arange(k, device=dev) // (groupsize if groupsize != -1 else k))[inv].to(torch.int32)
+                shared = random_g_idx(K)
+                for m in (layer.self_attn.q_proj, layer.self_attn.k_proj, layer.self_attn.v_proj, layer.mlp.gate_proj, layer.mlp.up_proj):
+                    m.g_idx.copy_(shared)
+                layer.self_attn.o_proj.g_idx.copy_(random_g_idx(layer.self_attn.o_proj.infeatures))
+                layer.mlp.down_proj.g_idx.copy_(random_g_idx(layer.mlp.down_proj.infeatures))
         for name, p in model.named_parameters():
             if p.dim() == 1:
                 p.fill_(1.0)                                  # RMSNorm weights
@@ -146,6 +162,9 @@ class DecodeEngine:
                 up=self._pack_raw(mlp.up_proj_qweight, mlp.up_proj_scales, mlp.up_proj_qzeros, mlp.up_proj_g_idx, mlp.bits,
                                   mlp.groupsize, mlp.infeatures, mlp.intermediate_size),
                 theta=float(attn.rope_theta)))
+            L = self.layers[-1]   # gate and up share their input, hence (normally) their act-order permutation: checked ONCE here
+            L['gate']['pair_sorted'] = (L['gate']['srt'] is not None and L['up']['srt'] is not None and
+                                        bool(torch.equal(L['gate']['srt'][1], L['up']['srt'][1])))
         H, I = self.hidden, cfg.intermediate_size
         f16 = dict(dtype=torch.float16, device=dev)
         self.ids = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -214,6 +233,16 @@ class DecodeEngine:
 
     def _norm_mlp(self, x, nw, g, u, c, s):
         ptr = self.native.ptr
+        if g.get('pair_sorted'):
+            # act-order MLP: gate and up share the permutation of their common input -> sorted fused kernel
+            self._norm(x, nw, self.h, s)
+            rc = self.lib.gptq_fused_mlp_sorted_f16(self.h.data_ptr(), g['K'], g['srt'][1].data_ptr(), g['srt'][0].data_ptr(),
+                                                    g['sc'].data_ptr(), g['qz'].data_ptr(), u['srt'][0].data_ptr(), u['sc'].data_ptr(),
+                                                    u['qz'].data_ptr(), c.data_ptr(), g['N'], 1, g['K'], g['N'], g['bits'], g['gs'],
+                                                    self.ws.data_ptr(), self.ws.numel(), s)
+            if rc != -6:
+                self.native.check(rc, 'gptq_fused_mlp_sorted_f16')
+                return
         if self.fuse_norm:
             rc = self.lib.gptq_rmsnorm_fused_mlp_f16(x.data_ptr(), nw.data_ptr(), self.eps, g['qw'].data_ptr(), g['sc'].data_ptr(),
                                                      g['qz'].data_ptr(), ptr(g['gi']), u['qw'].data_ptr(), u['sc'].data_ptr(),

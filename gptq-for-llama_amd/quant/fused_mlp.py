@@ -11,6 +11,21 @@ from .quant_linear import QuantLinear, _as_rows, _int32c, g_idx_is_trivial
 PREFILL_SPLIT_M = 64
 
 
+def _same_perm(a, b):
+    """a == b elementwise, decided once per tensor pair (the comparison synchronises: not inside a hipGraph capture)."""
+    if a is b:
+        return True
+    memo = getattr(a, '_gptq_same_as', None)
+    key = (id(b), a._version, b._version)
+    if memo is None or memo[0] != key:
+        memo = (key, bool(torch.equal(a, b)))
+        try:
+            a._gptq_same_as = memo
+        except Exception:  # pragma: no cover
+            pass
+    return memo[1]
+
+
 def fused_gate_up(x, gate, up, bits, groupsize):
     """c = silu(x . deq(gate)) * (x . deq(up)); gate/up = (qweight, scales, qzeros, g_idx)."""
     _native.require_device(x, 'fused_gate_up')
@@ -20,6 +35,23 @@ def fused_gate_up(x, gate, up, bits, groupsize):
     gis = []
     for (qw, sc, qz, gi) in (gate, up):
         gis.append(None if (gi is None or g_idx_is_trivial(gi, K, groupsize)) else _int32c(gi[:K]))
+    if M == 1 and bits == 4 and all(gi is not None for gi in gis):
+        # act-order MLP at decode: gate and up share their input, hence their act-order permutation -> one x gather,
+        # two group-sorted weight copies (cached on the tensors), the trivial-g_idx fused kernel
+        from .quant_linear import act_order_sorted
+        sg = act_order_sorted(_int32c(gate[0]), gis[0], K, groupsize, bits)
+        su = act_order_sorted(_int32c(up[0]), gis[1], K, groupsize, bits)
+        if sg is not None and su is not None and _same_perm(sg[1], su[1]):
+            with torch.cuda.device(x.device):
+                c = torch.empty((M, N), device=x.device, dtype=torch.float16)
+                ws = _native.workspace(x.device)
+                rc = _native.lib().gptq_fused_mlp_sorted_f16(x2.data_ptr(), K, sg[1].data_ptr(), sg[0].data_ptr(), gate[1].data_ptr(),
+                                                             gate[2].data_ptr(), su[0].data_ptr(), up[1].data_ptr(), up[2].data_ptr(),
+                                                             c.data_ptr(), N, M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
+                                                             _native.stream_ptr(x.device))
+            if rc != -6:   # GPTQ_E_VARIANT: shape not served by the rowwave kernel -> generic path below
+                _native.check(rc, 'gptq_fused_mlp_sorted_f16')
+                return c
     if M > PREFILL_SPLIT_M and all(gi is None for gi in gis) and bits in (4, 8):
         from .quant_linear import _mid_m, matmul248
         if _mid_m(M, N):

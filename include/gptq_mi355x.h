@@ -195,6 +195,13 @@ int gptq_matmul248_sorted_f16(const void *x, int64_t ldx, const int32_t *perm, c
                               const void *scales, const int32_t *qzeros, const void *bias, void *y,
                               int64_t ldy, int M, int K, int N, int bits, int groupsize, void *workspace,
                               size_t workspace_bytes, gptq_stream_t stream);
+/* The fused gate/up + SiLU of an act-order MLP: gate_proj and up_proj see the same input, hence the same Hessian
+ * diagonal and the same act-order permutation (as q/k/v do, fused_attn.py:177-188) -- one perm, two re-sorted weight
+ * sets, c = silu(x[perm].Wg') * (x[perm].Wu').  Same validity rules as gptq_matmul248_sorted_f16. */
+int gptq_fused_mlp_sorted_f16(const void *x, int64_t ldx, const int32_t *perm, const int32_t *qweight_gate_sorted,
+                              const void *scales_gate, const int32_t *qzeros_gate, const int32_t *qweight_up_sorted,
+                              const void *scales_up, const int32_t *qzeros_up, void *c, int64_t ldc, int M, int K, int N,
+                              int bits, int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream);
 
 /*
  * [RMSNorm -> QuantLinear] and [RMSNorm -> fused gate/up] of a decoder layer as ONE launch, M == 1

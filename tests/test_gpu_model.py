@@ -198,6 +198,21 @@ def test_decode_engine_matches_hf_decoder(graph, fuse):
     assert r['tokens_per_s'] > 0
 
 
+def test_decode_engine_act_order_checkpoint():
+    """an --act-order model (BASELINE config 4 flavour): q/k/v and gate/up share their permutations, every linear of
+    the engine takes the group-sorted fast path (incl. the fused gate/up), logits match the HF decoder running the
+    same drop-in modules."""
+    q = D.build_random_llama(DEV, seed=4, act_order=True, **HD128)
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(7)
+    ids = torch.randint(0, HD128['vocab_size'], (1, 8), device=DEV, generator=gen)
+    expect = run_steps(q, ids, 1)
+    eng = D.DecodeEngine(q, t_max=64).capture()
+    assert all(L['gate'].get('pair_sorted') and L['qkv']['srt'] is not None and L['o']['srt'] is not None for L in eng.layers)
+    got = np.stack([eng.decode(ids[0, i]).float().cpu().numpy()[0] for i in range(ids.shape[1])])[:, None, :]
+    assert np.abs(got - expect).max() / np.abs(expect).max() < 2e-2
+
+
 # ---------------------------------------------------------------------------------------
 # GPTQ solver on the GPU (gptq-for-llama_amd/gptq.py + csrc/gptq_solver.hip) vs the reference's own results
 # (tests/golden/gptq_*.npz) and vs the CPU restatement on a larger layer

@@ -683,3 +683,25 @@ def test_fused_mlp_prefill_in_place_epilogue(bits, gs, M, K, N):
     up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
     c2 = quant.fused_mlp.fused_gate_up(dx, gate, up, bits, gs)
     assert rel_err(c2.cpu().numpy(), ref) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('gs,K,N', [(128, 4096, 11008), (64, 1024, 2816), (32, 512, 288)])
+def test_act_order_fused_mlp_sorted(gs, K, N):
+    """act-order gate/up at decode: one shared permutation (same input => same Hessian diagonal), two group-sorted
+    weight copies, the trivial-g_idx fused kernel; against the fused oracle on the checkpoint layout.  A pair with
+    DIFFERENT permutations must still be right (generic kernel)."""
+    from util import act_order_g_idx
+    rng = np.random.default_rng(K + N)
+    A = make_random_layer(4, gs, K, N, act_order=True, seed=5)
+    B = make_random_layer(4, gs, K, N, act_order=True, seed=6)
+    B_same = dict(B)
+    B_same['g_idx'] = A['g_idx'].copy()                       # what a real checkpoint has
+    x = (rng.standard_normal((1, K)) * 0.5).astype(np.float16)
+    for up_layer in (B_same, B):
+        gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+        up = tuple(dev(up_layer[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+        c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, gs)
+        ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']),
+                               (up_layer['qweight'], up_layer['scales'], up_layer['qzeros'], up_layer['g_idx']), 4)
+        assert rel_err(c.cpu().numpy(), ref) < TOL

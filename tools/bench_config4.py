@@ -50,3 +50,31 @@ for label, bits, gs, act in [('3-bit no-group', 3, -1, False), ('4-bit g128 act-
         print(json.dumps({'config': label, 'shape': '%dx%d' % (K, N), 'us': round(us, 2), 'GBps': round(nb / us / 1e3, 1), 'frac_of_8TBps': round(nb / us / 8e6, 4)}))
         del sets, g
         torch.cuda.empty_cache()
+
+# fused gate/up + SiLU of an act-order MLP (gate and up share the permutation): group-sorted fast path vs the generic g_idx kernel
+from quant import fused_mlp as FM
+K, N = 4096, 11008
+nb = 2 * (bytes_model(4, 128, K, N, True) - 2 * K - 2 * N) + 2 * K + 2 * N
+nsets = int(300e6 // nb) + 1
+gi = (torch.arange(K, device=dev) // 128).to(torch.int32)[torch.argsort(torch.randperm(K, device=dev, generator=gen))].contiguous()
+sets = [(make(4, 128, K, N, False), make(4, 128, K, N, False)) for _ in range(nsets)]
+x = torch.randn((1, K), device=dev, generator=gen).half()
+for label, flag in [('4-bit g128 act-order fused gate/up, sorted fast path', True), ('4-bit g128 act-order fused gate/up, generic kernel', False)]:
+    QL.ACT_ORDER_SORT = flag
+    def run(i):
+        (a, b) = sets[i]
+        return FM.fused_gate_up(x, (a[0], a[1], a[2], gi), (b[0], b[1], b[2], gi), 4, 128)
+    for i in range(nsets): run(i)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(nsets): run(i)
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (5 * nsets)
+    print(json.dumps({'config': label, 'shape': '2x%dx%d' % (K, N), 'us': round(us, 2), 'GBps': round(nb / us / 1e3, 1), 'frac_of_8TBps': round(nb / us / 8e6, 4)}))
+    del g
+QL.ACT_ORDER_SORT = True

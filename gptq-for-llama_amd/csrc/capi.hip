@@ -163,7 +163,7 @@ static int run_rowwave(const Problem &q, hipStream_t s) {
         if (!u) return GPTQ_E_VARIANT;
     }
     if (q.norm_w && (u != 8 || q.bits != 4 || q.M != 1)) return GPTQ_E_VARIANT;
-    if (q.xperm && (q.bits != 4 || q.norm_w)) return GPTQ_E_VARIANT;
+    if (q.xperm && q.bits != 4) return GPTQ_E_VARIANT;
     const int ntile = (q.N + 255) / 256;
     const int nchunk = (rows + 4 * u - 1) / (4 * u);
     const int split_max = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
@@ -599,6 +599,28 @@ int gptq_fused_mlp_sorted_f16(const void *x, int64_t ldx, const int32_t *perm, c
     if (int rc = validate(q)) return rc;
     if (!fast_eligible(q, 32 / (bits == 3 ? 4 : bits))) return GPTQ_E_VARIANT;
     return run_rowwave(q, (hipStream_t)stream);   // one launch per row of x
+}
+
+int gptq_rmsnorm_sorted_f16(const void *x, const void *norm_weight, float eps, const int32_t *perm, const int32_t *qweight_sorted,
+                            const void *scales, const int32_t *qzeros, const int32_t *qweight_up_sorted, const void *scales_up,
+                            const int32_t *qzeros_up, const void *bias, void *y, int K, int N, int bits, int groupsize, void *workspace,
+                            size_t workspace_bytes, gptq_stream_t stream) {
+    if (!norm_weight || !perm) return GPTQ_E_NULL;
+    Problem q = make_problem(x, K, qweight_sorted, scales, qzeros, nullptr, bias, y, N, 1, K, N, bits, groupsize, workspace, workspace_bytes);
+    if (qweight_up_sorted) {
+        if (bias) return GPTQ_E_VARIANT;
+        q.fused2 = true;
+        q.qw[1] = qweight_up_sorted;
+        q.sc[1] = scales_up;
+        q.qz[1] = qzeros_up;
+        q.gi[1] = nullptr;
+    }
+    q.xperm = perm;
+    q.norm_w = norm_weight;
+    q.norm_eps = eps;
+    if (int rc = validate(q)) return rc;
+    if (!aligned(norm_weight, 2) || !fast_eligible(q, 32 / (bits == 3 ? 4 : bits))) return GPTQ_E_VARIANT;
+    return run_rowwave(q, (hipStream_t)stream);
 }
 
 int gptq_decode_rope_kv_f16(void *qkv, const int64_t *position, void *k_cache, void *v_cache, int heads, int head_dim, int t_max,

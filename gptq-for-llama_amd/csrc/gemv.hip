@@ -115,10 +115,13 @@ __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
                 pk[i] = xperm[(size_t)row * KPW + (e < U * KPW ? e : 0)];
             }
 #pragma unroll
-            for (int i = 0; i < XE; i++) xe[i] = x[pk[i]];   // dependent gather, still ahead of the weights
+            for (int i = 0; i < XE; i++) {                   // dependent gather, still ahead of the weights
+                xe[i] = x[pk[i]];
+                if constexpr (NORM) nwe[i] = nw[pk[i]];       // NORM + XPERM: normalise the gathered values (sum(x^2) is order-free)
+            }
             __builtin_amdgcn_sched_barrier(0);               // (the scheduler would sink it behind them)
         }
-        if constexpr (NORM) {
+        if constexpr (NORM && !XPERM) {
 #pragma unroll
             for (int i = 0; i < XE; i++) {
                 const int e = lane + 64 * i;
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is in flight before any math
         if constexpr (DBG) st[2] = stamp_cycles(0);
-        if constexpr (XPERM) {
+        if constexpr (XPERM && !NORM) {
 #pragma unroll
             for (int i = 0; i < XE; i++) {
                 const int e = lane + 64 * i;
@@ -522,10 +525,24 @@ static int launch_rowwave_xperm(const GemvParams &p, hipStream_t stream) {
 }
 
 template <int BITS, int U, bool FUSED2>
+static int launch_rowwave_norm_xperm(const GemvParams &p, hipStream_t stream) {
+    constexpr int KPW = 32 / BITS;
+    const int rows = p.K / KPW;
+    dim3 grid((p.N + 255) / 256, p.split_k), block(256);
+    hipLaunchKernelGGL((gemv_rowwave_kernel<BITS, U, FUSED2, false, true, true>), grid, block, 0, stream, p.qw[0], p.x, p.sc[0], p.qz[0],
+                       p.N, rows, p.split_k, p.upg_shift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias, (u64_t *)nullptr, p.norm_w,
+                       p.norm_eps, p.xperm);
+    return (int)hipGetLastError();
+}
+
+template <int BITS, int U, bool FUSED2>
 static int launch_rowwave(const GemvParams &p, hipStream_t stream) {
     if (p.xperm) {
         if constexpr (BITS == 4) {
-            if (p.norm_w) return GPTQ_E_VARIANT;
+            if (p.norm_w) {
+                if constexpr (U == 8) return launch_rowwave_norm_xperm<BITS, U, FUSED2>(p, stream);
+                else return GPTQ_E_VARIANT;
+            }
             return launch_rowwave_xperm<BITS, U, FUSED2>(p, stream);
         } else {
             return GPTQ_E_VARIANT;

@@ -54,6 +54,8 @@ _SIGNATURES = {
                                   c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
     'gptq_fused_mlp_sorted_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
+    'gptq_rmsnorm_sorted_f16': [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
     'gptq_rmsnorm_matmul248_f16': [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
     'gptq_rmsnorm_fused_mlp_f16': [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

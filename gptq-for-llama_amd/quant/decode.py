@@ -221,6 +221,14 @@ class DecodeEngine:
     def _norm_gemv(self, x, nw, w, y, s):
         """y = QuantLinear(rmsnorm(x)): one launch when the fused kernel serves the shape, else two."""
         ptr = self.native.ptr
+        if self.fuse_norm and w['bias'] is None and w['srt'] is not None:      # act-order: norm + gather + GEMV in one launch
+            qs, perm = w['srt']
+            rc = self.lib.gptq_rmsnorm_sorted_f16(x.data_ptr(), nw.data_ptr(), self.eps, perm.data_ptr(), qs.data_ptr(), w['sc'].data_ptr(),
+                                                  w['qz'].data_ptr(), None, None, None, None, y.data_ptr(), w['K'], w['N'], w['bits'],
+                                                  w['gs'], self.ws.data_ptr(), self.ws.numel(), s)
+            if rc != -6:
+                self.native.check(rc, 'gptq_rmsnorm_sorted_f16')
+                return
         if self.fuse_norm and w['bias'] is None and w['srt'] is None:
             rc = self.lib.gptq_rmsnorm_matmul248_f16(x.data_ptr(), nw.data_ptr(), self.eps, w['qw'].data_ptr(), w['sc'].data_ptr(),
                                                      w['qz'].data_ptr(), ptr(w['gi']), None, y.data_ptr(), w['K'], w['N'], w['bits'],
@@ -233,6 +241,14 @@ class DecodeEngine:
 
     def _norm_mlp(self, x, nw, g, u, c, s):
         ptr = self.native.ptr
+        if g.get('pair_sorted') and self.fuse_norm:
+            rc = self.lib.gptq_rmsnorm_sorted_f16(x.data_ptr(), nw.data_ptr(), self.eps, g['srt'][1].data_ptr(), g['srt'][0].data_ptr(),
+                                                  g['sc'].data_ptr(), g['qz'].data_ptr(), u['srt'][0].data_ptr(), u['sc'].data_ptr(),
+                                                  u['qz'].data_ptr(), None, c.data_ptr(), g['K'], g['N'], g['bits'], g['gs'],
+                                                  self.ws.data_ptr(), self.ws.numel(), s)
+            if rc != -6:
+                self.native.check(rc, 'gptq_rmsnorm_sorted_f16')
+                return
         if g.get('pair_sorted'):
             # act-order MLP: gate and up share the permutation of their common input -> sorted fused kernel
             self._norm(x, nw, self.h, s)

@@ -202,6 +202,13 @@ int gptq_fused_mlp_sorted_f16(const void *x, int64_t ldx, const int32_t *perm, c
                               const void *scales_gate, const int32_t *qzeros_gate, const int32_t *qweight_up_sorted,
                               const void *scales_up, const int32_t *qzeros_up, void *c, int64_t ldc, int M, int K, int N,
                               int bits, int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream);
+/* [RMSNorm -> act-order QuantLinear] (qweight_up_sorted == NULL) or [RMSNorm -> act-order gate/up + SiLU] of one decode
+ * token in ONE launch: the kernel gathers x and the norm weight through perm and normalises what it gathered
+ * (sum(x^2) does not depend on the order).  M == 1, 4-bit, groups of >= 64. */
+int gptq_rmsnorm_sorted_f16(const void *x, const void *norm_weight, float eps, const int32_t *perm, const int32_t *qweight_sorted,
+                            const void *scales, const int32_t *qzeros, const int32_t *qweight_up_sorted, const void *scales_up,
+                            const int32_t *qzeros_up, const void *bias, void *y, int K, int N, int bits, int groupsize,
+                            void *workspace, size_t workspace_bytes, gptq_stream_t stream);
 
 /*
  * [RMSNorm -> QuantLinear] and [RMSNorm -> fused gate/up] of a decoder layer as ONE launch, M == 1

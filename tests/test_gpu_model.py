@@ -174,6 +174,46 @@ def test_rmsnorm_fused_into_gemv(fused):
     assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / np.abs(ref.astype(np.float64)).max() < tol
 
 
+@pytest.mark.parametrize('fused', [False, True])
+def test_rmsnorm_fused_into_act_order_gemv(fused):
+    """[RMSNorm -> act-order QuantLinear / gate-up+SiLU] in one launch (gptq_rmsnorm_sorted_f16: gather x and the norm
+    weight through the permutation, normalise the gathered values) against rmsnorm + matmul / fused_mlp of the oracle
+    on the checkpoint layout."""
+    from quant import _native, quant_linear as QL
+    from util import make_random_layer
+    lib = _native.lib()
+    K, N, gs = 4096, 1024, 128
+    rng = np.random.default_rng(12)
+    A, B = make_random_layer(4, gs, K, N, act_order=True, seed=1), make_random_layer(4, gs, K, N, act_order=True, seed=2)
+    B['g_idx'] = A['g_idx'].copy()
+    x = (rng.standard_normal((1, K)) * 3).astype(np.float16)
+    nw = (1 + 0.2 * rng.standard_normal(K)).astype(np.float16)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    xd, nwd = d(x), d(nw)
+    ws = _native.workspace(torch.device(DEV))
+    s = torch.cuda.current_stream().cuda_stream
+    y = torch.empty((1, N), dtype=torch.float16, device=DEV)
+    a = [d(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx')]
+    b = [d(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx')]
+    sa, sb = QL.act_order_sorted(a[0], a[3], K, gs, 4), QL.act_order_sorted(b[0], b[3], K, gs, 4)
+    assert sa is not None and sb is not None and torch.equal(sa[1], sb[1])
+    xn = oracle.rmsnorm(x, nw, 1e-6)
+    if fused:
+        rc = lib.gptq_rmsnorm_sorted_f16(xd.data_ptr(), nwd.data_ptr(), 1e-6, sa[1].data_ptr(), sa[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                         sb[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), None, y.data_ptr(), K, N, 4, gs, ws.data_ptr(),
+                                         ws.numel(), s)
+        ref = oracle.fused_mlp(xn, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), 4)
+        tol = 2e-3
+    else:
+        rc = lib.gptq_rmsnorm_sorted_f16(xd.data_ptr(), nwd.data_ptr(), 1e-6, sa[1].data_ptr(), sa[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(),
+                                         None, None, None, None, y.data_ptr(), K, N, 4, gs, ws.data_ptr(), ws.numel(), s)
+        ref = oracle.matmul248(xn, A['qweight'], A['scales'], A['qzeros'], A['g_idx'], 4)
+        tol = 1e-3
+    _native.check(rc, 'gptq_rmsnorm_sorted_f16')
+    got = y.cpu().numpy()
+    assert np.abs(got.astype(np.float64) - ref.astype(np.float64)).max() / np.abs(ref.astype(np.float64)).max() < tol
+
+
 @pytest.mark.parametrize('fuse', [False, True])
 @pytest.mark.parametrize('graph', [False, True])
 def test_decode_engine_matches_hf_decoder(graph, fuse):

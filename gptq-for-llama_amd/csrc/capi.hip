@@ -92,7 +92,7 @@ static int ilog2_exact(int v) {
 // per wave and S = workgroups per 256-column tile (DESIGN.md "dispatch").
 // 3-bit rowwave: units are 32-k blocks (3 packed rows each)
 static int run_rowwave3(const Problem &q, hipStream_t s) {
-    if (q.fused2 || q.norm_w || q.xperm) return GPTQ_E_VARIANT;
+    if (q.norm_w || q.xperm) return GPTQ_E_VARIANT;
     const int nblocks = q.K / 32;
     const int G = n_groups(q.K, q.groupsize);
     int gshift = -1;
@@ -119,7 +119,7 @@ static int run_rowwave3(const Problem &q, hipStream_t s) {
     const int fs = g_force_split_k.load();
     if (fs >= 1) split_k = fs;
     if (split_k > nchunk) split_k = nchunk;
-    if (split_k > SPLITK_MAX_SINGLE) split_k = SPLITK_MAX_SINGLE;
+    if (split_k > (q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE)) split_k = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
     // the per-column combine words live in the first SPLITK_TICKET_OFFSET bytes of the workspace (the rest belongs
     // to the stream kernel's tickets / partial tiles and is not zero): wider layers run without a K split
     const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)q.N * 8 && (size_t)q.N * 8 <= SPLITK_TICKET_OFFSET;
@@ -132,7 +132,7 @@ static int run_rowwave3(const Problem &q, hipStream_t s) {
         fill_params(q, m, 1, p);
         p.split_k = split_k;
         p.upg_shift = gshift;
-        int rc = gemv_fast_dispatch(3, false, u, p, s);
+        int rc = gemv_fast_dispatch(3, q.fused2, u, p, s);
         if (rc) return rc;
     }
     return 0;
@@ -262,7 +262,7 @@ static int run_gemv(const Problem &q, hipStream_t s) {
         const int rc = run_rowwave_mr(q, s);
         if (rc != GPTQ_E_VARIANT) return rc;
     }
-    const bool eligible3 = q.bits == 3 && !q.fused2 && !q.gi[0] && q.M <= GEMV_MAX_M;   // one launch per row
+    const bool eligible3 = q.bits == 3 && !q.gi[0] && !(q.fused2 && q.gi[1]) && q.M <= GEMV_MAX_M;   // one launch per row
     if (eligible3 || fast_eligible(q, 32 / (q.bits == 3 ? 4 : q.bits))) {
         int rc = run_rowwave(q, s);
         if (rc != GPTQ_E_VARIANT || g_force_variant.load() >= 0) return rc;

@@ -280,13 +280,15 @@ __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
 // The 1024 offset is removed per BLOCK (a - 1024 * sum x) before the group accumulator so that a
 // single group over all of K (3-bit "no-group" checkpoints) keeps fp32 accuracy.
 // ---------------------------------------------------------------------------------------
-template <int UB>
-__global__ void __launch_bounds__(256) gemv_rowwave3_kernel(const uint32_t *__restrict__ qw, const half_t *__restrict__ x,
-                                                            const half_t *__restrict__ sc, const int32_t *__restrict__ qz, int N,
-                                                            int nblocks, int S, int gshift, half_t *__restrict__ y,
-                                                            u64_t *__restrict__ ws, const half_t *__restrict__ bias) {
+template <int UB, bool FUSED2>
+__global__ void __launch_bounds__(256) gemv_rowwave3_kernel(const uint32_t *__restrict__ qw0, const half_t *__restrict__ x,
+                                                            const half_t *__restrict__ sc0, const int32_t *__restrict__ qz0, int N,
+                                                            int nblocks, int S, int gshift, const uint32_t *__restrict__ qw1,
+                                                            const half_t *__restrict__ sc1, const int32_t *__restrict__ qz1,
+                                                            half_t *__restrict__ y, u64_t *__restrict__ ws, const half_t *__restrict__ bias) {
     typedef uint32_t x16_t __attribute__((ext_vector_type(16)));
-    __shared__ float red[4][256];
+    constexpr int NS = FUSED2 ? 2 : 1;
+    __shared__ float red[NS][4][256];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t tile = blockIdx.x, slice = blockIdx.y;
@@ -296,28 +298,44 @@ __global__ void __launch_bounds__(256) gemv_rowwave3_kernel(const uint32_t *__re
     const half2_t ones = {(half_t)1.0f, (half_t)1.0f};
     const uint32_t MSK = sreg_const(0x00070007u), MAG = vreg_const(0x64006400u);
     const int ldz = N / 32 * 3;
+    const uint32_t *qw[2] = {qw0, qw1};
+    const half_t *sc[2] = {sc0, sc1};
+    const int32_t *qz[2] = {qz0, qz1};
 
-    float yv[4] = {0.f, 0.f, 0.f, 0.f};
+    float yv[NS][4];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) yv[s][j] = 0.f;
     for (uint32_t c = slice; c < nchunk; c += (uint32_t)S) {
         const uint32_t blk0 = c * (4 * UB) + wave * UB;   // first 32-k block of this wave (uniform)
         if (blk0 >= (uint32_t)nblocks) continue;           // nblocks % UB == 0
         const uint32_t g = gshift >= 0 ? (blk0 >> gshift) : 0u;
-        u32x4 w[UB][3];
+        u32x4 w[NS][UB][3];
+        half4_t s4[NS];
+        uint32_t z[NS][3];
 #pragma unroll
-        for (int b = 0; b < UB; b++)
+        for (int s = 0; s < NS; s++) {
 #pragma unroll
-            for (int r = 0; r < 3; r++)
-                w[b][r] = __builtin_nontemporal_load((const u32x4 *)(qw + (size_t)((blk0 + b) * 3 + r) * (uint32_t)N + nc));
-        const half4_t s4 = *(const half4_t *)(sc + (size_t)g * (uint32_t)N + nc);
-        const uint32_t *zrow = (const uint32_t *)qz + (size_t)g * ldz + 3 * (nc >> 5);
-        const uint32_t z0 = zrow[0], z1 = zrow[1], z2 = zrow[2];
+            for (int b = 0; b < UB; b++)
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+                    w[s][b][r] = __builtin_nontemporal_load((const u32x4 *)(qw[s] + (size_t)((blk0 + b) * 3 + r) * (uint32_t)N + nc));
+            s4[s] = *(const half4_t *)(sc[s] + (size_t)g * (uint32_t)N + nc);
+            const uint32_t *zrow = (const uint32_t *)qz[s] + (size_t)g * ldz + 3 * (nc >> 5);
+            z[s][0] = zrow[0]; z[s][1] = zrow[1]; z[s][2] = zrow[2];
+        }
         const x16_t *xq = (const x16_t *)x + blk0;
         x16_t xr[UB];
 #pragma unroll
         for (int b = 0; b < UB; b++) xr[b] = xq[b];
         __builtin_amdgcn_sched_barrier(0);
 
-        float gacc[4] = {0.f, 0.f, 0.f, 0.f};
+        float gacc[NS][4];
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) gacc[s][j] = 0.f;
         float xs_g = 0.f;
 #pragma unroll
         for (int b = 0; b < UB; b++) {
@@ -326,43 +344,54 @@ __global__ void __launch_bounds__(256) gemv_rowwave3_kernel(const uint32_t *__re
             for (int i = 0; i < 16; i++) xs = __builtin_amdgcn_fdot2(as_half2(xr[b][i]), ones, xs, false);
             xs_g += xs;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t a0 = w[b][0][j], a1 = w[b][1][j], a2 = w[b][2][j];
-                float a = 0.f;
+            for (int s = 0; s < NS; s++)
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int bit = 6 * i;
-                    uint32_t t;
-                    if (bit + 6 <= 32) t = __builtin_amdgcn_ubfe(a0, bit, 6);
-                    else if (bit < 32) t = __builtin_amdgcn_alignbit(a1, a0, bit) & 0x3Fu;
-                    else if (bit + 6 <= 64) t = __builtin_amdgcn_ubfe(a1, bit - 32, 6);
-                    else if (bit < 64) t = __builtin_amdgcn_alignbit(a2, a1, bit - 32) & 0x3Fu;
-                    else t = __builtin_amdgcn_ubfe(a2, bit - 64, 6);
-                    const uint32_t h = (((t << 13) | t) & MSK) | MAG;
-                    a = __builtin_amdgcn_fdot2(as_half2(h), as_half2(xr[b][i]), a, false);
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t a0 = w[s][b][0][j], a1 = w[s][b][1][j], a2 = w[s][b][2][j];
+                    float a = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int bit = 6 * i;
+                        uint32_t t;
+                        if (bit + 6 <= 32) t = __builtin_amdgcn_ubfe(a0, bit, 6);
+                        else if (bit < 32) t = __builtin_amdgcn_alignbit(a1, a0, bit) & 0x3Fu;
+                        else if (bit + 6 <= 64) t = __builtin_amdgcn_ubfe(a1, bit - 32, 6);
+                        else if (bit < 64) t = __builtin_amdgcn_alignbit(a2, a1, bit - 32) & 0x3Fu;
+                        else t = __builtin_amdgcn_ubfe(a2, bit - 64, 6);
+                        const uint32_t h = (((t << 13) | t) & MSK) | MAG;
+                        a = __builtin_amdgcn_fdot2(as_half2(h), as_half2(xr[b][i]), a, false);
+                    }
+                    gacc[s][j] += a - 1024.0f * xs;
                 }
-                gacc[j] += a - 1024.0f * xs;
-            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int bit = 3 * ((nc + j) & 31), wi = bit >> 5, o = bit & 31;
-            const uint64_t lo = wi == 0 ? z0 : (wi == 1 ? z1 : z2);
-            const uint64_t hi = wi == 0 ? z1 : (wi == 1 ? z2 : 0u);
-            const float zf = (float)((uint32_t)(((lo | (hi << 32)) >> o) & 7u) + 1u);
-            yv[j] += (float)s4[j] * (gacc[j] - zf * xs_g);
-        }
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int bit = 3 * ((nc + j) & 31), wi = bit >> 5, o = bit & 31;
+                const uint64_t lo = wi == 0 ? z[s][0] : (wi == 1 ? z[s][1] : z[s][2]);
+                const uint64_t hi = wi == 0 ? z[s][1] : (wi == 1 ? z[s][2] : 0u);
+                const float zf = (float)((uint32_t)(((lo | (hi << 32)) >> o) & 7u) + 1u);
+                yv[s][j] += (float)s4[s][j] * (gacc[s][j] - zf * xs_g);
+            }
     }
-    *(float4_t *)&red[wave][4 * lane] = float4_t{yv[0], yv[1], yv[2], yv[3]};
+#pragma unroll
+    for (int s = 0; s < NS; s++) *(float4_t *)&red[s][wave][4 * lane] = float4_t{yv[s][0], yv[s][1], yv[s][2], yv[s][3]};
     __syncthreads();
     const int t = threadIdx.x;
     const uint32_t n = tile * 256 + t;
-    float t0 = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    float t0 = red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t], t1 = 0.f;
+    if constexpr (FUSED2) t1 = red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t];
     if (n < (uint32_t)N) {
         bool mine = true;
-        if (S > 1) mine = splitk_add1(ws + n, t0, S, t0);
+        if (S > 1) {
+            if constexpr (FUSED2) mine = splitk_add2(ws + n, t0, t1, S, t0, t1);
+            else mine = splitk_add1(ws + n, t0, S, t0);
+        }
         if (mine) {
-            half_t h = (half_t)t0;
+            float v = t0;
+            if constexpr (FUSED2) v = t0 * (1.0f / (1.0f + __expf(-t0))) * t1;  // silu on the fp32 accumulator
+            half_t h = (half_t)v;
             if (bias) h = (half_t)((float)h + (float)bias[n]);
             y[n] = h;
         }
@@ -763,14 +792,16 @@ int gemv_rowwave_mr_dispatch(bool fused2, int u, const GemvParams &p, hipStream_
 // the packed rows per group or -1 (one group); p.ws zeroed workspace when split_k > 1.
 int gemv_fast_dispatch(int bits, bool fused2, int u, const GemvParams &p, hipStream_t s) {
     if (bits == 3) {   // u = 32-k blocks in flight per wave (2 or 1); p.upg_shift = log2(blocks per group) or -1
-        if (fused2 || p.norm_w || p.xperm) return GPTQ_E_VARIANT;
+        if (p.norm_w || p.xperm) return GPTQ_E_VARIANT;
         dim3 grid((p.N + 255) / 256, p.split_k), block(256);
         const int nblocks = p.K / 32;
-        if (u == 2) hipLaunchKernelGGL(gemv_rowwave3_kernel<2>, grid, block, 0, s, p.qw[0], p.x, p.sc[0], p.qz[0], p.N, nblocks, p.split_k,
-                                       p.upg_shift, p.y, p.ws, p.bias);
-        else if (u == 1) hipLaunchKernelGGL(gemv_rowwave3_kernel<1>, grid, block, 0, s, p.qw[0], p.x, p.sc[0], p.qz[0], p.N, nblocks,
-                                            p.split_k, p.upg_shift, p.y, p.ws, p.bias);
+#define GPTQ_R3_LAUNCH(UB_, F_)                                                                                                       \
+    hipLaunchKernelGGL((gemv_rowwave3_kernel<UB_, F_>), grid, block, 0, s, p.qw[0], p.x, p.sc[0], p.qz[0], p.N, nblocks, p.split_k,    \
+                       p.upg_shift, p.qw[1], p.sc[1], p.qz[1], p.y, p.ws, p.bias)
+        if (u == 2) { if (fused2) GPTQ_R3_LAUNCH(2, true); else GPTQ_R3_LAUNCH(2, false); }
+        else if (u == 1) { if (fused2) GPTQ_R3_LAUNCH(1, true); else GPTQ_R3_LAUNCH(1, false); }
         else return GPTQ_E_VARIANT;
+#undef GPTQ_R3_LAUNCH
         return (int)hipGetLastError();
     }
     switch (bits) {

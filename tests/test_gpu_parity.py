@@ -705,3 +705,19 @@ def test_act_order_fused_mlp_sorted(gs, K, N):
         ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']),
                                (up_layer['qweight'], up_layer['scales'], up_layer['qzeros'], up_layer['g_idx']), 4)
         assert rel_err(c.cpu().numpy(), ref) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('gs,K,N', [(-1, 4096, 11008), (128, 1024, 2816), (64, 256, 288)])
+def test_3bit_fused_mlp_rowwave(gs, K, N):
+    """3-bit gate/up + SiLU at decode through the 3-bit rowwave kernel (both weight sets in one launch), BASELINE
+    config 4 (3-bit no-group) for the MLP; M = 1 and 2."""
+    A = make_random_layer(3, gs, K, N, seed=K)
+    B = make_random_layer(3, gs, K, N, seed=K + 1)
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    for M in (1, 2):
+        x = (np.random.default_rng(M + K).standard_normal((M, K)) * 0.5).astype(np.float16)
+        c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 3, K if gs == -1 else gs)
+        ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), 3)
+        assert rel_err(c.cpu().numpy(), ref) < TOL

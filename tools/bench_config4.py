@@ -78,3 +78,24 @@ for label, flag in [('4-bit g128 act-order fused gate/up, sorted fast path', Tru
     print(json.dumps({'config': label, 'shape': '2x%dx%d' % (K, N), 'us': round(us, 2), 'GBps': round(nb / us / 1e3, 1), 'frac_of_8TBps': round(nb / us / 8e6, 4)}))
     del g
 QL.ACT_ORDER_SORT = True
+
+# 3-bit no-group fused gate/up + SiLU (gemv_rowwave3_kernel<UB, true>)
+K, N = 4096, 11008
+nb = 2 * (bytes_model(3, -1, K, N, False) - 2 * K - 2 * N) + 2 * K + 2 * N
+nsets = int(300e6 // nb) + 1
+sets = [(make(3, -1, K, N, False), make(3, -1, K, N, False)) for _ in range(nsets)]
+def run(i):
+    (a, b) = sets[i]
+    return FM.fused_gate_up(x, (a[0], a[1], a[2], a[3]), (b[0], b[1], b[2], b[3]), 3, K)
+for i in range(nsets): run(i)
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    for i in range(nsets): run(i)
+g.replay(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5): g.replay()
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / (5 * nsets)
+print(json.dumps({'config': '3-bit no-group fused gate/up', 'shape': '2x%dx%d' % (K, N), 'us': round(us, 2), 'GBps': round(nb / us / 1e3, 1), 'frac_of_8TBps': round(nb / us / 8e6, 4)}))

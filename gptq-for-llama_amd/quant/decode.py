@@ -332,6 +332,52 @@ class DecodeEngine:
         return self.logits
 
 
+def _cache_layer_kv(cache, li):
+    """(keys, values) [1, heads, T, head_dim] of layer li from a transformers cache (5.x: cache.layers[li].keys)."""
+    layers = getattr(cache, 'layers', None)
+    if layers is not None and hasattr(layers[li], 'keys'):
+        return layers[li].keys, layers[li].values
+    kv = cache[li]
+    return kv[0], kv[1]
+
+
+def engine_generate(model, input_ids, max_new_tokens, eos_token_id=None, engine=None, t_max=2048):
+    """Greedy generation: the prompt goes through the HF model once (the drop-in modules' prefill path: MFMA GEMMs,
+    fused MLP epilogue), its KV cache is copied into the engine's static cache, and every further token is ONE hipGraph
+    replay (DecodeEngine).  Returns the full sequence [1, prompt + generated].  Batch 1; the reference equivalent is
+    ``model.generate(input_ids, do_sample=False, max_new_tokens=...)`` through llama_inference.py:109-115."""
+    from transformers.cache_utils import DynamicCache
+    if input_ids.dim() != 2 or input_ids.shape[0] != 1:
+        raise ValueError('engine_generate: batch 1 only')
+    dev = input_ids.device
+    T = input_ids.shape[1]
+    eng = engine if engine is not None else DecodeEngine(model, t_max=t_max).capture()
+    if T + max_new_tokens > eng.t_max:
+        raise ValueError('engine_generate: prompt + max_new_tokens exceeds the engine cache (%d)' % eng.t_max)
+    with torch.no_grad():
+        cache = DynamicCache(config=model.config)
+        out = model(input_ids, past_key_values=cache, use_cache=True)
+        for li in range(len(eng.layers)):
+            k, v = _cache_layer_kv(cache, li)
+            eng.kc[li, :T].copy_(k[0].transpose(0, 1).reshape(T, -1))
+            eng.vc[li, :T].copy_(v[0].transpose(0, 1).reshape(T, -1))
+        eng.pos.fill_(T)
+        nxt = out.logits[0, -1].argmax().reshape(1)
+        del out, cache
+        tokens = [nxt]
+        for i in range(max_new_tokens - 1):
+            if eos_token_id is not None and (i & 15) == 15 and any(int(t) == eos_token_id for t in tokens[-16:]):
+                break                                        # the host looks at the stream every 16 tokens only
+            nxt = eng.decode(nxt)[0].argmax().reshape(1)
+            tokens.append(nxt)
+        gen = torch.cat(tokens)
+        if eos_token_id is not None:
+            hit = (gen == eos_token_id).nonzero()
+            if hit.numel():
+                gen = gen[:int(hit[0]) + 1]
+    return torch.cat([input_ids[0], gen.to(input_ids.dtype)]).unsqueeze(0)
+
+
 def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fuse_norm=True, fuse_attn=True, start_pos=0):
     """the llama.py:385-438 protocol on the DecodeEngine (hipGraph replay per token)."""
     dev = next(model.parameters()).device

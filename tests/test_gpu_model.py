@@ -238,6 +238,28 @@ def test_decode_engine_matches_hf_decoder(graph, fuse):
     assert r['tokens_per_s'] > 0
 
 
+def test_engine_generate_continues_the_hf_prefill():
+    """prompt through the HF model (prefill kernels), KV cache copied into the engine, then one hipGraph replay per
+    token: the engine's logits at every generated position match an HF decoder that is fed the same tokens."""
+    q = D.build_random_llama(DEV, seed=5, **HD128)
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(21)
+    prompt = torch.randint(0, HD128['vocab_size'], (1, 9), device=DEV, generator=gen)
+    eng = D.DecodeEngine(q, t_max=64).capture()
+    seq = D.engine_generate(q, prompt, max_new_tokens=6, engine=eng)
+    assert seq.shape == (1, 15) and torch.equal(seq[:, :9], prompt)
+    # replay the same 15 tokens through the HF decoder in one pass and compare what the engine saw last
+    with torch.no_grad():
+        full = q(seq).logits[0].float().cpu().numpy()
+    last = eng.logits.float().cpu().numpy()[0]               # logits after consuming seq[0, 13] -> predicts seq[0, 14]
+    ref = full[13]
+    assert np.abs(last - ref).max() / np.abs(ref).max() < 2e-2
+    # greedy: every generated token is (within fp16 ties) the argmax of the HF logits at the previous position
+    for pos in range(9, 15):
+        tok = int(seq[0, pos])
+        assert full[pos - 1][tok] >= full[pos - 1].max() - 2e-2 * np.abs(full[pos - 1]).max()
+
+
 def test_decode_engine_act_order_checkpoint():
     """an --act-order model (BASELINE config 4 flavour): q/k/v and gate/up share their permutations, every linear of
     the engine takes the group-sorted fast path (incl. the fused gate/up), logits match the HF decoder running the

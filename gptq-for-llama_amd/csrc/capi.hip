@@ -344,6 +344,10 @@ static int run_auto(const Problem &q, hipStream_t s) {
         if (rc != GPTQ_E_VARIANT) return rc;
     }
     if (q.M <= SKINNY_MAX_M) return run_skinny(q, s);  // falls back to the GEMV for act-order / 3-bit
+    // 65 <= M <= 256: a single 256-row tile per column block cannot fill 256 CUs (4096^2: 111-113 us at M = 128 / 256); 64-row
+    // passes of the weight-streaming kernel are faster there (44 / 88 us; from M = 257 the tile GEMM has two tile rows and wins).  (The Python layer prefers dequantise-once +
+    // dense GEMM for this regime; this is for callers of the C ABI.)
+    if (!q.fused2 && q.M <= 4 * SKINNY_MAX_M) return run_skinny(q, s);
     const int unit_k = (q.bits == 2) ? 64 : 32;
     if (fast_eligible(q, unit_k)) {
         GemvParams p;

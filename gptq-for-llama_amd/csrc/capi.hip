@@ -87,7 +87,7 @@ static int ilog2_exact(int v) {
     return -1;
 }
 
-// The rowwave GEMV (gemv.hip) serves M == 1; larger M here means M launches (the dispatcher
+// The rowwave GEMV (gemv.hip) serves M == 1 (2 <= M <= 4 at 4 bits: run_rowwave_mr, one launch); larger M here means M launches (the dispatcher
 // sends M >= 2 to the weight-streaming MFMA kernel instead).  Picks U = packed rows in flight
 // per wave and S = workgroups per 256-column tile (DESIGN.md "dispatch").
 // 3-bit rowwave: units are 32-k blocks (3 packed rows each)

@@ -54,7 +54,7 @@ enum {
 /* gptq_query(what) */
 enum {
     GPTQ_Q_ABI_VERSION = 0,
-    GPTQ_Q_GEMV_MAX_M = 1,        /* largest M gptq_gemv_f16 serves with one launch per row   */
+    GPTQ_Q_GEMV_MAX_M = 1,        /* largest M of the rowwave GEMV family (4-bit: M <= 4 rows share one launch) */
     GPTQ_Q_SKINNY_MAX_M = 2,      /* largest M served by the weight-streaming MFMA kernel    */
     GPTQ_Q_WORKSPACE_BYTES = 3,   /* bytes of zero-initialised workspace split-K needs       */
     GPTQ_Q_NUM_GEMV_VARIANTS = 4,

@@ -233,3 +233,18 @@ def test_chain_encode_validates_and_picks_slices_without_a_gpu():
     assert encode([op(4096, 4096, x=None)])[0] == -4
     assert encode([op(4096, 4096, x=4098)])[0] == -3
     assert lib.gptq_chain_run_f16(None, 1, 4, 4096, 256, 0, None, 0, None) == -4
+
+
+def test_byte_model_matches_survey_8d():
+    """the algorithmic-bytes figures `roofline.achieved` is computed from, in bench.py and in the oracle"""
+    import bench
+    from oracle import oracle
+    assert bench.alg_bytes(1, 4096, 4096) == 8732672
+    assert bench.alg_bytes(1, 4096, 11008) == 23455232 == bench.alg_bytes(1, 11008, 4096)
+    assert bench.alg_bytes(1, 4096, 12288) == 26181632
+    assert bench.alg_bytes(1, 4096, 11008, nsets=2) == 46880256      # two weight sets, x and y once
+    per_layer = bench.alg_bytes(1, 4096, 12288) + bench.alg_bytes(1, 4096, 4096) + bench.alg_bytes(1, 4096, 11008, nsets=2) + bench.alg_bytes(1, 11008, 4096)
+    assert 32 * per_layer == 3367993344
+    assert oracle.algorithmic_bytes(1, 4096, 4096, 4, 128) == 8732672
+    assert oracle.algorithmic_bytes(1, 4096, 4096, 4, 128, act_order=True) == 8732672 + 4 * 4096
+    assert oracle.algorithmic_bytes(1, 4096, 4096, 3, 4096) == 6317568      # 3-bit, one group (config 4)

@@ -14,8 +14,9 @@ roofline   = the GEMV kernel family against the 8 TB/s HBM3E spec peak.
 cpu_baseline = the C/OpenMP oracle (oracle/gptq_oracle.c, a port of the reference kernel
              arithmetic) on the host cores, on a bounded sample of the same workload.
 --gpus N   = N data-parallel replicas (one process per GPU, no data-path collective; weak
-             scaling).  `--tp` additionally times the row-sharded variant (one RCCL all-reduce
-             per linear, BASELINE config 5) and reports it under "tp".
+             scaling).  The row-sharded layout of BASELINE config 5 (one all-reduce per linear) lives in
+             quant/tensor_parallel.py (world_size-2 gloo tests); its per-rank kernel timings on one GPU are in
+             tools/bench_config5.py -- a single-GPU box cannot time the collective.
 """
 import argparse
 import json

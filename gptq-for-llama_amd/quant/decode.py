@@ -176,6 +176,8 @@ class DecodeEngine:
         self.ab = torch.zeros((1, H), **f16)
         self.cb = torch.zeros((1, I), **f16)
         self.logits = torch.zeros((1, cfg.vocab_size), **f16)
+        self.stream_out = torch.zeros(self.t_max + 1, dtype=torch.int64, device=dev)   # greedy mode: token chosen after position p
+        self.greedy_graph = None
         nl = len(self.layers)
         self.kc = torch.zeros((nl, self.t_max, H), **f16)
         self.vc = torch.zeros((nl, self.t_max, H), **f16)
@@ -304,6 +306,27 @@ class DecodeEngine:
     def reset(self):
         self.pos.zero_()
 
+    def _greedy_step(self):
+        """one decode step whose argmax becomes the next input token, entirely on the device: ids <- argmax(logits),
+        and the choice is appended to stream_out[pos] (pos = number of tokens consumed so far)."""
+        self._step()                                   # consumes self.ids, advances pos
+        torch.argmax(self.logits, dim=-1, out=self.ids)
+        self.stream_out.index_copy_(0, self.pos, self.ids)
+
+    def capture_greedy(self):
+        """capture the self-feeding greedy step (engine_generate): a replay needs no host input at all."""
+        with torch.no_grad():
+            pos0, ids0 = self.pos.clone(), self.ids.clone()
+            self._greedy_step()
+            torch.cuda.synchronize(self.dev)
+            self.pos.copy_(pos0); self.ids.copy_(ids0)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._greedy_step()
+            self.greedy_graph = g
+            self.pos.copy_(pos0); self.ids.copy_(ids0)
+        return self
+
     def capture(self):
         """warm up once (module loads, workspace), then capture one decode step into a hipGraph."""
         with torch.no_grad():
@@ -362,15 +385,21 @@ def engine_generate(model, input_ids, max_new_tokens, eos_token_id=None, engine=
             eng.kc[li, :T].copy_(k[0].transpose(0, 1).reshape(T, -1))
             eng.vc[li, :T].copy_(v[0].transpose(0, 1).reshape(T, -1))
         eng.pos.fill_(T)
-        nxt = out.logits[0, -1].argmax().reshape(1)
+        first = out.logits[0, -1].argmax().reshape(1)
         del out, cache
-        tokens = [nxt]
-        for i in range(max_new_tokens - 1):
-            if eos_token_id is not None and (i & 15) == 15 and any(int(t) == eos_token_id for t in tokens[-16:]):
-                break                                        # the host looks at the stream every 16 tokens only
-            nxt = eng.decode(nxt)[0].argmax().reshape(1)
-            tokens.append(nxt)
-        gen = torch.cat(tokens)
+        if eng.greedy_graph is None:
+            eng.capture_greedy()
+        eng.ids.copy_(first)
+        eng.stream_out[T] = first[0]                         # stream_out[p] = token generated after p consumed tokens
+        done = 1
+        while done < max_new_tokens:
+            burst = min(16, max_new_tokens - done)           # the host looks at the stream every 16 tokens only
+            for _ in range(burst):
+                eng.greedy_graph.replay()
+            done += burst
+            if eos_token_id is not None and bool((eng.stream_out[T:T + done] == eos_token_id).any()):
+                break
+        gen = eng.stream_out[T:T + done].clone()
         if eos_token_id is not None:
             hit = (gen == eos_token_id).nonzero()
             if hit.numel():

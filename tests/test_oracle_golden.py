@@ -235,3 +235,29 @@ def test_gptq_solver_vs_reference_gptq(name):
     assert np.mean(gptq_levels(Q, scale, zero, g_idx) != gptq_levels(f['Q'], f['scale'], f['zero'], f['g_idx'])) < 1e-3
     assert rel_err(Q, f['Q']) < 1e-5
     assert abs(err - float(f['error'])) / float(f['error']) < 1e-4
+
+
+@pytest.mark.parametrize('bits,gs,act', [(4, 64, False), (3, -1, False), (4, 32, True), (2, 64, True)])
+def test_gptq_solver_properties(bits, gs, act):
+    """size-independent properties of the solver restatement: every output weight lies on its group's grid, g_idx
+    has exactly `groupsize` members per group, and the error-feedback solution beats round-to-nearest on the
+    calibration inputs (the whole point of gptq.py:171-205)."""
+    from oracle import gptq_solver as G
+    rng = np.random.default_rng(bits * 100 + (gs if gs > 0 else 7))
+    rows, cols = 40, 256
+    W = (rng.standard_normal((rows, cols)) * 0.05).astype(np.float32)
+    mix = (rng.standard_normal((cols, cols)) * 0.2 + np.eye(cols)).astype(np.float32)
+    X = (rng.standard_normal((512, cols)).astype(np.float32) @ mix) * np.exp(rng.standard_normal(cols) * 0.6).astype(np.float32)
+    H, n = G.hessian_add_batch(np.zeros((cols, cols), np.float32), 0, X[None])
+    Q, scale, zero, g_idx, err = G.fasterquant(W, H, bits, 128, 0.01, gs, act, False)
+    maxq = 2 ** bits - 1
+    lv = Q / scale[:, g_idx] + zero[:, g_idx]
+    assert np.abs(lv - np.rint(lv)).max() < 1e-3 and lv.min() > -1e-3 and lv.max() < maxq + 1e-3
+    gsz = cols if gs == -1 else gs
+    assert np.array_equal(np.bincount(g_idx, minlength=cols // gsz), np.full(cols // gsz, gsz))
+    ref = X @ W.T
+    Wg = W.reshape(rows * (cols // gsz), gsz)
+    s_r, z_r = G.find_params(Wg, maxq, False)
+    rtn = G.quantize(Wg, s_r[:, None], z_r[:, None], maxq).reshape(rows, cols)
+    assert np.linalg.norm(X @ Q.T - ref) < np.linalg.norm(X @ rtn.T - ref)
+    assert err > 0

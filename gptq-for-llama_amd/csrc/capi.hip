@@ -219,9 +219,18 @@ static int run_generic(const Problem &q, hipStream_t s) {
     return 0;
 }
 
-// 2 <= M <= 4, 4-bit, trivial g_idx: ONE rowwave launch for all rows (gemv_rowwave_mr_kernel)
+// 2 <= M <= 4, 4-bit, trivial g_idx: ONE rowwave launch for all rows.  M = 2: dot2 kernel with both x rows in SGPRs
+// (gemv_rowwave_mr_kernel); M = 3, 4: MFMA 4x4x4 kernel (gemv_rowwave_mfma_kernel), 14 % faster there -- measured
+// 4096^2 / 4096x11008, us: M = 2: 5.3 / 8.5 (MFMA 5.5 / 8.6); M = 4: 6.9 / 10.9 (dot2 7.9 / 12.8).  The time grows with
+// M because the combine issues M * N * S returning atomics.  The two-block MFMA variant (M <= 8) is compiled and
+// tested (gptq_set_gemv_variant(101)) but loses to the stream kernel (M = 8: 10.4 vs 8.5 us) and is not dispatched.
+// gptq_set_gemv_variant(100) forces the dot2 kernel, 101 the MFMA kernel (A/B measurements, tests).
 static int run_rowwave_mr(const Problem &q, hipStream_t s) {
-    if (q.bits != 4 || q.M < 2 || q.M > 4 || q.norm_w || q.xperm || g_force_variant.load() >= 0) return GPTQ_E_VARIANT;
+    const int fv = g_force_variant.load();
+    if (fv >= 0 && fv != 100 && fv != 101) return GPTQ_E_VARIANT;
+    const bool mfma = fv == 101 || (fv != 100 && q.M >= 3);
+    const int mmax = fv == 101 ? (q.fused2 ? 4 : 8) : 4;
+    if (q.bits != 4 || q.M < 2 || q.M > mmax || q.norm_w || q.xperm) return GPTQ_E_VARIANT;
     if (!fast_eligible(q, 8)) return GPTQ_E_VARIANT;
     const int rows = q.K / 8;
     const int G = n_groups(q.K, q.groupsize);
@@ -234,7 +243,8 @@ static int run_rowwave_mr(const Problem &q, hipStream_t s) {
     }
     auto u_ok = [&](int u) { return rows % u == 0 && (G == 1 || rpg % u == 0); };
     int u = 0;
-    for (int c = (q.M == 2 ? 8 : 4); c >= (q.M == 2 ? 4 : 2) && !u; c >>= 1)   // x rows live in SGPRs: MR * u * 4 dwords
+    const int uhi = (mfma || q.M == 2) ? 8 : 4, ulo = (mfma || q.M == 2) ? 4 : 2;   // dot2 variant: x rows live in SGPRs (MR * u * 4 dwords)
+    for (int c = uhi; c >= ulo && !u; c >>= 1)
         if (u_ok(c)) u = c;
     if (!u) return GPTQ_E_VARIANT;
     const int ntile = (q.N + 255) / 256;
@@ -254,11 +264,11 @@ static int run_rowwave_mr(const Problem &q, hipStream_t s) {
     fill_params(q, 0, q.M, p);
     p.split_k = split_k;
     p.upg_shift = gshift;
-    return gemv_rowwave_mr_dispatch(q.fused2, u, p, s);
+    return mfma ? gemv_rowwave_mfma_dispatch(q.fused2, u, p, s) : gemv_rowwave_mr_dispatch(q.fused2, u, p, s);
 }
 
 static int run_gemv(const Problem &q, hipStream_t s) {
-    if (q.M >= 2 && q.M <= 4) {
+    if (q.M >= 2 && q.M <= 8) {   // (M > 4 only when the MFMA variant is forced)
         const int rc = run_rowwave_mr(q, s);
         if (rc != GPTQ_E_VARIANT) return rc;
     }
@@ -339,7 +349,7 @@ static int run_skinny(const Problem &q, hipStream_t s) {
 static int run_auto(const Problem &q, hipStream_t s) {
     if (q.M == 0) return 0;
     if (q.M <= 2) return run_gemv(q, s);               // rowwave GEMV (M = 2: both rows in one launch; generic kernel for act-order)
-    if (q.M <= 4) {                                    // small decode batch: rowwave with 4 x rows per weight pass
+    if (q.M <= 8) {                                    // small decode batch (M <= 4; M <= 8 only when the MFMA variant is forced)
         const int rc = run_rowwave_mr(q, s);
         if (rc != GPTQ_E_VARIANT) return rc;
     }

@@ -787,6 +787,184 @@ int gemv_rowwave_mr_dispatch(bool fused2, int u, const GemvParams &p, hipStream_
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// rowwave with MFMA 4x4x4 for 2 <= M <= 8 (small decode batches).  v_mfma_f32_4x4x4_16b_f16 is 16 independent
+// 4 x 4 x 4 products, one per group of four lanes: lane l supplies ONE column of B (4 k values) and receives rows
+// i = 0..3 of that column of D; A is row l % 4 of x.  In the rowwave layout a lane owns 4 columns x 8 k per packed
+// row, so a packed word is two B operands -- and the magic-exponent unpack already yields them in the right shape:
+// t_q = {OFF + q_q, OFF + q_{q+4}} -> B1 = (t0, t1) = k order [0,4,1,5], B2 = (t2, t3) = [2,6,3,7], with
+// A1 = (X0, X1), A2 = (X2, X3) the same x pairs the dot2 path uses.  Per packed word: the 7-VALU unpack + 2 MFMAs
+// per block of four x rows (instead of 4 dot2 per row): the kernel stays unpack-bound up to M = 8.
+// sum_k x (for the zero-point term) comes from the same MFMA against a B of ones.
+// ---------------------------------------------------------------------------------------
+template <int U, bool FUSED2, int MB>
+__global__ void __launch_bounds__(256) gemv_rowwave_mfma_kernel(const uint32_t *__restrict__ qw0, const half_t *__restrict__ x, int ldx,
+                                                                const half_t *__restrict__ sc0, const int32_t *__restrict__ qz0, int N,
+                                                                int rows, int S, int gshift, const uint32_t *__restrict__ qw1,
+                                                                const half_t *__restrict__ sc1, const int32_t *__restrict__ qz1,
+                                                                half_t *__restrict__ y, int ldy, u64_t *__restrict__ ws,
+                                                                const half_t *__restrict__ bias, int M) {
+    constexpr int BITS = 4;
+    using UP = Unpack<BITS>;
+    constexpr int KPW = UP::KPW, NP = UP::NP;
+    constexpr int NS = FUSED2 ? 2 : 1;
+    constexpr int MR = 4 * MB;
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    __shared__ float red[MR][NS][4][256];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t tile = blockIdx.x, slice = blockIdx.y;
+    const uint32_t n0 = tile * 256 + lane * 4;
+    const uint32_t nc = n0 < (uint32_t)N ? n0 : 0;
+    const uint32_t nchunk = ((uint32_t)rows + 4 * U - 1) / (4 * U);
+    const uint32_t *qw[2] = {qw0, qw1};
+    const half_t *sc[2] = {sc0, sc1};
+    const int32_t *qz[2] = {qz0, qz1};
+    const uint32_t MSK = sreg_const(UP::MSK_C), MAG = vreg_const(UP::MAG_C);
+    const h4_t ones = {(half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f};
+    const half_t *xrow[MB];   // this lane's A row of each block of four x rows (rows past M re-read row M-1; never written)
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+        const int m = 4 * mb + (lane & 3);
+        xrow[mb] = x + (size_t)(m < M ? m : M - 1) * ldx;
+    }
+
+    float4_t yv[MB][NS][4];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) yv[mb][s][c] = (float4_t)0.f;
+
+    for (uint32_t ch = slice; ch < nchunk; ch += (uint32_t)S) {
+        const uint32_t row = ch * (4 * U) + wave * U;
+        if (row >= (uint32_t)rows) continue;
+        // x first (L2 hits; vector loads return in order, so behind the weights they would arrive last)
+        u32x4 xv[MB][U];
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+            for (int u = 0; u < U; u++) xv[mb][u] = *(const u32x4 *)(xrow[mb] + (size_t)(row + u) * KPW);
+        u32x4 w[NS][U];
+        half4_t s4[NS];
+        uint32_t zw[NS];
+        const uint32_t g = gshift >= 0 ? (row >> gshift) : 0u;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                w[s][u] = __builtin_nontemporal_load((const u32x4 *)(qw[s] + (size_t)(row + u) * (uint32_t)N + nc));
+            s4[s] = *(const half4_t *)(sc[s] + (size_t)g * (uint32_t)N + nc);
+            zw[s] = (uint32_t)qz[s][(size_t)g * ((uint32_t)N / KPW) + nc / KPW];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is in flight before any math
+
+        float4_t acc[MB][NS][4], xs[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; mb++) {
+            xs[mb] = (float4_t)0.f;
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[mb][s][c] = (float4_t)0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            h4_t A1[MB], A2[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++) {
+                const u32x4 v = xv[mb][u];
+                // halves h0..h7 of this row's 8 k -> pairs X_q = (h_q, h_{q+4}); A1 = (X0, X1), A2 = (X2, X3)
+                const uint32_t X0 = __builtin_amdgcn_perm(v[2], v[0], 0x05040100u), X1 = __builtin_amdgcn_perm(v[2], v[0], 0x07060302u);
+                const uint32_t X2 = __builtin_amdgcn_perm(v[3], v[1], 0x05040100u), X3 = __builtin_amdgcn_perm(v[3], v[1], 0x07060302u);
+                A1[mb] = __builtin_bit_cast(h4_t, u32x2{X0, X1});
+                A2[mb] = __builtin_bit_cast(h4_t, u32x2{X2, X3});
+                xs[mb] = __builtin_amdgcn_mfma_f32_4x4x4f16(A1[mb], ones, xs[mb], 0, 0, 0);
+                xs[mb] = __builtin_amdgcn_mfma_f32_4x4x4f16(A2[mb], ones, xs[mb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    half2_t t[NP];
+                    UP::pairs_rc(w[s][u][c], t, MSK, MAG);
+                    const h4_t B1 = __builtin_bit_cast(h4_t, u32x2{as_u32(t[0]), as_u32(t[1])});
+                    const h4_t B2 = __builtin_bit_cast(h4_t, u32x2{as_u32(t[2]), as_u32(t[3])});
+#pragma unroll
+                    for (int mb = 0; mb < MB; mb++) {
+                        acc[mb][s][c] = __builtin_amdgcn_mfma_f32_4x4x4f16(A1[mb], B1, acc[mb][s][c], 0, 0, 0);
+                        acc[mb][s][c] = __builtin_amdgcn_mfma_f32_4x4x4f16(A2[mb], B2, acc[mb][s][c], 0, 0, 0);
+                    }
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float zf = (float)(((zw[s] >> (BITS * ((nc + c) % KPW))) & ((1u << BITS) - 1u)) + 1u) + UP::OFF;
+                const float sv = (float)s4[s][c];
+#pragma unroll
+                for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) yv[mb][s][c][i] += sv * (acc[mb][s][c][i] - zf * xs[mb][i]);
+            }
+    }
+
+    // red[m][s][wave][column]: lane holds columns 4*lane + c, rows 4*mb + i
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+                *(float4_t *)&red[4 * mb + i][s][wave][4 * lane] = float4_t{yv[mb][s][0][i], yv[mb][s][1][i], yv[mb][s][2][i], yv[mb][s][3][i]};
+    __syncthreads();
+    const int t = threadIdx.x;
+    const uint32_t n = tile * 256 + t;
+    if (n >= (uint32_t)N) return;
+#pragma unroll
+    for (int m = 0; m < MR; m++) {
+        if (m >= M) break;
+        float t0 = red[m][0][0][t] + red[m][0][1][t] + red[m][0][2][t] + red[m][0][3][t], t1 = 0.f;
+        if constexpr (FUSED2) t1 = red[m][1][0][t] + red[m][1][1][t] + red[m][1][2][t] + red[m][1][3][t];
+        bool mine = true;
+        if (S > 1) {
+            u64_t *word = ws + (size_t)m * (uint32_t)N + n;
+            if constexpr (FUSED2) mine = splitk_add2(word, t0, t1, S, t0, t1);
+            else mine = splitk_add1(word, t0, S, t0);
+        }
+        if (mine) {
+            float v = t0;
+            if constexpr (FUSED2) v = t0 * (1.0f / (1.0f + __expf(-t0))) * t1;
+            half_t h = (half_t)v;
+            if (bias) h = (half_t)((float)h + (float)bias[n]);
+            y[(size_t)m * ldy + n] = h;
+        }
+    }
+}
+
+// 2 <= p.M <= 8, 4-bit: MFMA 4x4x4 rowwave (M <= 4: one block of four x rows, fused gate/up allowed; M <= 8: two blocks)
+int gemv_rowwave_mfma_dispatch(bool fused2, int u, const GemvParams &p, hipStream_t s) {
+    if (p.M < 2 || p.M > 8 || p.xperm || p.norm_w || (fused2 && p.M > 4)) return GPTQ_E_VARIANT;
+    const int rows = p.K / 8;
+    dim3 grid((p.N + 255) / 256, p.split_k), block(256);
+#define GPTQ_MF_LAUNCH(U_, F_, MB_)                                                                                                        \
+    hipLaunchKernelGGL((gemv_rowwave_mfma_kernel<U_, F_, MB_>), grid, block, 0, s, p.qw[0], p.x, (int)p.ldx, p.sc[0], p.qz[0], p.N, rows,   \
+                       p.split_k, p.upg_shift, p.qw[1], p.sc[1], p.qz[1], p.y, (int)p.ldy, p.ws, p.bias, p.M)
+    if (p.M <= 4) {
+        if (u == 8) { if (fused2) GPTQ_MF_LAUNCH(8, true, 1); else GPTQ_MF_LAUNCH(8, false, 1); }
+        else if (u == 4) { if (fused2) GPTQ_MF_LAUNCH(4, true, 1); else GPTQ_MF_LAUNCH(4, false, 1); }
+        else return GPTQ_E_VARIANT;
+    } else {
+        if (u == 8) GPTQ_MF_LAUNCH(8, false, 2);
+        else if (u == 4) GPTQ_MF_LAUNCH(4, false, 2);
+        else return GPTQ_E_VARIANT;
+    }
+#undef GPTQ_MF_LAUNCH
+    return (int)hipGetLastError();
+}
+
 // M == 1.  u = packed rows in flight per wave (8, 4 or 2; rows % u == 0 and a wave's u rows lie
 // in one quantisation group); p.split_k = workgroups per 256-column tile; p.upg_shift = log2 of
 // the packed rows per group or -1 (one group); p.ws zeroed workspace when split_k > 1.

@@ -41,6 +41,7 @@ struct GemvParams {
 
 int gemv_fast_dispatch(int bits, bool fused2, int u, const GemvParams &p, hipStream_t s);
 int gemv_rowwave_mr_dispatch(bool fused2, int u, const GemvParams &p, hipStream_t s);   // 2 <= M <= 4, 4-bit, one launch
+int gemv_rowwave_mfma_dispatch(bool fused2, int u, const GemvParams &p, hipStream_t s); // 2 <= M <= 8, 4-bit, MFMA 4x4x4
 int gemv_generic_dispatch(int bits, bool fused2, int nl, const GemvParams &p, hipStream_t s);
 
 // skinny MFMA (weight streaming, M <= 64) and tiled MFMA GEMM (prefill)

@@ -630,11 +630,22 @@ def test_chain_matches_oracle_op_by_op(K, I, gs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('M', [2, 3, 4])
+@pytest.mark.parametrize('variant', [-1, 100, 101])
+@pytest.mark.parametrize('M', [2, 3, 4, 5, 8])
 @pytest.mark.parametrize('gs,K,N', [(128, 4096, 4096), (128, 1024, 2816), (64, 512, 288), (-1, 256, 1024), (32, 256, 512)])
-def test_small_batch_rowwave(gs, K, N, M):
-    """2 <= M <= 4 at 4 bits: all rows in ONE rowwave launch (gemv_rowwave_mr_kernel), plain and fused gate/up, bias,
-    strided x rows; split-K words are [M][N] and must be back to zero."""
+def test_small_batch_rowwave(gs, K, N, M, variant):
+    """2 <= M <= 4 (8 with the forced two-block MFMA variant) at 4 bits: all rows in ONE rowwave launch -- default choice,
+    dot2 kernel (100), MFMA 4x4x4 kernel (101) -- plain and fused gate/up, bias, strided x rows; split-K words are [M][N] and must be back to zero."""
+    if variant != 101 and M > 4:
+        pytest.skip('M > 4 is served by the stream kernel unless the two-block MFMA variant is forced')
+    prev = _native.lib().gptq_set_gemv_variant(variant)
+    try:
+        _small_batch_body(gs, K, N, M, plain_family=(variant == -1))
+    finally:
+        _native.lib().gptq_set_gemv_variant(prev)
+
+
+def _small_batch_body(gs, K, N, M, plain_family):
     import torch
     L = make_random_layer(4, gs, K, N, seed=M + K)
     U = make_random_layer(4, gs, K, N, seed=M + K + 1)
@@ -642,7 +653,8 @@ def test_small_batch_rowwave(gs, K, N, M):
     x = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
     bias = rng.standard_normal(N).astype(np.float16)
     check_forward(x, L, bias=bias)
-    check_forward(x, L, family='gemv')
+    if plain_family:
+        check_forward(x, L, family='gemv')
     # strided rows
     wide = torch.zeros((M, K + 64), dtype=torch.float16, device='cuda:0')
     wide[:, :K] = torch.from_numpy(x).cuda()

@@ -9,10 +9,13 @@ from bench import PackedSet, alg_bytes, BITS, GS
 from quant import _native
 dev = 'cuda:0'; lib = _native.lib(); ws = _native.workspace(torch.device(dev))
 gen = torch.Generator(device=dev); gen.manual_seed(0)
+if os.environ.get('GEMV_VARIANT'):
+    lib.gptq_set_gemv_variant(int(os.environ['GEMV_VARIANT']))   # 100 = dot2 small-batch kernel instead of the MFMA 4x4x4 one
+MS = [int(v) for v in os.environ.get('MS', '1,2,3,4,5,8,16,32,64,128,256').split(',')]
 for K, N in [(4096, 4096), (4096, 11008)]:
     nsets = int(300e6 // alg_bytes(1, K, N)) + 1
     sets = [PackedSet(K, N, dev, gen) for _ in range(nsets)]
-    for M in [1, 2, 4, 8, 16, 32, 64, 128, 256]:
+    for M in MS:
         x = torch.randn((M, K), device=dev, generator=gen).half(); y = torch.empty((M, N), dtype=torch.float16, device=dev)
         def run(i):
             w = sets[i]

@@ -11,6 +11,8 @@ dev = 'cuda:0'; lib = _native.lib(); ws = _native.workspace(torch.device(dev))
 gen = torch.Generator(device=dev); gen.manual_seed(0)
 if os.environ.get('GEMV_VARIANT'):
     lib.gptq_set_gemv_variant(int(os.environ['GEMV_VARIANT']))   # 100 = dot2 small-batch kernel instead of the MFMA 4x4x4 one
+if os.environ.get('SPLIT_K'):
+    lib.gptq_set_split_k(int(os.environ['SPLIT_K']))
 MS = [int(v) for v in os.environ.get('MS', '1,2,3,4,5,8,16,32,64,128,256').split(',')]
 for K, N in [(4096, 4096), (4096, 11008)]:
     nsets = int(300e6 // alg_bytes(1, K, N)) + 1

@@ -422,6 +422,92 @@ static float time_graph_prefetch(launch_fn fn, P base, const std::vector<WSet> &
     return ms * 1e3f / (reps * sets.size());
 }
 
+// ------------------------------------------------------------------------------------------
+// "column stripes on a repacked layout": what would the GEMV cost WITHOUT a K split (no combine atomics, no workspace)
+// if every workgroup owned 16 whole output columns and its weight slice were contiguous in memory (a load-time
+// repack: buf[wg][packed row][16 columns])?  One wave instruction = 16 packed rows x 16 columns (1 KiB, contiguous);
+// lane l -> row l / 4, columns 4 (l % 4) .. +3; x comes from LDS (rows differ per lane); reduce over the 16 row
+// lanes with shuffles, over the 4 waves through LDS, store y directly.  Group = 128 k = one row block.
+__global__ void __launch_bounds__(256) k_colstripe(const P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_smem[];
+    half_t *xl = (half_t *)cs_smem;                      // x[K]
+    float *red = (float *)(cs_smem + (size_t)p.K * 2);   // [4][16]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = blockIdx.x, N = p.N, rows = p.K / 8, nrb = rows / 16;
+    const uint32_t *slice = p.qw + (size_t)wg * rows * 16;
+    const int col0 = wg * 16 + 4 * (lane & 3);
+    const half2_t ones = {(half_t)1.f, (half_t)1.f};
+    const uint32_t MSK = sreg_const(0x00F000F0u), MAG = vreg_const(0x54005400u);
+    constexpr int U = 8;
+    float y[4] = {0.f, 0.f, 0.f, 0.f};
+    bool staged = false;
+    for (int rb0 = wave; rb0 < nrb; rb0 += 4 * U) {
+        u32x4 w[U];
+        half4_t s4[U];
+        uint32_t zw[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int rb = rb0 + 4 * u;
+            const int rbc = rb < nrb ? rb : nrb - 1;
+            w[u] = __builtin_nontemporal_load((const u32x4 *)(slice + (size_t)rbc * 256 + lane * 4));
+            s4[u] = *(const half4_t *)(p.sc + (size_t)rbc * N + col0);
+            zw[u] = p.qz[(size_t)rbc * (N / 8) + col0 / 8];
+        }
+        if (!staged) {   // x -> LDS once, behind the first weight loads
+            for (int i = threadIdx.x; i < p.K / 8; i += 256) *(u32x4 *)(xl + (size_t)i * 8) = *(const u32x4 *)(p.x + (size_t)i * 8);
+            __syncthreads();
+            staged = true;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int rb = rb0 + 4 * u;
+            if (rb >= nrb) break;
+            const int r = rb * 16 + (lane >> 2);
+            const u32x4 v = *(const u32x4 *)(xl + (size_t)r * 8);
+            half2_t X[4];
+            X[0] = as_half2(__builtin_amdgcn_perm(v[2], v[0], 0x05040100u)); X[1] = as_half2(__builtin_amdgcn_perm(v[2], v[0], 0x07060302u));
+            X[2] = as_half2(__builtin_amdgcn_perm(v[3], v[1], 0x05040100u)); X[3] = as_half2(__builtin_amdgcn_perm(v[3], v[1], 0x07060302u));
+            float xs = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) xs = __builtin_amdgcn_fdot2(X[q], ones, xs, false);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t ww = w[u][j];
+                half2_t t[4];
+                t[0] = as_half2(((ww << 4) & MSK) | MAG); t[1] = as_half2((ww & MSK) | MAG);
+                t[2] = as_half2(((ww >> 4) & MSK) | MAG); t[3] = as_half2(((ww >> 8) & MSK) | MAG);
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; q++) a = __builtin_amdgcn_fdot2(t[q], X[q], a, false);
+                const float zf = (float)(((zw[u] >> (4 * ((col0 + j) & 7))) & 15u) + 1u) + 64.0f;
+                y[j] += (float)s4[u][j] * (a - zf * xs);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) y[j] += __shfl_xor(y[j], off, 64);
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) red[wave * 16 + 4 * lane + j] = y[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) p.y[wg * 16 + threadIdx.x] = (half_t)(red[threadIdx.x] + red[16 + threadIdx.x] + red[32 + threadIdx.x] + red[48 + threadIdx.x]);
+}
+static void launch_colstripe(const P &p, hipStream_t s) {
+    hipLaunchKernelGGL(k_colstripe, dim3(p.N / 16), dim3(256), (size_t)p.K * 2 + 256, s, p);
+}
+// logical [rows][N] view of a buffer that k_colstripe reads as [N/16][rows][16] (for the reference check only)
+__global__ void unrepack_kernel(const uint32_t *buf, uint32_t *logical, int rows, int N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * N) return;
+    const int r = (int)(i / N), n = (int)(i % N);
+    logical[i] = buf[((size_t)(n / 16) * rows + r) * 16 + (n % 16)];
+}
+
 int main(int argc, char **argv) {
     hipStream_t s; CK(hipStreamCreate(&s));
     int shapes[][2] = {{4096, 4096}, {4096, 12288}, {11008, 4096}, {4096, 11008}};
@@ -527,6 +613,24 @@ int main(int argc, char **argv) {
                 float t = time_graph_chains(launch_rowwave<U, 0>, p, sets, s, 5, nch);
                 printf("  rowwave U8 S%d on %d parallel graph chain(s): %6.2f us per launch  %5.0f GB/s\n", p.S, nch, t, bytes / t / 1e3);
             }
+        }
+        if (N % 16 == 0 && rows % 16 == 0 && getenv("LAB_COLSTRIPE")) {
+            P p = base;
+            // reference on the logical view of set 1
+            uint32_t *logical; CK(hipMalloc(&logical, qw_n * 4));
+            const WSet &w1 = sets[1 % sets.size()];
+            hipLaunchKernelGGL(unrepack_kernel, dim3((unsigned)((qw_n + 255) / 256)), dim3(256), 0, s, w1.qw, logical, rows, N);
+            hipLaunchKernelGGL(ref_kernel, dim3((N + 255) / 256), dim3(256), 0, s, x, logical, w1.sc, w1.qz, yref, K, N);
+            CK(hipMemsetAsync(y, 0, N * 2, s));
+            { P q = p; q.qw = w1.qw; q.sc = w1.sc; q.qz = w1.qz; launch_colstripe(q, s); }
+            CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(href.data(), yref, N * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hy.data(), y, N * 2, hipMemcpyDeviceToHost));
+            double mx = 0, err = 0;
+            for (int n = 0; n < N; n++) { mx = fmax(mx, fabs(href[n])); err = fmax(err, fabs(href[n] - (double)(float)hy[n])); }
+            const float t = time_graph(launch_colstripe, p, sets, s, 5);
+            printf("  colstripe (no K split, repacked [wg][row][16]) wgs %5d: %6.2f us %5.0f GB/s err %.1e\n", N / 16, t, bytes / t / 1e3, err / mx);
+            CK(hipFree(logical));
         }
         if (N % 256 == 0 && rows % 32 == 0 && getenv("LAB_PREFETCH")) {
             constexpr int U = 8;

@@ -7,7 +7,9 @@ down_proj 11008x4096], 4-bit, groupsize 128; synthetic random-init packed weight
 issued through the C ABI (include/gptq_mi355x.h) exactly as the drop-in modules issue it after
 make_quant_attn / make_fused_mlp: 4 launches per layer, 128 per step, 3.37 GB of distinct
 weights per step (> the 256 MiB Infinity Cache, so every step streams from HBM).
-The step is captured once into a hipGraph and replayed; inputs are resident in HBM.
+issued through the C ABI exactly as the drop-in modules issue it at decode: gptq_stripe_matvec_f16 on the stripe16 images the
+modules build once at load time from the checkpoint buffers (csrc/stripe.hip; --kernel rowwave = the split-K kernels
+on the checkpoint layout, for A/B runs).  The step is captured once into a hipGraph and replayed; inputs are resident in HBM.
 
 value      = algorithmic GB/s of the whole job (SURVEY 8(d) byte model), all ranks summed.
 roofline   = the GEMV kernel family against the 8 TB/s HBM3E spec peak.
@@ -54,20 +56,31 @@ class PackedSet:
 
 
 class DecodeLinears:
-    """the 4 launches/layer x 32 layers of one decode token, as raw C-ABI calls."""
+    """the 4 launches/layer x 32 layers of one decode token, as raw C-ABI calls.
+    kernel = 'stripe' (default): gptq_stripe_matvec_f16 on the stripe16 images the drop-in modules build at load time
+    (csrc/stripe.hip: no K split, no combine atomics); 'rowwave': gptq_matmul248_f16 / gptq_fused_mlp_f16 on the
+    checkpoint layout (split-K + fixed-point atomic combine), kept for A/B runs."""
 
-    def __init__(self, dev, layers=LAYERS, seed=0):
-        from quant import _native
+    def __init__(self, dev, layers=LAYERS, seed=0, kernel='stripe'):
+        from quant import _native, quant_linear
         self.native = _native
         self.lib = _native.lib()
         self.dev = dev
+        self.kernel = kernel
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
         self.layers = []
         for _ in range(layers):
-            self.layers.append(dict(qkv=PackedSet(HIDDEN, 3 * HIDDEN, dev, gen), o=PackedSet(HIDDEN, HIDDEN, dev, gen),
-                                    gate=PackedSet(HIDDEN, INTER, dev, gen), up=PackedSet(HIDDEN, INTER, dev, gen),
-                                    down=PackedSet(INTER, HIDDEN, dev, gen)))
+            L = dict(qkv=PackedSet(HIDDEN, 3 * HIDDEN, dev, gen), o=PackedSet(HIDDEN, HIDDEN, dev, gen),
+                     gate=PackedSet(HIDDEN, INTER, dev, gen), up=PackedSet(HIDDEN, INTER, dev, gen),
+                     down=PackedSet(INTER, HIDDEN, dev, gen))
+            if kernel == 'stripe':     # what QuantLinear / QuantLlamaMLP do on their first decode call (quant_linear.stripe_copy)
+                for k in ('qkv', 'o', 'down'):
+                    L['st_' + k] = quant_linear.stripe_copy(L[k].qweight, L[k].scales, L[k].qzeros, BITS, GS)
+                L['st_mlp'] = quant_linear.stripe_copy(L['gate'].qweight, L['gate'].scales, L['gate'].qzeros, BITS, GS,
+                                                       up=(L['up'].qweight, L['up'].scales, L['up'].qzeros))
+                assert all(L[k] is not None for k in ('st_qkv', 'st_o', 'st_down', 'st_mlp'))
+            self.layers.append(L)
         self.x_h = torch.randn((1, HIDDEN), device=dev, generator=gen).half()
         self.x_i = (torch.randn((1, INTER), device=dev, generator=gen) * 0.5).half()
         self.y_qkv = torch.empty((1, 3 * HIDDEN), dtype=torch.float16, device=dev)
@@ -78,13 +91,24 @@ class DecodeLinears:
                                         alg_bytes(1, HIDDEN, INTER, nsets=2) + alg_bytes(1, INTER, HIDDEN))
         self.launches_per_step = 4 * layers
 
-    def _mm(self, x, w, y, stream):
+    def _stripe(self, x, st, y, K, N, nsets, stream):
+        rc = self.lib.gptq_stripe_matvec_f16(x.data_ptr(), st.data_ptr(), st.numel(), None, y.data_ptr(), K, N, BITS, GS, nsets,
+                                             None, 0.0, None, stream)
+        self.native.check(rc, 'gptq_stripe_matvec_f16')
+
+    def _mm(self, x, L, name, y, stream):
+        w = L[name]
+        if self.kernel == 'stripe':
+            return self._stripe(x, L['st_' + name], y, w.K, w.N, 1, stream)
         rc = self.lib.gptq_matmul248_f16(x.data_ptr(), w.K, w.qweight.data_ptr(), w.scales.data_ptr(), w.qzeros.data_ptr(),
                                          None, None, y.data_ptr(), w.N, 1, w.K, w.N, BITS, GS, self.ws.data_ptr(),
                                          self.ws.numel(), stream)
         self.native.check(rc, 'gptq_matmul248_f16')
 
-    def _mlp(self, x, g, u, y, stream):
+    def _mlp(self, x, L, y, stream):
+        g, u = L['gate'], L['up']
+        if self.kernel == 'stripe':
+            return self._stripe(x, L['st_mlp'], y, g.K, g.N, 2, stream)
         rc = self.lib.gptq_fused_mlp_f16(x.data_ptr(), g.K, g.qweight.data_ptr(), g.scales.data_ptr(), g.qzeros.data_ptr(),
                                          None, u.qweight.data_ptr(), u.scales.data_ptr(), u.qzeros.data_ptr(), None,
                                          y.data_ptr(), g.N, 1, g.K, g.N, BITS, GS, self.ws.data_ptr(), self.ws.numel(), stream)
@@ -93,21 +117,20 @@ class DecodeLinears:
     def step(self):
         s = torch.cuda.current_stream().cuda_stream
         for L in self.layers:
-            self._mm(self.x_h, L['qkv'], self.y_qkv, s)
-            self._mm(self.x_h, L['o'], self.y_h, s)
-            self._mlp(self.x_h, L['gate'], L['up'], self.y_i, s)
-            self._mm(self.x_i, L['down'], self.y_h, s)
+            self._mm(self.x_h, L, 'qkv', self.y_qkv, s)
+            self._mm(self.x_h, L, 'o', self.y_h, s)
+            self._mlp(self.x_h, L, self.y_i, s)
+            self._mm(self.x_i, L, 'down', self.y_h, s)
 
     def per_shape(self, reps=20):
         """event-timed launches per shape, rotating over the 32 layers' distinct weights (cold)."""
         out = {}
         cs = lambda: torch.cuda.current_stream().cuda_stream   # the capture stream inside torch.cuda.graph
         legs = {
-            'qkv_4096x12288': (lambda L: self._mm(self.x_h, L['qkv'], self.y_qkv, cs()), alg_bytes(1, HIDDEN, 3 * HIDDEN)),
-            'o_4096x4096': (lambda L: self._mm(self.x_h, L['o'], self.y_h, cs()), alg_bytes(1, HIDDEN, HIDDEN)),
-            'gate_up_silu_2x4096x11008': (lambda L: self._mlp(self.x_h, L['gate'], L['up'], self.y_i, cs()),
-                                          alg_bytes(1, HIDDEN, INTER, nsets=2)),
-            'down_11008x4096': (lambda L: self._mm(self.x_i, L['down'], self.y_h, cs()), alg_bytes(1, INTER, HIDDEN)),
+            'qkv_4096x12288': (lambda L: self._mm(self.x_h, L, 'qkv', self.y_qkv, cs()), alg_bytes(1, HIDDEN, 3 * HIDDEN)),
+            'o_4096x4096': (lambda L: self._mm(self.x_h, L, 'o', self.y_h, cs()), alg_bytes(1, HIDDEN, HIDDEN)),
+            'gate_up_silu_2x4096x11008': (lambda L: self._mlp(self.x_h, L, self.y_i, cs()), alg_bytes(1, HIDDEN, INTER, nsets=2)),
+            'down_11008x4096': (lambda L: self._mm(self.x_i, L, 'down', self.y_h, cs()), alg_bytes(1, INTER, HIDDEN)),
         }
         for name, (fn, nbytes) in legs.items():
             g = torch.cuda.CUDAGraph()
@@ -132,11 +155,10 @@ class DecodeLinears:
 
 
 def larger_model_shapes(dev, reps=5):
-    """side leg (reported only): the same two kernels on LLaMA-65B-shaped layers (BASELINE config 5 shapes on ONE GPU),
-    cold weights (rotation over > 256 MiB of distinct sets inside one hipGraph).  Shows how the fixed cost per launch
-    amortises: per launch ~ 4 us + bytes / 6.9 TB/s on both model sizes."""
-    from quant import _native
-    lib, ws = _native.lib(), _native.workspace(torch.device(dev))
+    """side leg (reported only): the same decode kernel on LLaMA-65B-shaped layers (BASELINE config 5 shapes on ONE GPU),
+    cold weights (rotation over > 256 MiB of distinct sets inside one hipGraph)."""
+    from quant import _native, quant_linear
+    lib = _native.lib()
     gen = torch.Generator(device=dev)
     gen.manual_seed(5)
     H65, I65 = 8192, 22016
@@ -145,20 +167,20 @@ def larger_model_shapes(dev, reps=5):
                               ('gate_up_silu_2x8192x22016', H65, I65, True), ('down_22016x8192', I65, H65, False)]:
         nb = alg_bytes(1, K, N, nsets=2 if fused else 1)
         nsets = int(300e6 // nb) + 1
-        sets = [(PackedSet(K, N, dev, gen), PackedSet(K, N, dev, gen) if fused else None) for _ in range(nsets)]
+        sts = []
+        for _ in range(nsets):
+            w = PackedSet(K, N, dev, gen)
+            u = PackedSet(K, N, dev, gen) if fused else None
+            sts.append(quant_linear.stripe_copy(w.qweight, w.scales, w.qzeros, BITS, GS, up=(u.qweight, u.scales, u.qzeros) if fused else None))
+            torch.cuda.synchronize()
+            del w, u
         x = torch.randn((1, K), device=dev, generator=gen).half()
         y = torch.empty((1, N), dtype=torch.float16, device=dev)
 
         def launch(i):
-            w, u = sets[i]
-            st = torch.cuda.current_stream().cuda_stream
-            if fused:
-                rc = lib.gptq_fused_mlp_f16(x.data_ptr(), K, w.qweight.data_ptr(), w.scales.data_ptr(), w.qzeros.data_ptr(), None,
-                                            u.qweight.data_ptr(), u.scales.data_ptr(), u.qzeros.data_ptr(), None, y.data_ptr(), N, 1, K, N,
-                                            BITS, GS, ws.data_ptr(), ws.numel(), st)
-            else:
-                rc = lib.gptq_matmul248_f16(x.data_ptr(), K, w.qweight.data_ptr(), w.scales.data_ptr(), w.qzeros.data_ptr(), None, None,
-                                            y.data_ptr(), N, 1, K, N, BITS, GS, ws.data_ptr(), ws.numel(), st)
+            st = sts[i]
+            rc = lib.gptq_stripe_matvec_f16(x.data_ptr(), st.data_ptr(), st.numel(), None, y.data_ptr(), K, N, BITS, GS, 2 if fused else 1,
+                                            None, 0.0, None, torch.cuda.current_stream().cuda_stream)
             _native.check(rc, name)
         for i in range(nsets):
             launch(i)
@@ -177,8 +199,103 @@ def larger_model_shapes(dev, reps=5):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (reps * nsets)
         out[name] = {'us_per_launch': round(us, 3), 'GBps': round(nb / us / 1e3, 1), 'frac_of_8TBps': round(nb / us / 1e3 / HBM_PEAK_GBS, 4)}
-        del sets, g
+        del sts, g
         torch.cuda.empty_cache()
+    return out
+
+
+def _time_cold(run, nsets, reps=5):
+    """us per launch of run(i), i rotating over nsets distinct weight sets inside one hipGraph (cold weights)."""
+    for i in range(nsets):
+        run(i)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(nsets):
+            run(i)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * nsets)
+
+
+def prefill_leg(dev, M=65536, reps=3):
+    """BASELINE config 3 (reported only): LLaMA-7B-shaped 4-bit g128 batched matmul at M = 32 x 2048 through the drop-in
+    matmul248 (hand-written MFMA tile GEMM, csrc/gemm_mfma.hip; reference kernel quant_linear.py:72-137), TFLOP/s =
+    2 M N K / t against the 2.5 PFLOP/s dense fp16 MFMA peak, next to hipBLASLt (torch.matmul) on the dequantised weight."""
+    from quant import quant_linear as QL
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    out = {'M': M, 'peak_TFLOPs': 2500.0, 'shapes': {}}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for K, N in [(HIDDEN, HIDDEN), (HIDDEN, 3 * HIDDEN), (HIDDEN, INTER), (INTER, HIDDEN)]:
+        w = PackedSet(K, N, dev, gen)
+        x = torch.randn((M, K), device=dev, generator=gen).half()
+        gi = (torch.arange(K, device=dev) // GS).to(torch.int32)
+        f = lambda: QL.matmul248(x, w.qweight, w.scales, w.qzeros, gi, BITS, 15)
+        y = f()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            y = f()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        W = QL.dequantize(w.qweight, w.scales, w.qzeros, None, BITS, GS)
+        yd = x @ W
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            yd = x @ W
+        e1.record()
+        torch.cuda.synchronize()
+        msd = e0.elapsed_time(e1) / reps
+        tf, tfd = 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / msd / 1e9
+        out['shapes']['%dx%d' % (K, N)] = {'ms': round(ms, 3), 'TFLOPs': round(tf, 1), 'frac_of_2.5PF': round(tf / 2500.0, 4),
+                                           'hipblaslt_dense_TFLOPs': round(tfd, 1), 'vs_hipblaslt': round(tf / tfd, 3),
+                                           'max_abs_diff_vs_dense': float((y.float() - yd.float()).abs().max())}
+        del w, x, y, yd, W
+        torch.cuda.empty_cache()
+    return out
+
+
+def config4_leg(dev):
+    """BASELINE config 4 (reported only): LLaMA-7B-shaped 3-bit no-group and 4-bit g128 act-order, batch 1, cold weights,
+    through the drop-in matmul248 (3-bit: rowwave3 kernel, an extension -- the reference raises for bits == 3,
+    quant_linear.py:308-309; act-order: rows sorted by group at load + stripe16 kernel with the x gather fused)."""
+    from quant import quant_linear as QL
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(4)
+
+    def make(bits, gs, K, N, act):
+        G = 1 if gs == -1 else K // gs
+        qw = torch.randint(-2**31, 2**31 - 1, (K // 32 * bits, N), dtype=torch.int32, device=dev, generator=gen)
+        qz = torch.randint(-2**31, 2**31 - 1, (G, N // 32 * bits), dtype=torch.int32, device=dev, generator=gen)
+        sc = (torch.rand((G, N), device=dev, generator=gen) * 0.01 + 0.001).half()
+        gi = (torch.arange(K, device=dev) // (K if gs == -1 else gs)).to(torch.int32)
+        if act:
+            gi = gi[torch.argsort(torch.randperm(K, device=dev, generator=gen))].contiguous()
+        return qw, sc, qz, gi
+
+    out = {}
+    for label, bits, gs, act in [('w3_nogroup', 3, -1, False), ('w4_g128_act_order', 4, 128, True)]:
+        out[label] = {}
+        for K, N in [(HIDDEN, HIDDEN), (HIDDEN, 3 * HIDDEN), (INTER, HIDDEN), (HIDDEN, INTER)]:
+            G = 1 if gs == -1 else K // gs
+            nb = 4 * (K * bits // 32) * N + 4 * G * (N * bits // 32) + 2 * G * N + 2 * K + 2 * N + (4 * K if act else 0)
+            nsets = int(300e6 // nb) + 1
+            sets = [make(bits, gs, K, N, act) for _ in range(nsets)]
+            x = torch.randn((1, K), device=dev, generator=gen).half()
+            us = _time_cold(lambda i: QL.matmul248(x, sets[i][0], sets[i][1], sets[i][2], sets[i][3], bits, 2**bits - 1), nsets)
+            out[label]['%dx%d' % (K, N)] = {'us_per_launch': round(us, 3), 'GBps': round(nb / us / 1e3, 1),
+                                            'frac_of_8TBps': round(nb / us / 1e3 / HBM_PEAK_GBS, 4)}
+            del sets
+            torch.cuda.empty_cache()
     return out
 
 
@@ -298,6 +415,9 @@ def main():
     ap.add_argument('--no-decode', action='store_true')
     ap.add_argument('--no-per-shape', action='store_true')
     ap.add_argument('--eager', action='store_true', help='time eager launches instead of hipGraph replay')
+    ap.add_argument('--kernel', choices=('stripe', 'rowwave'), default='stripe', help='decode matvec kernel family (A/B runs)')
+    ap.add_argument('--no-prefill', action='store_true')
+    ap.add_argument('--no-config4', action='store_true')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -312,7 +432,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
 
-    work = DecodeLinears(dev, seed=rank)
+    work = DecodeLinears(dev, seed=rank, kernel=args.kernel)
     for _ in range(2):
         work.step()
     torch.cuda.synchronize()
@@ -361,10 +481,13 @@ def main():
             'config': {'workload': 'LLaMA-7B-shaped 4-bit g128 matvec, batch=1 seq=1 (BASELINE configs[1]): 32 layers x '
                                    '{qkv 4096x12288, o 4096x4096, gate/up+SiLU 2x4096x11008, down 11008x4096}',
                        'launches_per_step': work.launches_per_step, 'algorithmic_bytes_per_step': work.bytes_per_step,
-                       'launch_mode': 'eager' if args.eager else 'hipGraph replay', 'parallelism': 'dp%d replicas' % world},
+                       'launch_mode': 'eager' if args.eager else 'hipGraph replay', 'parallelism': 'dp%d replicas' % world,
+                       'weight_layout': 'stripe16 image built at load time from the checkpoint buffers (gptq_stripe_repack)'
+                                        if args.kernel == 'stripe' else 'checkpoint layout'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': 'gptq::gemv_rowwave_kernel<4,8,*> (all 128 launches/step: 96 single-set + 32 fused gate/up)',
+                         'kernel': ('gptq::stripe_gemv_kernel<NU,NS,*> (all 128 launches/step: 96 single-set + 32 fused gate/up)'
+                                    if args.kernel == 'stripe' else 'gptq::gemv_rowwave_kernel<4,8,*> (all 128 launches/step)'),
                          'avg_launch_us': round(us_per_launch, 3), 'algorithmic_bytes_per_launch': int(bytes_per_launch)},
         }
         # the side legs run at N = 1 only (the other ranks would sit in the final barrier meanwhile)
@@ -374,6 +497,16 @@ def main():
                 out['per_shape_llama65b_reported_only'] = larger_model_shapes(dev)
             except Exception as e:
                 out['per_shape_llama65b_reported_only'] = {'error': repr(e)[:200]}
+        if not args.no_prefill and world == 1:
+            try:
+                out['prefill_config3_reported_only'] = prefill_leg(dev)
+            except Exception as e:
+                out['prefill_config3_reported_only'] = {'error': repr(e)[:200]}
+        if not args.no_config4 and world == 1:
+            try:
+                out['config4_reported_only'] = config4_leg(dev)
+            except Exception as e:
+                out['config4_reported_only'] = {'error': repr(e)[:200]}
         if not args.no_decode and world == 1:
             try:
                 out['decode'] = decode_tokens_per_s(dev)

@@ -122,7 +122,8 @@ static int run_rowwave3(const Problem &q, hipStream_t s) {
     if (split_k > (q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE)) split_k = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
     // the per-column combine words live in the first SPLITK_TICKET_OFFSET bytes of the workspace (the rest belongs
     // to the stream kernel's tickets / partial tiles and is not zero): wider layers run without a K split
-    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)q.N * 8 && (size_t)q.N * 8 <= SPLITK_TICKET_OFFSET;
+    const size_t ws_need = (size_t)q.N * 8 * (q.fused2 ? 2 : 1);   // one combine word per column (two for gate/up)
+    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= ws_need && ws_need <= SPLITK_TICKET_OFFSET;
     if (split_k > 1 && !ws_ok) {
         if (fs >= 1) return GPTQ_E_WORKSPACE;
         split_k = 1;
@@ -176,7 +177,8 @@ static int run_rowwave(const Problem &q, hipStream_t s) {
     if (split_k > split_max) split_k = split_max;
     // the per-column combine words live in the first SPLITK_TICKET_OFFSET bytes of the workspace (the rest belongs
     // to the stream kernel's tickets / partial tiles and is not zero): wider layers run without a K split
-    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= (size_t)q.N * 8 && (size_t)q.N * 8 <= SPLITK_TICKET_OFFSET;
+    const size_t ws_need = (size_t)q.N * 8 * (q.fused2 ? 2 : 1);   // one combine word per column (two for gate/up)
+    const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= ws_need && ws_need <= SPLITK_TICKET_OFFSET;
     if (split_k > 1 && !ws_ok) {
         if (fs >= 1) return GPTQ_E_WORKSPACE;
         split_k = 1;
@@ -257,7 +259,7 @@ static int run_rowwave_mr(const Problem &q, hipStream_t s) {
     if (split_k > nchunk) split_k = nchunk;
     const int split_max = q.fused2 ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE;
     if (split_k > split_max) split_k = split_max;
-    const size_t words = (size_t)q.M * q.N * 8;
+    const size_t words = (size_t)q.M * q.N * 8 * (q.fused2 ? 2 : 1);
     const bool ws_ok = q.ws && aligned(q.ws, 8) && q.ws_bytes >= words && words <= SPLITK_TICKET_OFFSET;
     if (split_k > 1 && !ws_ok) return GPTQ_E_VARIANT;   // the per-row / stream paths handle it
     GemvParams p;
@@ -384,12 +386,6 @@ int gptq_query(int what) {
         case GPTQ_Q_SKINNY_MAX_M: return SKINNY_MAX_M;
         case GPTQ_Q_WORKSPACE_BYTES: return (int)WS_BYTES;
         case GPTQ_Q_NUM_GEMV_VARIANTS: return GEMV_NUM_VARIANTS;
-        case GPTQ_Q_CHAIN_WORKGROUPS: {
-            int dev = 0, cus = 0;
-            if (hipGetDevice(&dev) != hipSuccess) return -1;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
-            return cus;
-        }
     }
     return -1;
 }
@@ -411,7 +407,6 @@ const char *gptq_strerror(int code) {
 
 int gptq_set_gemv_variant(int variant) { return g_force_variant.exchange(variant); }
 int gptq_set_split_k(int split_k) { return g_force_split_k.exchange(split_k); }
-int gptq_set_chain_depth(int depth) { return chain_set_depth(depth); }
 void *gptq_set_debug_buffer(void *buf) { return g_debug_buffer.exchange(buf); }
 int gptq_set_gemm_kernel(int version) {
     return (version == 2 || version == 3 || (version >= 100 && version <= 104)) ? gemm_set_version(version) : GPTQ_E_VARIANT;
@@ -671,74 +666,50 @@ int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k
                                     (float *)workspace, heads, t_max, base, scale, (hipStream_t)stream);
 }
 
-// ---- persistent matvec chain ----
-static size_t chain_off_counters(int n) { return (size_t)n * sizeof(ChainOpDev); }
-static size_t chain_off_status(int n) { return chain_off_counters(n) + (size_t)n * CHAIN_NCNT * CHAIN_CNT_STRIDE * 4; }
-static size_t chain_off_end(int n) { return chain_off_status(n) + 128; }
+// ---- stripe16: no-split-K decode GEMV on a load-time repacked copy (stripe.hip) ----
+size_t gptq_stripe_bytes(int K, int N, int bits, int groupsize, int nsets) { return stripe_total_bytes(K, N, bits, groupsize, nsets); }
 
-size_t gptq_chain_state_bytes(int n_ops) { return n_ops > 0 ? chain_off_end(n_ops) : 0; }
-size_t gptq_chain_status_offset(int n_ops) { return n_ops > 0 ? chain_off_status(n_ops) : 0; }
-
-int gptq_chain_encode(const gptq_chain_op *ops, int n_ops, int bits, int num_workgroups, void *state_host, size_t state_bytes) {
-    if (!ops || !state_host) return GPTQ_E_NULL;
-    if (bits != 4) return bits == 2 || bits == 3 || bits == 8 ? GPTQ_E_VARIANT : GPTQ_E_BITS;
-    if (n_ops <= 0 || num_workgroups <= 0) return GPTQ_E_SHAPE;
-    if (state_bytes < gptq_chain_state_bytes(n_ops)) return GPTQ_E_WORKSPACE;
-    memset(state_host, 0, gptq_chain_state_bytes(n_ops));
-    ChainOpDev *d = (ChainOpDev *)state_host;
-    const int G = num_workgroups;
-    for (int i = 0; i < n_ops; i++) {
-        const gptq_chain_op &o = ops[i];
-        const bool fused = o.qweight_up != nullptr;
-        if (!o.x || !o.y || !o.qweight || !o.scales || !o.qzeros) return GPTQ_E_NULL;
-        if (fused && (!o.scales_up || !o.qzeros_up)) return GPTQ_E_NULL;
-        if (o.K <= 0 || o.N <= 0 || o.groupsize <= 0 || o.K % 32 != 0 || o.N % 32 != 0) return GPTQ_E_SHAPE;   // the library-wide contract
-        if (o.K % 256 != 0 || o.K > CHAIN_MAX_K || o.N > CHAIN_MAX_N) return GPTQ_E_VARIANT;
-        int gshift = -1;
-        if (o.groupsize < o.K) {
-            if (o.groupsize < 64 || (o.groupsize & (o.groupsize - 1))) return GPTQ_E_VARIANT;
-            gshift = 0;
-            while ((8 << gshift) < o.groupsize) gshift++;
-        }
-        if (!aligned(o.x, 16) || !aligned(o.y, 2) || !aligned(o.qweight, 16) || !aligned(o.scales, 8) || !aligned(o.qzeros, 4)) return GPTQ_E_ALIGN;
-        if (fused && (!aligned(o.qweight_up, 16) || !aligned(o.scales_up, 8) || !aligned(o.qzeros_up, 4))) return GPTQ_E_ALIGN;
-        if (o.norm_weight && !aligned(o.norm_weight, 16)) return GPTQ_E_ALIGN;
-        ChainOpDev &e = d[i];
-        e.qw[0] = (const uint32_t *)o.qweight; e.sc[0] = (const half_t *)o.scales; e.qz[0] = o.qzeros;
-        e.qw[1] = (const uint32_t *)o.qweight_up; e.sc[1] = (const half_t *)o.scales_up; e.qz[1] = o.qzeros_up;
-        e.x = (const half_t *)o.x; e.y = (half_t *)o.y; e.resid = (const half_t *)o.residual; e.nw = (const half_t *)o.norm_weight;
-        e.eps = o.norm_eps;
-        e.K = o.K; e.N = o.N; e.rows = o.K / 8; e.tiles = (o.N + 255) / 256; e.nchunk = e.rows / 32; e.gshift = gshift;
-        e.ns = fused ? 2 : 1; e.rows_per_wave = 8;
-        // K slices per tile: minimise (rounds of jobs over the G workgroups) x (chunks per job); ties -> fewer atomics
-        const int smax = std::min(e.nchunk, fused ? SPLITK_MAX_PAIR : SPLITK_MAX_SINGLE);
-        long best = -1;
-        for (int S = 1; S <= smax; S++) {
-            const long rounds = ((long)e.tiles * S + G - 1) / G, cpj = (e.nchunk + S - 1) / S;
-            if (best < 0 || rounds * cpj < best) { best = rounds * cpj; e.S = S; }
-        }
-        e.jobs = e.tiles * e.S;
-        e.dep_count = i > 0 ? d[i - 1].N : 0;
-    }
-    return 0;
+int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *qweight_up, const void *scales_up,
+                       const int32_t *qzeros_up, void *stripes, size_t stripes_bytes, int K, int N, int bits, int groupsize,
+                       gptq_stream_t stream) {
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0) return GPTQ_E_SHAPE;
+    if (!qweight || !scales || !qzeros || !stripes) return GPTQ_E_NULL;
+    const bool fused = qweight_up != nullptr;
+    if (fused && (!scales_up || !qzeros_up)) return GPTQ_E_NULL;
+    const size_t need = stripe_total_bytes(K, N, bits, groupsize, fused ? 2 : 1);
+    if (need == 0) return GPTQ_E_VARIANT;
+    if (stripes_bytes < need) return GPTQ_E_WORKSPACE;
+    if (!aligned(qweight, 4) || !aligned(scales, 2) || !aligned(qzeros, 4) || !aligned(stripes, 16)) return GPTQ_E_ALIGN;
+    return stripe_repack_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, (const uint32_t *)qweight_up,
+                                (const half_t *)scales_up, qzeros_up, stripes, K, N, groupsize, (hipStream_t)stream);
 }
 
-int gptq_chain_run_f16(void *state_dev, int n_ops, int bits, int max_k, int num_workgroups, int flags, void *workspace,
-                       size_t workspace_bytes, gptq_stream_t stream) {
-    if (!state_dev || !workspace) return GPTQ_E_NULL;
-    if (bits != 4) return GPTQ_E_VARIANT;
-    if (n_ops <= 0 || num_workgroups <= 0 || max_k <= 0 || max_k > CHAIN_MAX_K) return GPTQ_E_SHAPE;
-    if (workspace_bytes < (size_t)2 * CHAIN_MAX_N * sizeof(u64_t)) return GPTQ_E_WORKSPACE;
-    if (!aligned(state_dev, 128) || !aligned(workspace, 8)) return GPTQ_E_ALIGN;
-    u64_t *dbg = (flags & 1) ? (u64_t *)g_debug_buffer.load() : nullptr;
-    if ((flags & 1) && !dbg) return GPTQ_E_NULL;
-    char *st = (char *)state_dev;
-    // one memset covers the arrival counters and the status line behind them
-    hipError_t e = hipMemsetAsync(st + chain_off_counters(n_ops), 0, chain_off_end(n_ops) - chain_off_counters(n_ops), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    return chain_launch(bits, (const ChainOpDev *)st, n_ops, max_k, (uint32_t *)(st + chain_off_counters(n_ops)), (u64_t *)workspace,
-                        (uint32_t *)(st + chain_off_status(n_ops)), dbg,
-                        num_workgroups, (hipStream_t)stream);
+int gptq_stripe_matvec_f16(const void *x, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int K, int N, int bits,
+                           int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm, gptq_stream_t stream) {
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
+    if (!x || !stripes || !y) return GPTQ_E_NULL;
+    const int gq = stripe_gq_shift(K, N, bits, groupsize);
+    if (gq == -2 || (nsets == 2 && bias)) return GPTQ_E_VARIANT;
+    if (stripes_bytes < stripe_total_bytes(K, N, bits, groupsize, nsets)) return GPTQ_E_WORKSPACE;
+    if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || (norm_weight && !aligned(norm_weight, 16)) || (perm && !aligned(perm, 16)))
+        return GPTQ_E_ALIGN;
+    StripeParams p{};
+    p.x = (const half_t *)x;
+    p.R = (const uint32_t *)stripes;
+    p.tab = (const uint32_t *)((const char *)stripes + stripe_tab_offset(K, N, nsets));
+    p.y = (half_t *)y;
+    p.bias = (const half_t *)bias;
+    p.norm_w = (const half_t *)norm_weight;
+    p.norm_eps = norm_eps;
+    p.xperm = perm;
+    p.K = K;
+    p.N = N;
+    p.G = groupsize >= K ? 1 : K / groupsize;
+    p.NS = nsets;
+    p.gq_shift = gq;
+    return stripe_gemv_dispatch(p, (hipStream_t)stream);
 }
 
 // ---- GPTQ solver: the sequential loop of one column block (gptq_solver.hip) ----

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) gemv_rowwave_kernel(
     if (n < (uint32_t)N) {
         bool mine = true;
         if (S > 1) {
-            if constexpr (FUSED2) mine = splitk_add2(ws + n, t0, t1, S, t0, t1);
+            if constexpr (FUSED2) mine = splitk_add2(ws + 2 * (size_t)n, t0, t1, S, t0, t1);
             else mine = splitk_add1(ws + n, t0, S, t0);
         }
         if (mine) {
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256) gemv_rowwave3_kernel(const uint32_t *__re
     if (n < (uint32_t)N) {
         bool mine = true;
         if (S > 1) {
-            if constexpr (FUSED2) mine = splitk_add2(ws + n, t0, t1, S, t0, t1);
+            if constexpr (FUSED2) mine = splitk_add2(ws + 2 * (size_t)n, t0, t1, S, t0, t1);
             else mine = splitk_add1(ws + n, t0, S, t0);
         }
         if (mine) {
@@ -752,9 +752,9 @@ __global__ void __launch_bounds__(256) gemv_rowwave_mr_kernel(const uint32_t *__
         if constexpr (FUSED2) t1 = red[m][1][0][t] + red[m][1][1][t] + red[m][1][2][t] + red[m][1][3][t];
         bool mine = true;
         if (S > 1) {
-            u64_t *word = ws + (size_t)m * (uint32_t)N + n;
-            if constexpr (FUSED2) mine = splitk_add2(word, t0, t1, S, t0, t1);
-            else mine = splitk_add1(word, t0, S, t0);
+            const size_t wi = (size_t)m * (uint32_t)N + n;
+            if constexpr (FUSED2) mine = splitk_add2(ws + 2 * wi, t0, t1, S, t0, t1);
+            else mine = splitk_add1(ws + wi, t0, S, t0);
         }
         if (mine) {
             float v = t0;
@@ -930,9 +930,9 @@ __global__ void __launch_bounds__(256) gemv_rowwave_mfma_kernel(const uint32_t *
         if constexpr (FUSED2) t1 = red[m][1][0][t] + red[m][1][1][t] + red[m][1][2][t] + red[m][1][3][t];
         bool mine = true;
         if (S > 1) {
-            u64_t *word = ws + (size_t)m * (uint32_t)N + n;
-            if constexpr (FUSED2) mine = splitk_add2(word, t0, t1, S, t0, t1);
-            else mine = splitk_add1(word, t0, S, t0);
+            const size_t wi = (size_t)m * (uint32_t)N + n;
+            if constexpr (FUSED2) mine = splitk_add2(ws + 2 * wi, t0, t1, S, t0, t1);
+            else mine = splitk_add1(ws + wi, t0, S, t0);
         }
         if (mine) {
             float v = t0;

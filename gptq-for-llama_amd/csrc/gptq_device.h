@@ -155,40 +155,55 @@ GPTQ_DEV float wave_sum_xor(float v, int from) {
 // slice whose returned value completes the count owns the total: it decodes it, stores zero
 // back (the workspace is all-zero between launches) and writes the output.  No ticket, no
 // second pass, no fence; integer addition makes the sum independent of arrival order.
-//   single value : [63:56] count (S <= 128) | [55:0] sum of (trunc(v * 2^24) + 2^49), |v| <= 2^24
-//   value pair   : [63:58] count (S <= 16)  | [57:29] b | [28:0] a, fields = round(v * 2^15) + 2^24
-//                  (fused gate/up kernel: |partial| < 512, resolution 2^-15)
+//   word : [63:56] count (S <= 64) | [55:0] sum of (trunc(v * 2^24) + 2^49), |v| <= 2^24
+//          64 slices add at most 64 * (2^49 + 2^48) = 1.5 * 2^55 < 2^56: the sum never carries into the count
+//          (with S = 128 it would: 128 * 2^49 = 2^56 -- the arrival count would read S + 1 and no slice would own it).
+// The fused gate/up kernel keeps TWO such words per column (gate, up): same range and resolution as the single
+// combine -- no clamp on the partial sums (the reference accumulates in fp32 without range limits,
+// fused_mlp.py:128-160).
 // ---------------------------------------------------------------------------------------
 typedef unsigned long long u64_t;
-constexpr int SPLITK_MAX_SINGLE = 128;  // 128 * (2^49 + 2^48) < 2^56
-constexpr int SPLITK_MAX_PAIR = 16;     // 16 * 2^25 <= 2^29
+constexpr int SPLITK_MAX_SINGLE = 64;
+constexpr int SPLITK_MAX_PAIR = 64;
 
-GPTQ_DEV bool splitk_add1(u64_t *word, float v, int S, float &total) {
+GPTQ_DEV u64_t splitk_encode(float v) {
     const float c = fminf(fmaxf(v, -16777216.0f), 16777216.0f);               // |v| <= 2^24 (fp16 max is 65504)
     const long long fx = (long long)(c * 16777216.0f) + (1LL << 49);            // exact: power-of-two scale
-    const u64_t add = (u64_t)fx + (1ULL << 56);
+    return (u64_t)fx + (1ULL << 56);
+}
+GPTQ_DEV float splitk_decode(u64_t now, int S) {
+    const long long sum = (long long)(now & ((1ULL << 56) - 1)) - (long long)S * (1LL << 49);
+    return (float)sum * (1.0f / 16777216.0f);
+}
+
+GPTQ_DEV bool splitk_add1(u64_t *word, float v, int S, float &total) {
+    const u64_t add = splitk_encode(v);
     const u64_t old = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const u64_t now = old + add;
     if ((int)(now >> 56) != S) return false;
     __hip_atomic_store(word, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long sum = (long long)(now & ((1ULL << 56) - 1)) - (long long)S * (1LL << 49);
-    total = (float)sum * (1.0f / 16777216.0f);
+    total = splitk_decode(now, S);
     return true;
 }
 
-GPTQ_DEV bool splitk_add2(u64_t *word, float a, float b, int S, float &ta, float &tb) {
-    const float lim = 511.99f;
-    const long long fa = (long long)rintf(fminf(fmaxf(a, -lim), lim) * 32768.0f) + (1LL << 24);
-    const long long fb = (long long)rintf(fminf(fmaxf(b, -lim), lim) * 32768.0f) + (1LL << 24);
-    const u64_t add = (u64_t)fa | ((u64_t)fb << 29) | (1ULL << 58);
-    const u64_t old = __hip_atomic_fetch_add(word, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64_t now = old + add;
-    if ((int)(now >> 58) != S) return false;
-    __hip_atomic_store(word, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long sa = (long long)(now & ((1ULL << 29) - 1)) - (long long)S * (1LL << 24);
-    const long long sb = (long long)((now >> 29) & ((1ULL << 29) - 1)) - (long long)S * (1LL << 24);
-    ta = (float)sa * (1.0f / 32768.0f);
-    tb = (float)sb * (1.0f / 32768.0f);
+// words[0] = gate, words[1] = up.  Both atomics are in flight together; the slice that completes the count of word 0
+// owns the column.  Atomics to different addresses may retire out of order, so in the rare case that another
+// slice's addend to word 1 is still in flight the owner re-reads word 1 until its count is complete (the other
+// slice issued that atomic before the one the owner has already seen: it needs nothing from the owner to land;
+// the spin is bounded anyway).
+GPTQ_DEV bool splitk_add2(u64_t *words, float a, float b, int S, float &ta, float &tb) {
+    const u64_t addb = splitk_encode(b), adda = splitk_encode(a);
+    const u64_t oldb = __hip_atomic_fetch_add(words + 1, addb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64_t olda = __hip_atomic_fetch_add(words, adda, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64_t nowa = olda + adda;
+    if ((int)(nowa >> 56) != S) return false;
+    u64_t nowb = oldb + addb;
+    for (int spin = 0; (int)(nowb >> 56) != S && spin < (1 << 22); spin++)
+        nowb = __hip_atomic_load(words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(words, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(words + 1, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ta = splitk_decode(nowa, S);
+    tb = splitk_decode(nowb, S);
     return true;
 }
 

@@ -64,26 +64,24 @@ int dequant_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, cons
 int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 
-// ---- persistent matvec chain (chain.hip) ----
-constexpr int CHAIN_NCNT = 16;         // striped arrival counters per op
-constexpr int CHAIN_CNT_STRIDE = 32;   // uint32 per counter (128-byte lines)
-constexpr int CHAIN_MAX_N = 16384;     // two alternating combine-word regions inside the first 256 KiB of the workspace
-constexpr int CHAIN_MAX_K = 16384;     // x of one op staged in LDS (32 KiB)
-struct ChainOpDev {                    // device-side op descriptor, 128 bytes
-    const uint32_t *qw[2];
-    const half_t *sc[2];
-    const int32_t *qz[2];
+// ---- stripe16: no-split-K GEMV on a load-time repacked copy (stripe.hip) ----
+struct StripeParams {
     const half_t *x;
+    const uint32_t *R;     // [N/16][K/128][NS][64][4]
+    const uint32_t *tab;   // half2 [N/16][NS][G][16] {scale, zero + 1}
     half_t *y;
-    const half_t *resid;
-    const half_t *nw;
-    float eps;
-    int32_t K, N, rows, tiles, S, nchunk, gshift, ns, jobs, dep_count, rows_per_wave;
+    const half_t *bias;
+    const half_t *norm_w;  // non-NULL: RMS-normalise x while it is staged
+    float norm_eps;
+    const int32_t *xperm;  // non-NULL: x (and norm_w) gathered through this permutation
+    int K, N, G, NS, gq_shift;
 };
-static_assert(sizeof(ChainOpDev) == 128, "ChainOpDev layout");
-int chain_set_depth(int d);  // development: weight tasks in flight per compute wave (2..4); returns the previous value
-int chain_launch(int bits, const ChainOpDev *ops_dev, int n_ops, int max_k, uint32_t *counters, u64_t *ws, uint32_t *status, u64_t *dbg,
-                 int nwg, hipStream_t s);
+int stripe_gq_shift(int K, int N, int bits, int groupsize);            // log2(groupsize / 32), -1 one group, -2 ineligible
+size_t stripe_tab_offset(int K, int N, int nsets);
+size_t stripe_total_bytes(int K, int N, int bits, int groupsize, int nsets);
+int stripe_repack_launch(const uint32_t *qw0, const half_t *sc0, const int32_t *qz0, const uint32_t *qw1, const half_t *sc1,
+                         const int32_t *qz1, void *out, int K, int N, int groupsize, hipStream_t s);
+int stripe_gemv_dispatch(const StripeParams &p, hipStream_t s);
 
 int gptq_block_launch(const float *W, int64_t ldw, const float *Hinv, int64_t ldh, int rows, int i1, int count, int groupsize, int maxq,
                       const float *scale, const float *zero, int64_t ldg, float *Q, int64_t ldq, float *Err, int64_t lde, float *loss_rows,

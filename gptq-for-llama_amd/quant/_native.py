@@ -27,7 +27,6 @@ _SIGNATURES = {
     'gptq_query': [c_int],
     'gptq_set_gemv_variant': [c_int],
     'gptq_set_split_k': [c_int],
-    'gptq_set_chain_depth': [c_int],
     'gptq_set_debug_buffer': [c_void_p],
     'gptq_set_gemm_kernel': [c_int],
     'gptq_matmul248_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -68,19 +67,13 @@ _SIGNATURES = {
                              c_float, c_void_p],
     'gptq_solver_block_f32': [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
                               c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p],
-    'gptq_chain_state_bytes': [c_int],
-    'gptq_chain_status_offset': [c_int],
-    'gptq_chain_encode': [c_void_p, c_int, c_int, c_int, c_void_p, c_size_t],
-    'gptq_chain_run_f16': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
+    'gptq_stripe_bytes': [c_int, c_int, c_int, c_int, c_int],
+    'gptq_stripe_repack': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
+                           c_void_p],
+    'gptq_stripe_matvec_f16': [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float,
+                               c_void_p, c_void_p],
 }
 
-
-class ChainOp(ctypes.Structure):
-    """struct gptq_chain_op (include/gptq_mi355x.h)"""
-    _fields_ = [('x', c_void_p), ('qweight', c_void_p), ('scales', c_void_p), ('qzeros', c_void_p),
-                ('qweight_up', c_void_p), ('scales_up', c_void_p), ('qzeros_up', c_void_p), ('y', c_void_p),
-                ('residual', c_void_p), ('norm_weight', c_void_p), ('norm_eps', c_float), ('K', c_int), ('N', c_int),
-                ('groupsize', c_int)]
 
 EXPORTS = sorted(list(_SIGNATURES) + ['gptq_strerror'])
 
@@ -107,8 +100,7 @@ def lib():
                 fn.restype = c_int
             L.gptq_set_debug_buffer.restype = c_void_p
             L.gptq_decode_attn_workspace_bytes.restype = c_size_t
-            for name in ('gptq_chain_state_bytes', 'gptq_chain_status_offset'):
-                getattr(L, name).restype = c_size_t
+            L.gptq_stripe_bytes.restype = c_size_t
             L.gptq_strerror.argtypes = [c_int]
             L.gptq_strerror.restype = ctypes.c_char_p
             _lib = L

@@ -163,8 +163,12 @@ class DecodeEngine:
                                   mlp.groupsize, mlp.infeatures, mlp.intermediate_size),
                 theta=float(attn.rope_theta)))
             L = self.layers[-1]   # gate and up share their input, hence (normally) their act-order permutation: checked ONCE here
-            L['gate']['pair_sorted'] = (L['gate']['srt'] is not None and L['up']['srt'] is not None and
-                                        bool(torch.equal(L['gate']['srt'][1], L['up']['srt'][1])))
+            g, u = L['gate'], L['up']
+            g['pair_sorted'] = (g['srt'] is not None and u['srt'] is not None and bool(torch.equal(g['srt'][1], u['srt'][1])))
+            g['st2'] = None     # gate and up in ONE stripe16 image (silu(gate) * up in the kernel epilogue)
+            if g['bits'] == 4 and ((g['gi'] is None and u['gi'] is None) or g['pair_sorted']):
+                a, b = (g['srt'][0], u['srt'][0]) if g['pair_sorted'] else (g['qw'], u['qw'])
+                g['st2'] = quant_linear.stripe_copy(a, g['sc'], g['qz'], g['bits'], g['gs'], up=(b, u['sc'], u['qz']))
         H, I = self.hidden, cfg.intermediate_size
         f16 = dict(dtype=torch.float16, device=dev)
         self.ids = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -192,7 +196,10 @@ class DecodeEngine:
             gi = quant_linear._int32c(g_idx[:K])
         qw = quant_linear._int32c(qweight)
         srt = quant_linear.act_order_sorted(qw, gi, K, groupsize, bits) if (gi is not None and bits == 4) else None
-        return dict(qw=qw, sc=scales, qz=quant_linear._int32c(qzeros), gi=gi, bits=bits, gs=groupsize, K=K, N=N, bias=bias, srt=srt)
+        qz = quant_linear._int32c(qzeros)
+        # stripe16 image (csrc/stripe.hip) of the layer, or of its group-sorted rows for an act-order layer: the decode kernel
+        st = quant_linear.stripe_copy(srt[0] if srt is not None else qw, scales, qz, bits, groupsize) if (gi is None or srt is not None) else None
+        return dict(qw=qw, sc=scales, qz=qz, gi=gi, bits=bits, gs=groupsize, K=K, N=N, bias=bias, srt=srt, st=st)
 
     def _pack(self, ql):
         return self._pack_raw(ql.qweight, ql.scales, ql.qzeros, ql.g_idx, ql.bits, ql.groupsize, ql.infeatures, ql.outfeatures,
@@ -204,6 +211,10 @@ class DecodeEngine:
             raise NotImplementedError('bias + fused residual')
         b = residual if residual is not None else w['bias']
         ptr = self.native.ptr
+        if w['st'] is not None:       # stripe16: no K split, no workspace (act-order: x gathered through perm in the kernel)
+            quant_linear.stripe_matvec(x, w['st'], y, w['K'], w['N'], w['bits'], w['gs'], bias=b,
+                                       perm=w['srt'][1] if w['srt'] is not None else None)
+            return
         if w['srt'] is not None:      # act-order layer: group-sorted copy + fused x gather
             qs, perm = w['srt']
             rc = self.lib.gptq_matmul248_sorted_f16(x.data_ptr(), w['K'], perm.data_ptr(), qs.data_ptr(), w['sc'].data_ptr(),
@@ -223,6 +234,10 @@ class DecodeEngine:
     def _norm_gemv(self, x, nw, w, y, s):
         """y = QuantLinear(rmsnorm(x)): one launch when the fused kernel serves the shape, else two."""
         ptr = self.native.ptr
+        if self.fuse_norm and w['st'] is not None:      # RMSNorm fused into the staging of x (every workgroup sees all of x)
+            quant_linear.stripe_matvec(x, w['st'], y, w['K'], w['N'], w['bits'], w['gs'], bias=w['bias'], norm_weight=nw, eps=self.eps,
+                                       perm=w['srt'][1] if w['srt'] is not None else None)
+            return
         if self.fuse_norm and w['bias'] is None and w['srt'] is not None:      # act-order: norm + gather + GEMV in one launch
             qs, perm = w['srt']
             rc = self.lib.gptq_rmsnorm_sorted_f16(x.data_ptr(), nw.data_ptr(), self.eps, perm.data_ptr(), qs.data_ptr(), w['sc'].data_ptr(),
@@ -243,6 +258,14 @@ class DecodeEngine:
 
     def _norm_mlp(self, x, nw, g, u, c, s):
         ptr = self.native.ptr
+        if g.get('st2') is not None:
+            perm = g['srt'][1] if g.get('pair_sorted') else None
+            if self.fuse_norm:
+                quant_linear.stripe_matvec(x, g['st2'], c, g['K'], g['N'], g['bits'], g['gs'], nsets=2, norm_weight=nw, eps=self.eps, perm=perm)
+            else:
+                self._norm(x, nw, self.h, s)
+                quant_linear.stripe_matvec(self.h, g['st2'], c, g['K'], g['N'], g['bits'], g['gs'], nsets=2, perm=perm)
+            return
         if g.get('pair_sorted') and self.fuse_norm:
             rc = self.lib.gptq_rmsnorm_sorted_f16(x.data_ptr(), nw.data_ptr(), self.eps, g['srt'][1].data_ptr(), g['srt'][0].data_ptr(),
                                                   g['sc'].data_ptr(), g['qz'].data_ptr(), u['srt'][0].data_ptr(), u['sc'].data_ptr(),

@@ -12,18 +12,22 @@ PREFILL_SPLIT_M = 64
 
 
 def _same_perm(a, b):
-    """a == b elementwise, decided once per tensor pair (the comparison synchronises: not inside a hipGraph capture)."""
+    """a == b elementwise, decided once per tensor pair (the comparison synchronises: not inside a hipGraph capture).
+    The memo holds a WEAK reference to b and is valid only while that very object is alive (object ids and
+    addresses are recycled)."""
+    import weakref
+    from .quant_linear import _ver
     if a is b:
         return True
     memo = getattr(a, '_gptq_same_as', None)
-    key = (id(b), a._version, b._version)
-    if memo is None or memo[0] != key:
-        memo = (key, bool(torch.equal(a, b)))
+    key = (_ver(a), _ver(b))
+    if memo is None or memo[0]() is not b or memo[1] != key:
+        memo = (weakref.ref(b), key, bool(torch.equal(a, b)))
         try:
             a._gptq_same_as = memo
         except Exception:  # pragma: no cover
             pass
-    return memo[1]
+    return memo[2]
 
 
 def fused_gate_up(x, gate, up, bits, groupsize):
@@ -35,13 +39,28 @@ def fused_gate_up(x, gate, up, bits, groupsize):
     gis = []
     for (qw, sc, qz, gi) in (gate, up):
         gis.append(None if (gi is None or g_idx_is_trivial(gi, K, groupsize)) else _int32c(gi[:K]))
+    if M == 1 and bits == 4 and all(gi is None for gi in gis):
+        # decode: gate and up packed into ONE stripe16 image, silu(gate) * up in the kernel epilogue
+        from .quant_linear import stripe_copy, stripe_matvec
+        st = stripe_copy(_int32c(gate[0]), gate[1], _int32c(gate[2]), bits, groupsize, up=(_int32c(up[0]), up[1], _int32c(up[2])))
+        if st is not None:
+            with torch.cuda.device(x.device):
+                c = torch.empty((M, N), device=x.device, dtype=torch.float16)
+                stripe_matvec(x2, st, c, K, N, bits, groupsize, nsets=2)
+            return c
     if M == 1 and bits == 4 and all(gi is not None for gi in gis):
         # act-order MLP at decode: gate and up share their input, hence their act-order permutation -> one x gather,
         # two group-sorted weight copies (cached on the tensors), the trivial-g_idx fused kernel
-        from .quant_linear import act_order_sorted
+        from .quant_linear import act_order_sorted, stripe_copy, stripe_matvec
         sg = act_order_sorted(_int32c(gate[0]), gis[0], K, groupsize, bits)
         su = act_order_sorted(_int32c(up[0]), gis[1], K, groupsize, bits)
         if sg is not None and su is not None and _same_perm(sg[1], su[1]):
+            st = stripe_copy(sg[0], gate[1], _int32c(gate[2]), bits, groupsize, up=(su[0], up[1], _int32c(up[2])))
+            if st is not None:
+                with torch.cuda.device(x.device):
+                    c = torch.empty((M, N), device=x.device, dtype=torch.float16)
+                    stripe_matvec(x2, st, c, K, N, bits, groupsize, nsets=2, perm=sg[1])
+                return c
             with torch.cuda.device(x.device):
                 c = torch.empty((M, N), device=x.device, dtype=torch.float16)
                 ws = _native.workspace(x.device)

@@ -32,12 +32,20 @@ def _infer_groupsize(K, G):
     return K if G <= 1 else -(-K // G)
 
 
+def _ver(t):
+    """version counter of a tensor; inference-mode tensors have none (they are immutable outside inference mode)."""
+    try:
+        return t._version
+    except Exception:
+        return -1
+
+
 def g_idx_is_trivial(g_idx, K, groupsize):
     """True iff g_idx[:K] == arange(K) // groupsize.  The verdict is memoised ON the tensor object
     (keyed by its version counter), never by address: the caching allocator hands the address of
     a freed g_idx to the next one."""
     memo = getattr(g_idx, '_gptq_trivial', None)
-    key = (g_idx._version, K, groupsize)
+    key = (_ver(g_idx), K, groupsize)
     if memo is not None and memo[0] == key:
         return memo[1]
     g = g_idx[:K]
@@ -78,7 +86,7 @@ def act_order_sorted(qweight, g_idx, K, groupsize, bits):
     if groupsize % f != 0 or K % groupsize != 0:
         return None
     memo = getattr(qweight, '_gptq_sorted', None)
-    key = (qweight._version, g_idx._version, K, groupsize)
+    key = (_ver(qweight), _ver(g_idx), K, groupsize)
     if memo is not None and memo[0] == key:
         return memo[1]
     g = g_idx[:K].to(torch.int64)
@@ -96,6 +104,56 @@ def act_order_sorted(qweight, g_idx, K, groupsize, bits):
     except Exception:  # pragma: no cover
         pass
     return res
+
+
+# ----------------------------------------------------------------------------------------------
+# stripe16 decode path (csrc/stripe.hip): at M == 1 a 4-bit layer is served from a load-time repacked
+# copy in which every workgroup's 16 output columns are contiguous (no K split, no combine atomics).
+# The copy is built once per weight set (or gate/up pair) by gptq_stripe_repack and cached ON the qweight
+# tensor, keyed by the version counters of the checkpoint buffers -- which stay untouched and remain the
+# state_dict.  Costs one extra copy of the packed weights; GPTQ_STRIPE=0 keeps the rowwave kernels.
+# ----------------------------------------------------------------------------------------------
+STRIPE = _os.environ.get('GPTQ_STRIPE', '1') != '0'
+
+
+def stripe_copy(qweight, scales, qzeros, bits, groupsize, up=None):
+    """uint8 tensor holding the stripe16 image of (qweight, scales, qzeros) -- or of the pair with
+    ``up = (qweight, scales, qzeros)`` for the fused gate/up matvec -- or None when the shape is not served
+    (bits != 4, K % 128, group size not a power-of-two multiple of 32 ...)."""
+    if not STRIPE or bits != 4 or not qweight.is_cuda:
+        return None
+    K, N = qweight.shape[0] * 32 // bits, qweight.shape[1]
+    lib = _native.lib()
+    nsets = 2 if up is not None else 1
+    nbytes = lib.gptq_stripe_bytes(K, N, bits, groupsize, nsets)
+    if nbytes == 0:
+        return None
+    srcs = (qweight, scales, qzeros) + (tuple(up) if up is not None else ())
+    key = tuple((_ver(t), t.data_ptr(), tuple(t.shape)) for t in srcs) + (groupsize,)
+    memo = getattr(qweight, '_gptq_stripe', None)
+    if memo is not None and memo[0] == key:
+        return memo[1]
+    if any(t.dtype != d or not t.is_contiguous() for t, d in zip(srcs, (torch.int32, torch.float16, torch.int32) * 2)):
+        return None
+    with torch.cuda.device(qweight.device):
+        st = torch.empty(nbytes, dtype=torch.uint8, device=qweight.device)
+        u = up if up is not None else (None, None, None)
+        rc = lib.gptq_stripe_repack(qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), _native.ptr(u[0]), _native.ptr(u[1]),
+                                    _native.ptr(u[2]), st.data_ptr(), nbytes, K, N, bits, groupsize, _native.stream_ptr(qweight.device))
+    _native.check(rc, 'gptq_stripe_repack')
+    try:
+        qweight._gptq_stripe = (key, st)
+    except Exception:  # pragma: no cover
+        pass
+    return st
+
+
+def stripe_matvec(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, norm_weight=None, eps=0.0, perm=None):
+    """out[1, N] = x[1, K] through a stripe16 image (gptq_stripe_matvec_f16) on the current stream."""
+    rc = _native.lib().gptq_stripe_matvec_f16(x.data_ptr(), st.data_ptr(), st.numel(), _native.ptr(bias), out.data_ptr(), K, N, bits,
+                                              groupsize, nsets, _native.ptr(norm_weight), float(eps), _native.ptr(perm),
+                                              _native.stream_ptr(x.device))
+    _native.check(rc, 'gptq_stripe_matvec_f16')
 
 
 def _as_rows(t):
@@ -161,7 +219,10 @@ def _mid_m(M, N):
 
 
 def dequantize(qweight, scales, qzeros, g_idx, bits, groupsize=None):
-    """dense fp16 [K, N] weight, bit-identical to what the kernels multiply with."""
+    """dense fp16 [K, N] weight with the reference's own rounding (fp16(q - z) * fp16 scale -> fp16,
+    quant_linear.py:128): bit-identical to what the prefill tile GEMM and the generic GEMV multiply with.  The
+    decode kernels (stripe16 / rowwave / stream) keep (q - z) * s in fp32 instead, i.e. they are slightly MORE
+    exact than this matrix; all paths sit inside the 1e-3 budget of the parity tests."""
     K, N = qweight.shape[0] * 32 // bits, qweight.shape[1]
     groupsize = _infer_groupsize(K, scales.shape[0]) if groupsize is None else groupsize
     gi = None
@@ -175,7 +236,8 @@ def dequantize(qweight, scales, qzeros, g_idx, bits, groupsize=None):
     return W
 
 
-_FAMILIES = {None: 'gptq_matmul248_f16', 'abi': 'gptq_matmul248_f16', 'gemv': 'gptq_gemv_f16', 'skinny': 'gptq_skinny_f16'}
+_FAMILIES = {None: 'gptq_matmul248_f16', 'abi': 'gptq_matmul248_f16', 'gemv': 'gptq_gemv_f16', 'skinny': 'gptq_skinny_f16',
+             'stripe': 'gptq_matmul248_f16'}
 
 
 def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, family=None):
@@ -199,11 +261,18 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
                 out += bias
             return out
         ws = _native.workspace(x.device)
-        if gi is not None:
-            srt = act_order_sorted(qweight, gi, K, groupsize, bits)
-            if srt is not None:
-                _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family)
+        srt = act_order_sorted(qweight, gi, K, groupsize, bits) if gi is not None else None
+        if M == 1 and family in (None, 'stripe') and (gi is None or srt is not None):
+            # decode: no-split-K kernel on the stripe16 copy (of the group-sorted rows for an act-order layer)
+            st = stripe_copy(srt[0] if srt is not None else qweight, scales, qzeros, bits, groupsize)
+            if st is not None:
+                stripe_matvec(x, st, out, K, N, bits, groupsize, bias=bias, perm=srt[1] if srt is not None else None)
                 return out
+        if family == 'stripe':
+            raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M == 1, 4-bit, K % 128 == 0 ...)')
+        if srt is not None:
+            _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family)
+            return out
         rc = getattr(_native.lib(), _FAMILIES[family])(
             x.data_ptr(), x.stride(0) if M > 1 else K, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
             _native.ptr(gi), _native.ptr(bias), out.data_ptr(), N, M, K, N, bits, groupsize,
@@ -217,6 +286,8 @@ def transpose_matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq):
     quant/quant_linear.py:272-279)."""
     K, N, groupsize, qweight, scales, qzeros, gi = _prep_weight(input, qweight, scales, qzeros, g_idx, bits)
     dy = _as_rows(input)
+    if dy.shape[1] != N:
+        raise RuntimeError('transpose_matmul248: input has %d features, weight has %d output columns' % (dy.shape[1], N))
     M = dy.shape[0]
     with torch.cuda.device(dy.device):
         out = torch.empty((M, K), device=dy.device, dtype=torch.float16)

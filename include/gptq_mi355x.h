@@ -57,8 +57,7 @@ enum {
     GPTQ_Q_GEMV_MAX_M = 1,        /* largest M of the rowwave GEMV family (4-bit: M <= 4 rows share one launch) */
     GPTQ_Q_SKINNY_MAX_M = 2,      /* largest M served by the weight-streaming MFMA kernel    */
     GPTQ_Q_WORKSPACE_BYTES = 3,   /* bytes of zero-initialised workspace split-K needs       */
-    GPTQ_Q_NUM_GEMV_VARIANTS = 4,
-    GPTQ_Q_CHAIN_WORKGROUPS = 5   /* workgroups of the persistent chain kernel = CUs of the current device */
+    GPTQ_Q_NUM_GEMV_VARIANTS = 4
 };
 
 int gptq_query(int what);
@@ -71,7 +70,6 @@ const char *gptq_strerror(int code);
  * gptq_set_split_k forces the number of K slices (>= 1).  Both return the previous value. */
 int gptq_set_gemv_variant(int variant);
 int gptq_set_split_k(int split_k);
-int gptq_set_chain_depth(int depth);   /* development: 8-KiB weight tasks in flight per wave of the chain kernel (2..4) */
 /* Prefill GEMM kernel selection (tests / A-B measurements): 2 = ping-pong kernel (default), 3 = all-LDS-DMA
  * kernel with packed B in LDS (4-bit, groupsize % 64 == 0; measured 2-4 % slower).  Returns the previous value. */
 int gptq_set_gemm_kernel(int version);
@@ -243,48 +241,26 @@ int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k
                                void *workspace, size_t workspace_bytes, int heads, int head_dim, int t_max,
                                float base, float scale, gptq_stream_t stream);
 
-/* ---- persistent matvec chain: n DEPENDENT batch-1 QuantLinear ops in ONE launch (csrc/chain.hip) ----------------
- * A decode step issues its QuantLinear.forward calls (quant_linear.py:373-377) back to back, each one consuming
- * the previous one's output: fused qkv -> (attention) -> o_proj (fused_attn.py:117-161), gate/up+SiLU -> down_proj
- * (fused_mlp.py:203-218), each block behind an RMSNorm (triton_norm.py:50-67).  One launch per op leaves HBM idle
- * for ~3 us per op (launch, first-byte latency, combine round trip, kernel boundary).  The chain keeps one
- * workgroup per CU resident and streams the weights of op i+1 while op i is being combined and published.
- * Semantics of op i (M = 1, trivial g_idx, 4-bit in this release):
- *     xin = norm_weight ? rmsnorm(x, norm_weight, norm_eps) : x                    (triton_norm.py:22-39)
- *     v   = qweight_up ? silu(xin.Wg) * (xin.Wu) : xin.W                           (fp32, fused_mlp.py:128-168)
- *     y   = residual ? fp16(fp16(v) + residual) : fp16(v)                          (residual may alias y)
- * and op i starts only when every output of op i-1 is final (strict chain), so x / residual may be any buffer
- * written by an earlier op of the same chain or by earlier work on the stream.
- * Usage: fill gptq_chain_op[n]; gptq_chain_encode() validates and writes the device image into HOST memory;
- * copy those gptq_chain_state_bytes(n) bytes to device memory once; gptq_chain_run_f16() replays it (one memset
- * node + one kernel; hipGraph-capturable; buffers addressed by the image must stay alive).
- * num_workgroups: gptq_query(GPTQ_Q_CHAIN_WORKGROUPS) (= CUs of the current device); all workgroups must be
- * co-resident, so nothing else may occupy the GPU for the duration of the launch.
- * Limits: bits == 4, K % 256 == 0, K <= 16384, N % 32 == 0, N <= 16384, groupsize a power of two >= 64 or >= K.
- * workspace: the library workspace (first 256 KiB used, all-zero on entry and on exit).
- * flags: bit 0 = development timeline: s_memrealtime stamps [n_ops][num_workgroups][16] uint64 into the buffer given
- * to gptq_set_debug_buffer() (tools/chain_check.py).
- * After a run, the uint32 at byte offset gptq_chain_status_offset(n) of the device image is 0 unless a bounded
- * wait expired (results invalid; cannot happen while the co-residency requirement holds). */
-typedef struct gptq_chain_op {
-    const void *x;
-    const int32_t *qweight;
-    const void *scales;
-    const int32_t *qzeros;
-    const int32_t *qweight_up; /* NULL, or the second weight set of a fused gate/up + SiLU op */
-    const void *scales_up;
-    const int32_t *qzeros_up;
-    void *y;
-    const void *residual;      /* NULL or fp16 [N] */
-    const void *norm_weight;   /* NULL or fp16 [K] */
-    float norm_eps;
-    int K, N, groupsize;
-} gptq_chain_op;
-size_t gptq_chain_state_bytes(int n_ops);
-size_t gptq_chain_status_offset(int n_ops);
-int gptq_chain_encode(const gptq_chain_op *ops, int n_ops, int bits, int num_workgroups, void *state_host, size_t state_bytes);
-int gptq_chain_run_f16(void *state_dev, int n_ops, int bits, int max_k, int num_workgroups, int flags, void *workspace,
-                       size_t workspace_bytes, gptq_stream_t stream);
+/* ---- stripe16: the batch-1 decode matvec WITHOUT a K split, on a load-time repacked copy (csrc/stripe.hip) --------
+ * Replaces, for M == 1, the launch of matmul_248_kernel (quant/quant_linear.py:263-269) / fusedmatmul_248_kernel
+ * (quant/fused_mlp.py:206-218) on a layout the library owns: the checkpoint buffers are repacked ONCE at load time
+ * (the reference has no counterpart; its load path ends at load_state_dict, llama_inference.py:57-60) into
+ *   R   uint32 [N/16][K/128][nsets][64][4]  every workgroup's 16 columns contiguous, 1 KiB per wave load, nibbles
+ *                                            re-ordered for a one-shift unpack (see csrc/stripe.hip)
+ *   tab half2  [N/16][nsets][G][16]          {scale, zero + 1} per (group, column)
+ * stored back to back in ONE buffer of gptq_stripe_bytes() bytes (0 = shape not eligible: bits must be 4,
+ * K % 128 == 0, K <= 24576, groupsize a power-of-two multiple of 32 that divides K, or >= K).  The checkpoint buffers are not
+ * modified and stay the owner of the state_dict.  nsets == 2 packs gate and up together and the matvec returns
+ * silu(x Wg) * (x Wu).  norm_weight != NULL fuses the RMSNorm of x (rms_norm_fwd_fused, quant/triton_norm.py:22-39)
+ * in front; perm != NULL reads x (and norm_weight) through a permutation (an act-order layer whose qweight rows were
+ * sorted by group with gptq_act_order_repack BEFORE gptq_stripe_repack).  No workspace, no atomics: results are
+ * bit-identical run to run. */
+size_t gptq_stripe_bytes(int K, int N, int bits, int groupsize, int nsets);
+int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *qweight_up, const void *scales_up,
+                       const int32_t *qzeros_up, void *stripes, size_t stripes_bytes, int K, int N, int bits, int groupsize,
+                       gptq_stream_t stream);
+int gptq_stripe_matvec_f16(const void *x, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int K, int N, int bits,
+                           int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm, gptq_stream_t stream);
 
 /* ---- GPTQ solver (the caller that PRODUCES the weights; reference gptq.py:128-228) -------------------------------
  * One column block [i1, i1 + count), count <= 128, of the sequential quantise / error-feedback loop (gptq.py:177-199)

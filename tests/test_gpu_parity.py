@@ -573,60 +573,168 @@ def test_fuzz_fused_mlp_vs_oracle(case):
 
 
 # ---------------------------------------------------------------------------------------
-# persistent matvec chain (csrc/chain.hip): n dependent ops in one launch vs the oracle run op by op
+# stripe16 decode path (csrc/stripe.hip): repack bit-exact vs the numpy restatement; matvec vs the oracle on the
+# ORIGINAL checkpoint buffers (the layout must be invisible in the results)
 # ---------------------------------------------------------------------------------------
-@pytest.mark.gpu
-@pytest.mark.parametrize('K,I,gs', [(1024, 2816, 128), (2048, 1536, 64), (512, 1024, 512)])
-def test_chain_matches_oracle_op_by_op(K, I, gs):
-    """[RMSNorm + qkv] -> [o + residual] -> [RMSNorm + gate/up + SiLU] -> [down + residual] as ONE launch
-    (decoder-layer call order of reference fused_attn.py:117-161 / fused_mlp.py:203-218) against the oracle's
-    rmsnorm / matmul248 / fused_mlp applied one after the other; ragged tiles (N % 256 != 0) and a single group."""
-    from quant.chain import MatvecChain
-    import torch
-    bits = 4
-    assert I % 256 == 0                           # I is the K of down_proj
-    rng = np.random.default_rng(K + I)
-    Lq, Lo, Lg, Lu, Ld = (make_random_layer(bits, gs, a, b, seed=i) for i, (a, b) in enumerate(
-        [(K, 3 * K + 32), (K, K), (K, I), (K, I), (I, K)]))
-    h0 = rng.standard_normal(K).astype(np.float16)
-    attn = (rng.standard_normal(K) * 0.5).astype(np.float16)
-    ln1 = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
-    ln2 = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+def _stripe_image(Ls, gs):
+    K = Ls[0]['qweight'].shape[0] * 8
+    t = [(dev(L['qweight']), dev(L['scales']), dev(L['qzeros'])) for L in Ls]
+    st = QL.stripe_copy(t[0][0], t[0][1], t[0][2], 4, K if gs == -1 else gs, up=t[1] if len(t) == 2 else None)
+    torch.cuda.synchronize()
+    return st, t
+
+
+@pytest.mark.parametrize('K,N,gs,NS', [(4096, 4096, 128, 1), (1024, 288, 64, 2), (384, 64, 32, 1), (512, 64, -1, 2), (2176, 32, 128, 1),
+                                       (4096, 11008, 128, 2)])
+def test_stripe_repack_bit_exact(K, N, gs, NS):
+    Ls = [make_random_layer(4, gs, K, N, seed=K + N + i) for i in range(NS)]
+    st, _ = _stripe_image(Ls, gs)
+    assert st is not None
+    ref = oracle.stripe16_repack([(L['qweight'], L['scales'], L['qzeros']) for L in Ls], gs)
+    assert np.array_equal(st.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('bias', [False, True])
+@pytest.mark.parametrize('K,N,gs', [(4096, 4096, 128), (4096, 12288, 128), (11008, 4096, 128), (128, 32, 128), (1024, 288, 32), (2176, 96, 64),
+                                    (3072, 64, 256), (512, 64, -1), (8192, 256, 128), (22016, 64, 128), (24576, 32, 128), (5120, 160, 128)])
+def test_stripe_matvec_vs_oracle(K, N, gs, bias):
+    """every row-block count per wave (1 .. 24, ragged tails), group sizes 32 .. K, bias epilogue; twice: bit-identical"""
+    L = make_random_layer(4, gs, K, N, seed=K + N)
+    x = np.random.default_rng(K).standard_normal((1, K)).astype(np.float16)
+    b = np.random.default_rng(N).standard_normal(N).astype(np.float16) if bias else None
+    y1 = hip_forward(x, L, b, family='stripe')
+    ref = oracle_forward(x, L, b)
+    # with a bias the result is rounded to fp16 twice (fp16(fp16(acc) + bias), reference quant_linear.py:376): a 1-ulp
+    # difference of the first rounding can survive as 1-2 ulp of a LARGER sum -> 2e-3 there, 1e-3 without bias
+    assert rel_err(y1, ref) < (2 * TOL if bias else TOL), rel_err(y1, ref)
+    y2 = hip_forward(x, L, b, family='stripe')
+    assert np.array_equal(y1.view(np.uint16), y2.view(np.uint16))
+    ye = oracle.matmul248_exact(x, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)
+    if b is None:
+        assert rel_err(y1, ye) < TOL
+
+
+def test_stripe_is_the_default_decode_path_and_rowwave_still_agrees():
+    L = make_random_layer(4, 128, 4096, 4096, seed=5)
+    x = np.random.default_rng(5).standard_normal((1, 4096)).astype(np.float16)
+    ys = hip_forward(x, L)                       # default dispatch at M == 1
+    yf = hip_forward(x, L, family='stripe')
+    yr = hip_forward(x, L, family='gemv')        # rowwave (split-K) on the checkpoint layout
+    assert np.array_equal(ys.view(np.uint16), yf.view(np.uint16))
+    assert rel_err(ys, yr) < TOL
+    with pytest.raises(RuntimeError):            # shapes the stripe kernel does not serve are refused when forced
+        hip_forward(x[:, :1056], make_random_layer(4, 32, 1056, 64, seed=1), family='stripe')
+
+
+@pytest.mark.parametrize('K,N,gs', [(4096, 11008, 128), (1024, 2816, 64), (512, 96, 32), (2176, 32, -1)])
+def test_stripe_fused_mlp_vs_oracle(K, N, gs):
+    A, B = make_random_layer(4, gs, K, N, seed=31), make_random_layer(4, gs, K, N, seed=32)
+    x = (np.random.default_rng(2).standard_normal((1, K)) * 0.5).astype(np.float16)
+    g = K if gs == -1 else gs
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, g).cpu().numpy()
+    c2 = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, g).cpu().numpy()
+    assert getattr(gate[0], '_gptq_stripe', None) is not None          # the stripe image was built and cached
+    ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), 4)
+    assert rel_err(c, ref) < 2e-3
+    assert np.array_equal(c.view(np.uint16), c2.view(np.uint16))
+
+
+@pytest.mark.parametrize('K,N,gs,NS', [(4096, 12288, 128, 1), (1024, 288, 64, 1), (4096, 11008, 128, 2), (2176, 64, 32, 2)])
+def test_stripe_fused_rmsnorm(K, N, gs, NS):
+    """[RMSNorm -> QuantLinear] and [RMSNorm -> gate/up + SiLU] in one launch vs oracle.rmsnorm + oracle matvec"""
+    Ls = [make_random_layer(4, gs, K, N, seed=41 + i) for i in range(NS)]
+    rng = np.random.default_rng(K)
+    x = rng.standard_normal((1, K)).astype(np.float16)
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
     eps = 1e-6
-
-    def mm(x, L, bias=None):
-        return oracle.matmul248(x[None, :], L['qweight'], L['scales'], L['qzeros'], L['g_idx'], bits, bias=bias)[0]
-    qkv_ref = mm(oracle.rmsnorm(h0[None, :], ln1, eps)[0], Lq)
-    h1 = mm(attn, Lo, bias=h0)
-    act_ref = oracle.fused_mlp(oracle.rmsnorm(h1[None, :], ln2, eps), (Lg['qweight'], Lg['scales'], Lg['qzeros'], Lg['g_idx']),
-                               (Lu['qweight'], Lu['scales'], Lu['qzeros'], Lu['g_idx']), bits)[0]
-    h2 = mm(act_ref, Ld, bias=h1)
-
-    dev = 'cuda:0'
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    W = {n: {k: t(L[k]) for k in ('qweight', 'scales', 'qzeros')} for n, L in (('q', Lq), ('o', Lo), ('g', Lg), ('u', Lu), ('d', Ld))}
-    h, a_in = t(h0), t(attn)
-    qkv = torch.zeros(3 * K + 32, dtype=torch.float16, device=dev)
-    act = torch.zeros(I, dtype=torch.float16, device=dev)
-    ch = MatvecChain(bits, gs, dev)
-    ch.add(h, W['q']['qweight'], W['q']['scales'], W['q']['qzeros'], qkv, norm_weight=t(ln1), norm_eps=eps)
-    ch.add(a_in, W['o']['qweight'], W['o']['scales'], W['o']['qzeros'], h, residual=h)
-    ch.add(h, W['g']['qweight'], W['g']['scales'], W['g']['qzeros'], act, up=(W['u']['qweight'], W['u']['scales'], W['u']['qzeros']),
-           norm_weight=t(ln2), norm_eps=eps)
-    ch.add(act, W['d']['qweight'], W['d']['scales'], W['d']['qzeros'], h, residual=h)
-    ch.run()
+    st, _ = _stripe_image(Ls, gs)
+    out = torch.empty((1, N), dtype=torch.float16, device=DEV)
+    QL.stripe_matvec(dev(x), st, out, K, N, 4, K if gs == -1 else gs, nsets=NS, norm_weight=dev(nw), eps=eps)
     torch.cuda.synchronize()
-    assert ch.status() == 0
-    assert rel_err(qkv.cpu().numpy(), qkv_ref) < TOL
-    assert rel_err(act.cpu().numpy(), act_ref) < 2 * TOL      # behind two matvecs and an RMSNorm
-    assert rel_err(h.cpu().numpy(), h2) < 2 * TOL
-    first = (qkv.clone(), act.clone(), h.clone())
-    # replay: same inputs -> bit-identical outputs (fixed-point combine), workspace back to zero
-    h.copy_(t(h0))
-    ch.run()
+    xn = oracle.rmsnorm(x, nw, eps)
+    if NS == 1:
+        ref = oracle.matmul248(xn, Ls[0]['qweight'], Ls[0]['scales'], Ls[0]['qzeros'], Ls[0]['g_idx'], 4)
+    else:
+        ref = oracle.fused_mlp(xn, *[(L['qweight'], L['scales'], L['qzeros'], L['g_idx']) for L in Ls], 4)
+    assert rel_err(out.cpu().numpy(), ref) < 2e-3
+
+
+@pytest.mark.parametrize('K,N,gs', [(4096, 4096, 128), (1024, 288, 32), (2176, 64, 64)])
+@pytest.mark.parametrize('norm', [False, True])
+def test_stripe_act_order(K, N, gs, norm):
+    """act-order layer: rows sorted by group at load (gptq_act_order_repack), then striped; x (and the norm weight)
+    gathered through the permutation inside the kernel -- against the oracle on the ORIGINAL g_idx."""
+    L = make_random_layer(4, gs, K, N, act_order=True, seed=K)
+    rng = np.random.default_rng(N)
+    x = rng.standard_normal((1, K)).astype(np.float16)
+    if not norm:
+        y, ref = check_forward(x, L)             # default dispatch: sorted copy -> stripe image -> XPERM kernel
+        qw = None
+        return
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+    qw, sc, qz, gi = dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx'])
+    srt = QL.act_order_sorted(qw, gi, K, gs, 4)
+    st = QL.stripe_copy(srt[0], sc, qz, 4, gs)
+    out = torch.empty((1, N), dtype=torch.float16, device=DEV)
+    QL.stripe_matvec(dev(x), st, out, K, N, 4, gs, norm_weight=dev(nw), eps=1e-6, perm=srt[1])
     torch.cuda.synchronize()
-    assert torch.equal(first[0], qkv) and torch.equal(first[1], act) and torch.equal(first[2], h)
-    assert int(ch.ws[:262144].view(torch.int64).ne(0).sum()) == 0
+    ref = oracle.matmul248(oracle.rmsnorm(x, nw, 1e-6), L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)
+    assert rel_err(out.cpu().numpy(), ref) < 2e-3
+
+
+def test_stripe_copy_follows_buffer_updates():
+    """the cached image is keyed by the version counters of the checkpoint buffers: an in-place update (load_state_dict)
+    rebuilds it"""
+    L1, L2 = make_random_layer(4, 128, 512, 64, seed=1), make_random_layer(4, 128, 512, 64, seed=2)
+    m = quant.QuantLinear(4, 128, 512, 64, False).to(DEV)
+    x = np.random.default_rng(0).standard_normal((1, 512)).astype(np.float16)
+    for L in (L1, L2):
+        m.load_state_dict({k: torch.from_numpy(L[k]) for k in ('qweight', 'qzeros', 'scales', 'g_idx')})
+        y = m(dev(x)).cpu().numpy()
+        assert rel_err(y, oracle_forward(x, L)) < TOL
+
+
+def test_split_k_64_with_positive_sums():
+    """with 128 slices the 2^49 biases of the fixed-point combine carry into the arrival count.  The cap is 64
+    now; all-positive partial sums at the cap (and a request above it) must still find their owner."""
+    K, N = 16384, 256
+    L = make_random_layer(4, 128, K, N, seed=3)
+    L['qzeros'][:] = 0                                                  # zero point 1: every (q - z) >= -1
+    x = np.abs(np.random.default_rng(4).standard_normal((1, K))).astype(np.float16)
+    lib = _native.lib()
+    for sk in (64, 128):
+        lib.gptq_set_split_k(sk)
+        try:
+            y1, _ = check_forward(x, L, family='gemv')
+            y2, _ = check_forward(x, L, family='gemv')
+            assert np.array_equal(y1.view(np.uint16), y2.view(np.uint16))
+        finally:
+            lib.gptq_set_split_k(-1)
+
+
+def test_fused_mlp_rowwave_large_partials_are_not_clamped():
+    """the gate/up split-K combine used to clamp every per-slice partial to +-512.  Scales 50x the usual
+    range put the partial sums far beyond that; the result must still match the oracle (rowwave path forced by bits = 8)."""
+    K, N = 2048, 512
+    A, B = make_random_layer(8, 128, K, N, seed=51), make_random_layer(8, 128, K, N, seed=52)
+    A['scales'] = (A['scales'].astype(np.float32) * 16).astype(np.float16)     # gate partials of a K slice: sigma ~ 220, total ~ 630
+    B['scales'] = (B['scales'].astype(np.float32) * 0.1).astype(np.float16)    # keeps silu(gate) * up inside fp16
+    x = (np.random.default_rng(6).standard_normal((1, K)) * 2).astype(np.float16)
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    lib = _native.lib()
+    lib.gptq_set_split_k(8)
+    try:
+        c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 8, 128).cpu().numpy()
+    finally:
+        lib.gptq_set_split_k(-1)
+    ga = oracle.matmul248_exact(x, A['qweight'], A['scales'], A['qzeros'], A['g_idx'], 8)
+    assert np.abs(ga).max() > 1500                                       # sums (and many slice partials) beyond the old +-512 range
+    ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), 8)
+    ok = np.isfinite(ref.astype(np.float32))
+    assert rel_err(np.where(ok, c, 0), np.where(ok, ref, 0)) < 2e-3
 
 
 @pytest.mark.gpu

@@ -188,51 +188,46 @@ def test_row_and_col_sharded_linear_gloo_world2(act_order):
     assert ret.get(timeout=5) == 1
 
 
-def test_chain_encode_validates_and_picks_slices_without_a_gpu():
-    """gptq_chain_encode is pure host code: shape limits, error codes and the K-slice choice per op."""
-    import ctypes
-    import struct
+def test_stripe16_layout_restatement_is_a_bijection():
+    """oracle.stripe16_repack (numpy restatement of csrc/stripe.hip's load-time repack) loses nothing: the
+    checkpoint buffers come back bit for bit, for one set and for a gate/up pair, several group sizes."""
+    for K, N, gs, NS in [(256, 32, 128, 1), (1024, 288, 64, 2), (384, 64, 32, 1), (512, 48 + 16, -1, 2)]:
+        Ls = [make_random_layer(4, gs, K, N, seed=K + N + i) for i in range(NS)]
+        img = oracle.stripe16_repack([(L['qweight'], L['scales'], L['qzeros']) for L in Ls], gs)
+        assert img.nbytes == _native.lib().gptq_stripe_bytes(K, N, 4, K if gs == -1 else gs, NS)
+        back = oracle.stripe16_unpack(img, K, N, gs, NS)
+        for L, (qw, sc, z) in zip(Ls, back):
+            assert np.array_equal(qw, L['qweight'])
+            assert np.array_equal(sc.view(np.uint16), L['scales'].view(np.uint16))
+            assert np.array_equal(z, oracle.np_unpack_cols(L['qzeros'], 4) + 1)
+    # one hand-checked word: k = 0..7 hold the values 0..7 -> positions (k0 k2 k4 k6 | k1 k3 k5 k7)
+    qw = np.zeros((16, 16), dtype=np.int32)
+    qw[0, 0] = 0x76543210
+    L = dict(qweight=np.tile(qw, (1, 1)), scales=np.ones((1, 16), np.float16), qzeros=np.zeros((1, 2), np.int32))
+    img = oracle.stripe16_repack([(L['qweight'], L['scales'], L['qzeros'])], 128)
+    assert int(img[:4].view(np.uint32)[0]) == 0x75316420
+
+
+def test_stripe_abi_validation_needs_no_gpu():
     lib = _native.lib()
-
-    def encode(ops, bits=4, nwg=256):
-        arr = (_native.ChainOp * len(ops))(*ops)
-        nbytes = lib.gptq_chain_state_bytes(len(ops))
-        buf = (ctypes.c_ubyte * nbytes)()
-        rc = lib.gptq_chain_encode(ctypes.cast(arr, ctypes.c_void_p), len(ops), bits, nwg, ctypes.cast(buf, ctypes.c_void_p), nbytes)
-        return rc, bytes(buf)
-
-    def op(K, N, gs=128, fused=False, **kw):
-        o = _native.ChainOp()
-        o.x = o.qweight = o.scales = o.qzeros = o.y = 4096
-        if fused:
-            o.qweight_up = o.scales_up = o.qzeros_up = 4096
-        o.K, o.N, o.groupsize = K, N, gs
-        for k, v in kw.items():
-            setattr(o, k, v)
-        return o
-
-    # the four ops of a LLaMA-7B decoder layer on 256 workgroups
-    rc, img = encode([op(4096, 12288), op(4096, 4096), op(4096, 11008, fused=True), op(11008, 4096)])
-    assert rc == 0
-    fields = [struct.unpack('<f11i', img[i * 128 + 80:(i + 1) * 128]) for i in range(4)]
-    #            eps  K      N      rows  tiles S   nchunk gshift ns jobs dep   rows/wave
-    assert fields[0][1:] == (4096, 12288, 512, 48, 16, 16, 4, 1, 768, 0, 8)
-    assert fields[1][1:] == (4096, 4096, 512, 16, 16, 16, 4, 1, 256, 12288, 8)
-    assert fields[2][1:] == (4096, 11008, 512, 43, 16, 16, 4, 2, 688, 4096, 8)
-    assert fields[3][1:] == (11008, 4096, 1376, 16, 15, 43, 4, 1, 240, 11008, 8)   # 15 and 16 slices both need 3 chunks per job: fewer atomics wins
-    assert lib.gptq_chain_status_offset(4) == 4 * 128 + 4 * 16 * 128
-    assert lib.gptq_chain_state_bytes(4) == lib.gptq_chain_status_offset(4) + 128
-    # refusals: nothing is written / launched
-    assert encode([op(4096, 4096)], bits=8)[0] == -6          # only 4-bit in this release
-    assert encode([op(4096, 4096)], bits=5)[0] == -1
-    assert encode([op(4000, 4096)])[0] == -6                  # K % 256
-    assert encode([op(32768, 4096)])[0] == -6                 # K > 16384 (x is staged in LDS)
-    assert encode([op(4096, 4104)])[0] == -2                  # N % 32 (library-wide shape contract)
-    assert encode([op(4096, 4096, gs=96)])[0] == -6           # group must be a power of two >= 64
-    assert encode([op(4096, 4096, gs=4096)])[0] == 0          # one group over all of K
-    assert encode([op(4096, 4096, x=None)])[0] == -4
-    assert encode([op(4096, 4096, x=4098)])[0] == -3
-    assert lib.gptq_chain_run_f16(None, 1, 4, 4096, 256, 0, None, 0, None) == -4
+    one = 16
+    assert lib.gptq_stripe_bytes(4096, 4096, 4, 128, 1) == 4096 // 8 * 4096 * 4 + 32 * 4096 * 4
+    assert lib.gptq_stripe_bytes(4096, 11008, 4, 128, 2) == 2 * (4096 // 8 * 11008 * 4 + 32 * 11008 * 4)
+    assert lib.gptq_stripe_bytes(4096, 4096, 8, 128, 1) == 0          # 4-bit only
+    assert lib.gptq_stripe_bytes(4096 + 64, 4096, 4, 128, 1) == 0     # K % 128
+    assert lib.gptq_stripe_bytes(4096, 4096, 4, 96, 1) == 0           # group not a power-of-two multiple of 32
+    assert lib.gptq_stripe_bytes(32768, 4096, 4, 128, 1) == 0         # more than 24 row blocks per wave
+    assert lib.gptq_stripe_bytes(4096, 4096, 4, 4096, 1) > 0          # one group
+    nb = lib.gptq_stripe_bytes(256, 64, 4, 128, 1)
+    assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb, 256, 64, 5, 128, None) == -1
+    assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb - 1, 256, 64, 4, 128, None) == -5
+    assert lib.gptq_stripe_repack(None, one, one, None, None, None, one, nb, 256, 64, 4, 128, None) == -4
+    assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb, 256, 64, 8, 128, None) == -6
+    assert lib.gptq_stripe_matvec_f16(one, one, nb, None, one, 256, 64, 4, 128, 3, None, 0.0, None, None) == -2   # nsets
+    assert lib.gptq_stripe_matvec_f16(one, one, nb - 1, None, one, 256, 64, 4, 128, 1, None, 0.0, None, None) == -5
+    assert lib.gptq_stripe_matvec_f16(one, one, nb, None, one, 256, 64, 2, 128, 1, None, 0.0, None, None) == -6
+    assert lib.gptq_stripe_matvec_f16(None, one, nb, None, one, 256, 64, 4, 128, 1, None, 0.0, None, None) == -4
+    assert lib.gptq_stripe_matvec_f16(2, one, nb, None, one, 256, 64, 4, 128, 1, None, 0.0, None, None) == -3
 
 
 def test_byte_model_matches_survey_8d():

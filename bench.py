@@ -395,12 +395,18 @@ def gptq_loop_baseline(dev):
 
 
 def decode_tokens_per_s(dev, tokens=64):
-    """full decode step (norms, fused qkv + RoPE, KV cache, SDPA, o_proj, fused MLP, lm_head) on a
-    random-init LLaMA-7B-shaped model built from the drop-in modules; protocol of the reference's
-    benchmark() (llama.py:385-438): one token per step with KV cache, sync per step, median."""
-    from quant.decode import build_random_llama, benchmark_decode, benchmark_decode_engine
+    """full decode step (norms, fused qkv + RoPE, KV cache, attention, o_proj, fused MLP, lm_head) on a
+    random-init LLaMA-7B-shaped model built from the drop-in modules exactly as load_quant() builds it.
+      hf_eager         the module chain launch by launch (engine hook off) -- protocol of benchmark(), llama.py:385-438
+      drop_in_forward  the same protocol through the public surface: model(input_ids[:, i:i+1], past_key_values=cache);
+                       one-token forwards are answered by the hipGraph decode engine (quant/engine_hook.py)
+      drop_in_generate model.generate(...) as llama_inference.py:119-127 calls it
+      engine_graph     quant.decode.DecodeEngine driven directly (one hipGraph replay per token)"""
+    from quant.decode import build_random_llama, benchmark_decode, benchmark_decode_engine, benchmark_generate
     model = build_random_llama(dev)
-    out = {'hf_eager': benchmark_decode(model, tokens)}
+    out = {'hf_eager': benchmark_decode(model, 24, engine_hook=False)}
+    out['drop_in_forward'] = benchmark_decode(model, tokens)
+    out['drop_in_generate'] = benchmark_generate(model)
     out['engine_graph'] = benchmark_decode_engine(model, tokens=tokens, graph=True)
     out['tokens_per_s'] = out['engine_graph']['tokens_per_s']
     return out

@@ -94,10 +94,12 @@ def build_random_llama(dev='cuda:0', bits=4, groupsize=128, seed=0, fused=True, 
     return model
 
 
-def benchmark_decode(model, tokens=64, seed=0):
+def benchmark_decode(model, tokens=64, seed=0, engine_hook=True):
     """llama.py:385-438: feed ``input_ids[:, i:i+1]`` with the growing cache, sync after every
-    step, report the median (and peak memory).  Returns a dict."""
+    step, report the median (and peak memory).  Returns a dict.  engine_hook=False switches the transparent
+    decode engine of quant/engine_hook.py off for this run (the module chain launch by launch)."""
     from transformers.cache_utils import DynamicCache
+    model._gptq_engine_disabled = not engine_hook
 
     dev = next(model.parameters()).device
     gen = torch.Generator(device=dev)
@@ -115,10 +117,38 @@ def benchmark_decode(model, tokens=64, seed=0):
             torch.cuda.synchronize(dev)
             times.append(time.perf_counter() - tick)
             del out
+    model._gptq_engine_disabled = False
     med = float(np.median(times[2:])) if len(times) > 4 else float(np.median(times))
-    return {'protocol': 'llama.py:385-438 (one token per step, KV cache, sync per step, median)', 'mode': 'eager HF decoder + drop-in modules',
+    return {'protocol': 'llama.py:385-438 (one token per step, KV cache, sync per step, median)',
+            'mode': 'model(input_ids[:, i:i+1], past_key_values=cache) on the drop-in modules, ' +
+                    ('decode engine hook (quant/engine_hook.py)' if engine_hook else 'eager module chain'),
             'tokens': tokens, 'median_s_per_token': round(med, 6), 'tokens_per_s': round(1.0 / med, 1),
             'max_memory_MiB': round(torch.cuda.max_memory_allocated(dev) / 1024 / 1024, 1)}
+
+
+def benchmark_generate(model, prompt_len=16, new_tokens=128, seed=0):
+    """``model.generate(input_ids, do_sample=False, max_new_tokens=...)`` as llama_inference.py:119-127 calls it (greedy here
+    so that runs are comparable), wall time of the decode part: (t(new_tokens) - t(1 new token)) / (new_tokens - 1)."""
+    dev = next(model.parameters()).device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    ids = torch.randint(0, model.config.vocab_size, (1, prompt_len), device=dev, generator=gen)
+
+    def run(n):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = model.generate(ids, do_sample=False, max_new_tokens=n, min_new_tokens=n)
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, out
+    run(4)                                   # warm-up: engine build + graph capture happen here
+    t1, _ = run(1)
+    tn, out = run(new_tokens)
+    per_tok = (tn - t1) / (new_tokens - 1)
+    from .engine_hook import engine_steps
+    return {'call': 'model.generate(input_ids[1, %d], do_sample=False, max_new_tokens=%d) (llama_inference.py:119-127)' % (prompt_len, new_tokens),
+            'generated': int(out.shape[1] - prompt_len), 's_per_token': round(per_tok, 6), 'tokens_per_s': round(1.0 / per_tok, 1),
+            'engine_steps_total': engine_steps(model)}
 
 
 # ----------------------------------------------------------------------------------------------

@@ -181,3 +181,8 @@ def make_quant_attn(model):
         else:
             parent, child_name = model, name
         setattr(parent, child_name, attn)
+
+    # one-token forwards of the fused model (HF generate, the benchmark() protocol) are answered by the hipGraph decode
+    # engine from here on; everything else reaches the original forward (quant/engine_hook.py)
+    from .engine_hook import install_decode_engine
+    install_decode_engine(model)

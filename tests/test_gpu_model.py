@@ -346,3 +346,73 @@ def test_gpu_gptq_solver_vs_cpu_restatement(rows, cols, bits, gs, act, bs):
     Wr = G.quantize(Wg, s_r[:, None], z_r[:, None], 2 ** bits - 1).reshape(rows, cols)
     rtn_err = np.linalg.norm(Xf @ Wr.T - ref) / np.linalg.norm(ref)
     assert out_err < rtn_err, (out_err, rtn_err)
+
+
+# ---------------------------------------------------------------------------------------
+# the transparent decode engine behind model.forward / model.generate (quant/engine_hook.py)
+# ---------------------------------------------------------------------------------------
+HOOK_CFG = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                vocab_size=512, max_position_embeddings=256)
+
+
+def _greedy_with_logits(model, ids, n, hook):
+    model._gptq_engine_disabled = not hook
+    try:
+        with torch.no_grad():
+            out = model.generate(ids, do_sample=False, max_new_tokens=n, min_new_tokens=n, return_dict_in_generate=True, output_logits=True)
+    finally:
+        model._gptq_engine_disabled = False
+    return out.sequences[0, ids.shape[1]:].cpu().numpy(), torch.stack([l[0].float() for l in out.logits]).cpu().numpy(), out
+
+
+def test_generate_goes_through_the_decode_engine_and_matches_the_module_chain():
+    """model.generate() as llama_inference.py:119-127 calls it: the one-token forwards are answered by the hipGraph engine.
+    Same greedy tokens as the eager module chain for 48 tokens -- compared margin-aware: a step whose two best eager logits
+    are closer than the fp16 noise of the logits may legitimately flip, and ends the comparison."""
+    from quant.engine_hook import engine_steps
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=11, fused=True, **HOOK_CFG)
+    assert getattr(model, '_gptq_engine_state', None) is not None           # installed by make_quant_attn
+    ids = torch.randint(0, 512, (1, 7), device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    n = 48
+    tok_e, log_e, _ = _greedy_with_logits(model, ids, n, hook=False)
+    assert engine_steps(model) == 0
+    tok_h, log_h, _ = _greedy_with_logits(model, ids, n, hook=True)
+    assert engine_steps(model) == n - 1                                       # every step after the prefill
+    compared = 0
+    for i in range(n):
+        assert np.abs(log_h[i] - log_e[i]).max() < 2e-2 * max(1.0, np.abs(log_e[i]).max())
+        if tok_e[i] != tok_h[i]:
+            top2 = np.sort(log_e[i])[-2:]
+            assert top2[1] - top2[0] < 2e-2 * max(1.0, np.abs(log_e[i]).max()), 'engine token differs at a step with a clear winner'
+            break
+        compared += 1
+    assert compared >= 32, compared
+    # sampling, the call llama_inference.py makes (top_p / temperature go through HF's own logits processors)
+    with torch.no_grad():
+        s = model.generate(ids, do_sample=True, min_length=10, max_length=40, top_p=0.95, temperature=0.8)
+    assert s.shape[1] <= 40 and torch.equal(s[:, :7], ids)
+
+
+def test_engine_hook_keeps_the_callers_cache_consistent():
+    """tokens only the engine has seen are appended to the caller's cache before any eager call touches it: a multi-token
+    forward after engine steps gives the logits of a run that never used the engine."""
+    from transformers.cache_utils import DynamicCache
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=12, fused=True, **HOOK_CFG)
+    ids = torch.randint(0, 512, (1, 20), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+
+    def run(hook):
+        model._gptq_engine_disabled = not hook
+        cache = DynamicCache(config=model.config)
+        outs = []
+        with torch.no_grad():
+            outs.append(model(ids[:, :6], past_key_values=cache, use_cache=True).logits[:, -1])      # prefill: eager
+            for i in range(6, 14):                                                                     # 8 single tokens: engine when hooked
+                outs.append(model(ids[:, i:i + 1], past_key_values=cache, use_cache=True).logits[:, -1])
+            outs.append(model(ids[:, 14:17], past_key_values=cache, use_cache=True).logits[:, -1])  # 3 tokens at once: eager again
+            outs.append(model(ids[:, 17:18], past_key_values=cache, use_cache=True).logits[:, -1])  # and back to the engine
+        model._gptq_engine_disabled = False
+        return torch.cat(outs).float().cpu().numpy(), cache.get_seq_length()
+    ref, len_e = run(False)
+    got, len_h = run(True)
+    assert len_e == 18 and len_h >= 17          # the last engine token may still be engine-only (it is synced on demand)
+    assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())

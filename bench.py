@@ -15,10 +15,12 @@ value      = algorithmic GB/s of the whole job (SURVEY 8(d) byte model), all ran
 roofline   = the GEMV kernel family against the 8 TB/s HBM3E spec peak.
 cpu_baseline = the C/OpenMP oracle (oracle/gptq_oracle.c, a port of the reference kernel
              arithmetic) on the host cores, on a bounded sample of the same workload.
---gpus N   = N data-parallel replicas (one process per GPU, no data-path collective; weak
-             scaling).  The row-sharded layout of BASELINE config 5 (one all-reduce per linear) lives in
-             quant/tensor_parallel.py (world_size-2 gloo tests); its per-rank kernel timings on one GPU are in
-             tools/bench_config5.py -- a single-GPU box cannot time the collective.
+--gpus N   = N data-parallel replicas (one process per GPU, no data-path collective; weak scaling) -- the default, = --dp.
+--gpus N --tp row|megatron = BASELINE config 5: LLaMA-65B-shaped decode linears sharded over the N ranks (strong scaling):
+             'row' K-shards every linear on group boundaries with ONE fp32 all-reduce per linear (north_star's layout),
+             'megatron' N-shards qkv / gate / up and K-shards o / down (2 all-reduces per layer).  RCCL over xGMI; the
+             collectives are captured into the hipGraph.  quant/tensor_parallel.py is the module-level counterpart
+             (world_size-2 gloo tests).
 """
 import argparse
 import json
@@ -202,6 +204,132 @@ def larger_model_shapes(dev, reps=5):
         del sts, g
         torch.cuda.empty_cache()
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# BASELINE config 5: LLaMA-65B-shaped 4-bit g128 decode linears, sharded over the ranks (--tp row | megatron)
+# ------------------------------------------------------------------------------------------------------------
+H65, I65 = 8192, 22016
+
+
+class TPLayers:
+    """this rank's shard of `layers` LLaMA-65B-shaped decoder layers (random packed weights), as stripe16 images.
+      mode 'row'      north_star's literal layout: EVERY linear K-(row-)sharded on group boundaries (22016 = 172 groups:
+                      22,22,22,22,21,21,21,21 over 8 ranks), fp32 partials, ONE all-reduce per linear (4 per layer; gate and up
+                      share one), fp16 rounding and SiLU after the reduce
+      mode 'megatron' qkv and gate/up N-(column-)sharded (no collective, SiLU fused), o and down K-sharded: 2 all-reduces per layer
+    The collective is torch.distributed.all_reduce (RCCL over xGMI on MI355X; gloo in the CPU tests)."""
+
+    def __init__(self, dev, rank, world, mode, layers, seed=0):
+        from quant import _native, quant_linear, tensor_parallel as TP
+        self.native, self.lib, self.QL = _native, _native.lib(), quant_linear
+        self.dev, self.rank, self.world, self.mode = dev, rank, world, mode
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1000 + seed)            # every rank draws the same full matrices, then keeps its slice
+        kb_h = TP.row_shard_bounds(H65, GS, BITS, world)[rank]
+        kb_i = TP.row_shard_bounds(I65, GS, BITS, world)[rank]
+        nb_qkv = TP.col_shard_bounds(3 * H65, world)[rank]
+        nb_i = TP.col_shard_bounds(I65, world)[rank]
+        self.kb_h, self.kb_i, self.nb_qkv, self.nb_i = kb_h, kb_i, nb_qkv, nb_i
+
+        def k_shard(w, kb):
+            r0, r1, g0, g1 = kb[0] // 8, kb[1] // 8, kb[0] // GS, kb[1] // GS
+            return w.qweight[r0:r1].contiguous(), w.scales[g0:g1].contiguous(), w.qzeros[g0:g1].contiguous()
+
+        def n_shard(w, nb):
+            return (w.qweight[:, nb[0]:nb[1]].contiguous(), w.scales[:, nb[0]:nb[1]].contiguous(),
+                    w.qzeros[:, nb[0] // 8:nb[1] // 8].contiguous())
+        self.layers = []
+        for _ in range(layers):
+            full = dict(qkv=PackedSet(H65, 3 * H65, dev, gen), o=PackedSet(H65, H65, dev, gen), gate=PackedSet(H65, I65, dev, gen),
+                        up=PackedSet(H65, I65, dev, gen), down=PackedSet(I65, H65, dev, gen))
+            L = {}
+            if mode == 'row':
+                parts = {k: k_shard(full[k], kb_i if k == 'down' else kb_h) for k in full}
+            else:
+                parts = dict(qkv=n_shard(full['qkv'], nb_qkv), gate=n_shard(full['gate'], nb_i), up=n_shard(full['up'], nb_i),
+                             o=k_shard(full['o'], kb_h), down=k_shard(full['down'], kb_i))
+            for k in ('qkv', 'o', 'down'):
+                L[k] = quant_linear.stripe_copy(*parts[k], BITS, GS)
+            L['mlp'] = quant_linear.stripe_copy(*parts['gate'], BITS, GS, up=parts['up'])
+            torch.cuda.synchronize()
+            self.layers.append(L)
+            del full, parts
+        f16, f32 = dict(dtype=torch.float16, device=dev), dict(dtype=torch.float32, device=dev)
+        self.x_h = torch.randn((1, H65), device=dev, generator=gen).half()
+        self.x_i = (torch.randn((1, I65), device=dev, generator=gen) * 0.5).half()
+        self.p_qkv, self.p_h, self.p_mlp = torch.empty((1, 3 * H65), **f32), torch.empty((1, H65), **f32), torch.empty((2, I65), **f32)
+        self.y_qkv, self.y_h, self.y_i = torch.empty((1, 3 * H65), **f16), torch.empty((1, H65), **f16), torch.empty((1, I65), **f16)
+        self.y_qkv_loc = torch.empty((1, nb_qkv[1] - nb_qkv[0]), **f16)
+        self.y_i_loc = torch.empty((1, nb_i[1] - nb_i[0]), **f16)
+        # algorithmic bytes of the FULL (unsharded) layer stack: the whole job moves them once per step
+        self.bytes_per_step = layers * (alg_bytes(1, H65, 3 * H65) + alg_bytes(1, H65, H65) + alg_bytes(1, H65, I65, nsets=2) +
+                                        alg_bytes(1, I65, H65))
+        self.collectives_per_step = layers * (4 if mode == 'row' else 2)
+        self.launches_per_step = 4 * layers
+
+    def _partial(self, x, st, out32, K, N, nsets):
+        rc = self.lib.gptq_stripe_matvec_partial_f32(x.data_ptr(), st.data_ptr(), st.numel(), out32.data_ptr(), K, N, BITS, GS, nsets, None,
+                                                     torch.cuda.current_stream().cuda_stream)
+        self.native.check(rc, 'gptq_stripe_matvec_partial_f32')
+
+    def _full(self, x, st, out16, K, N, nsets):
+        rc = self.lib.gptq_stripe_matvec_f16(x.data_ptr(), st.data_ptr(), st.numel(), None, out16.data_ptr(), K, N, BITS, GS, nsets, None, 0.0,
+                                             None, torch.cuda.current_stream().cuda_stream)
+        self.native.check(rc, 'gptq_stripe_matvec_f16')
+
+    def _reduce(self, t):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t)
+
+    def step(self):
+        kh = slice(*self.kb_h)
+        ki = slice(*self.kb_i)
+        Kh, Ki = self.kb_h[1] - self.kb_h[0], self.kb_i[1] - self.kb_i[0]
+        for L in self.layers:
+            if self.mode == 'row':
+                self._partial(self.x_h[:, kh], L['qkv'], self.p_qkv, Kh, 3 * H65, 1)
+                self._reduce(self.p_qkv)
+                self.y_qkv.copy_(self.p_qkv)                                    # the ONE fp16 rounding
+                self._partial(self.x_h[:, kh], L['o'], self.p_h, Kh, H65, 1)
+                self._reduce(self.p_h)
+                self.y_h.copy_(self.p_h)
+                self._partial(self.x_h[:, kh], L['mlp'], self.p_mlp, Kh, I65, 2)
+                self._reduce(self.p_mlp)
+                torch.mul(torch.nn.functional.silu(self.p_mlp[0:1]), self.p_mlp[1:2], out=self.p_mlp[0:1])   # fp32, fused_mlp.py:160-166
+                self.y_i.copy_(self.p_mlp[0:1])
+                self._partial(self.x_i[:, ki], L['down'], self.p_h, Ki, H65, 1)
+                self._reduce(self.p_h)
+                self.y_h.copy_(self.p_h)
+            else:
+                self._full(self.x_h, L['qkv'], self.y_qkv_loc, H65, self.nb_qkv[1] - self.nb_qkv[0], 1)     # this rank's heads
+                self._partial(self.x_h[:, kh], L['o'], self.p_h, Kh, H65, 1)
+                self._reduce(self.p_h)
+                self.y_h.copy_(self.p_h)
+                self._full(self.x_h, L['mlp'], self.y_i_loc, H65, self.nb_i[1] - self.nb_i[0], 2)           # SiLU fused: columns are local
+                self._partial(self.x_i[:, ki], L['down'], self.p_h, Ki, H65, 1)
+                self._reduce(self.p_h)
+                self.y_h.copy_(self.p_h)
+
+
+def allreduce_latency_us(dev, world, nfloats, reps=50):
+    """mean us of one fp32 all-reduce of nfloats elements, back to back on the stream (reported next to the TP line)."""
+    if world == 1:
+        return 0.0
+    import torch.distributed as dist
+    t = torch.zeros(nfloats, dtype=torch.float32, device=dev)
+    for _ in range(5):
+        dist.all_reduce(t)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dist.all_reduce(t)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
 
 
 def _time_cold(run, nsets, reps=5):
@@ -422,6 +550,11 @@ def main():
     ap.add_argument('--no-per-shape', action='store_true')
     ap.add_argument('--eager', action='store_true', help='time eager launches instead of hipGraph replay')
     ap.add_argument('--kernel', choices=('stripe', 'rowwave'), default='stripe', help='decode matvec kernel family (A/B runs)')
+    ap.add_argument('--tp', choices=('row', 'megatron'), default=None,
+                    help='BASELINE config 5 instead of the replica mode: LLaMA-65B-shaped decode linears sharded over the --gpus ranks '
+                         '(row = every linear K-sharded, one all-reduce per linear; megatron = N-shard qkv/gate/up, K-shard o/down)')
+    ap.add_argument('--tp-layers', type=int, default=16)
+    ap.add_argument('--dp', action='store_true', help='N independent replicas of the single-GPU workload (the default)')
     ap.add_argument('--no-prefill', action='store_true')
     ap.add_argument('--no-config4', action='store_true')
     args = ap.parse_args()
@@ -434,19 +567,41 @@ def main():
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        # test hooks (a 1-GPU box): GPTQ_BENCH_BACKEND=gloo + GPTQ_BENCH_ONE_DEVICE=1 run all ranks on cuda:0 through gloo
+        backend = os.environ.get('GPTQ_BENCH_BACKEND', 'nccl')
+        if os.environ.get('GPTQ_BENCH_ONE_DEVICE'):
+            local_rank = 0
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
 
-    work = DecodeLinears(dev, seed=rank, kernel=args.kernel)
+    if args.tp:
+        work = TPLayers(dev, rank, world, args.tp, args.tp_layers)
+    else:
+        work = DecodeLinears(dev, seed=rank, kernel=args.kernel)
     for _ in range(2):
         work.step()
     torch.cuda.synchronize()
     graph = None
-    if not args.eager:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            work.step()
+    capturable = not (args.tp and distributed and os.environ.get('GPTQ_BENCH_BACKEND', 'nccl') != 'nccl')   # gloo collectives cannot be captured
+    if not args.eager and capturable:
+        try:                       # the collectives are captured with the kernels (RCCL supports stream capture)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                work.step()
+        except Exception:
+            if not args.tp:
+                raise
+            graph = None           # a stack that cannot capture its collectives: eager launches, still correct
+            torch.cuda.synchronize()
+            try:
+                work.step()        # the first launch after an invalidated capture reports (and clears) the runtime's sticky error
+            except RuntimeError:
+                pass
+            torch.cuda.synchronize()
     run = graph.replay if graph is not None else work.step
 
     for _ in range(args.warmup):
@@ -471,6 +626,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
 
+    tp_lat = None
+    if args.tp:   # collectives: every rank takes part
+        tp_lat = {'32KB_fp32_8192': round(allreduce_latency_us(dev, world, H65), 2), '96KB_fp32_24576': round(allreduce_latency_us(dev, world, 3 * H65), 2),
+                  '172KB_fp32_2x22016': round(allreduce_latency_us(dev, world, 2 * I65), 2)}
     if rank == 0:
         ms_per_step = wall_max * 1e3 / args.steps
         total_bytes = work.bytes_per_step * world
@@ -479,6 +638,29 @@ def main():
         bytes_per_launch = work.bytes_per_step / work.launches_per_step
         achieved = bytes_per_launch / us_per_launch / 1e3
         traffic, traffic_src = pmc_traffic()
+        if args.tp:
+            out = {
+                'metric': 'int4 g128 matvec GB/s (LLaMA-65B-shaped 4-bit batch-1 decode linears, sharded over the ranks)',
+                'value': round(work.bytes_per_step / (ms_per_step * 1e-3) / 1e9, 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+                'dtype': 'f16 (int4 weights dequantised on the fly, f32 accumulate, f32 partials across ranks)', 'data': 'synthetic',
+                'config': {'workload': 'LLaMA-65B-shaped 4-bit g128, %s over %d x MI355X, batch=1 decode (BASELINE configs[4]): %d layers x '
+                                       '{qkv 8192x24576, o 8192x8192, gate/up+SiLU 2x8192x22016, down 22016x8192}' %
+                                       ('row-sharded linears with one all-reduce per linear' if args.tp == 'row' else
+                                        'Megatron pairing (N-shard qkv/gate/up, K-shard o/down: 2 all-reduces per layer)', world, args.tp_layers),
+                           'parallelism': 'tp%d %s' % (world, args.tp), 'collective': 'torch.distributed.all_reduce (RCCL over xGMI), fp32',
+                           'collectives_per_step': work.collectives_per_step, 'launch_mode': 'hipGraph replay' if graph is not None else 'eager',
+                           'algorithmic_bytes_per_step': work.bytes_per_step},
+                'allreduce_us': tp_lat,
+                'roofline': {'bound': 'hbm', 'achieved': round(work.bytes_per_step / world / (ms_per_step * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                             'unit': 'GB/s', 'frac': round(work.bytes_per_step / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             'traffic': None, 'kernel': 'gptq::stripe_gemv_kernel (per-GPU share of the bytes / wall time incl. collectives)'},
+            }
+            print(json.dumps(out))
+            if distributed:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         out = {
             'metric': 'int4 g128 matvec GB/s (LLaMA-7B 4-bit batch-1 decode pass over all quantised linears)',
             'value': round(value, 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

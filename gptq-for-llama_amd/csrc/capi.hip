@@ -685,21 +685,23 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
                                 (const half_t *)scales_up, qzeros_up, stripes, K, N, groupsize, (hipStream_t)stream);
 }
 
-int gptq_stripe_matvec_f16(const void *x, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int K, int N, int bits,
-                           int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm, gptq_stream_t stream) {
+static int stripe_matvec(const void *x, const void *stripes, size_t stripes_bytes, const void *bias, void *y, float *y32, int K, int N, int bits,
+                         int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm, gptq_stream_t stream) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     if (K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
-    if (!x || !stripes || !y) return GPTQ_E_NULL;
+    if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
     const int gq = stripe_gq_shift(K, N, bits, groupsize);
-    if (gq == -2 || (nsets == 2 && bias)) return GPTQ_E_VARIANT;
+    if (gq == -2 || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
     if (stripes_bytes < stripe_total_bytes(K, N, bits, groupsize, nsets)) return GPTQ_E_WORKSPACE;
-    if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || (norm_weight && !aligned(norm_weight, 16)) || (perm && !aligned(perm, 16)))
+    if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || !aligned(y32, 4) || (norm_weight && !aligned(norm_weight, 16)) ||
+        (perm && !aligned(perm, 16)))
         return GPTQ_E_ALIGN;
     StripeParams p{};
     p.x = (const half_t *)x;
     p.R = (const uint32_t *)stripes;
     p.tab = (const uint32_t *)((const char *)stripes + stripe_tab_offset(K, N, nsets));
     p.y = (half_t *)y;
+    p.y32 = y32;
     p.bias = (const half_t *)bias;
     p.norm_w = (const half_t *)norm_weight;
     p.norm_eps = norm_eps;
@@ -710,6 +712,18 @@ int gptq_stripe_matvec_f16(const void *x, const void *stripes, size_t stripes_by
     p.NS = nsets;
     p.gq_shift = gq;
     return stripe_gemv_dispatch(p, (hipStream_t)stream);
+}
+
+int gptq_stripe_matvec_f16(const void *x, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int K, int N, int bits,
+                           int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm, gptq_stream_t stream) {
+    if (!y) return GPTQ_E_NULL;
+    return stripe_matvec(x, stripes, stripes_bytes, bias, y, nullptr, K, N, bits, groupsize, nsets, norm_weight, norm_eps, perm, stream);
+}
+
+int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t stripes_bytes, float *y_partial, int K, int N, int bits,
+                                   int groupsize, int nsets, const int32_t *perm, gptq_stream_t stream) {
+    if (!y_partial) return GPTQ_E_NULL;
+    return stripe_matvec(x, stripes, stripes_bytes, nullptr, nullptr, y_partial, K, N, bits, groupsize, nsets, nullptr, 0.f, perm, stream);
 }
 
 // ---- GPTQ solver: the sequential loop of one column block (gptq_solver.hip) ----

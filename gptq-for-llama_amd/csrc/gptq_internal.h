@@ -74,6 +74,7 @@ struct StripeParams {
     const half_t *norm_w;  // non-NULL: RMS-normalise x while it is staged
     float norm_eps;
     const int32_t *xperm;  // non-NULL: x (and norm_w) gathered through this permutation
+    float *y32;            // non-NULL: store the fp32 sums here instead of fp16 y (no bias): partial of a K-sharded layer
     int K, N, G, NS, gq_shift;
 };
 int stripe_gq_shift(int K, int N, int bits, int groupsize);            // log2(groupsize / 32), -1 one group, -2 ineligible

@@ -107,7 +107,7 @@ template <int NU, int NS, int DU, bool NORM, bool XPERM>
 __global__ void __launch_bounds__(STRIPE_NW * 64) stripe_gemv_kernel(const half_t *__restrict__ x, const uint32_t *__restrict__ R,
                                                                      const uint32_t *__restrict__ tab, half_t *__restrict__ y, int K, int nrb, int G,
                                                                      int gq_shift, const half_t *__restrict__ bias, const half_t *__restrict__ nw,
-                                                                     float eps, const int32_t *__restrict__ xperm) {
+                                                                     float eps, const int32_t *__restrict__ xperm, float *__restrict__ y32) {
     typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
     constexpr int NW = STRIPE_NW, T = NW * 64;
     constexpr int XP = (NU + 3) / 4;   // 16-byte pieces of x per thread: K / 8 <= NU * NW * 16 = XP * T (rounded up)
@@ -297,10 +297,15 @@ __global__ void __launch_bounds__(STRIPE_NW * 64) stripe_gemv_kernel(const half_
         }
         float v = a[0];
         if constexpr (NS == 2) v = a[0] * (1.0f / (1.0f + __expf(-a[0]))) * a[1];   // silu on the fp32 accumulator (fused_mlp.py:160-164)
-        half_t h = (half_t)v;
         const int n = stripe * 16 + tid;
-        if (bias) h = (half_t)((float)h + (float)bias[n]);
-        y[n] = h;
+        if (y32) {           // K-shard of a row-sharded layer: the partial sums leave in fp32 (rounded once, after the all-reduce);
+            y32[n] = a[0];   // gate and up separately ([2][N]): SiLU needs the complete sums
+            if constexpr (NS == 2) y32[(size_t)gridDim.x * 16 + n] = a[1];
+        } else {
+            half_t h = (half_t)v;
+            if (bias) h = (half_t)((float)h + (float)bias[n]);
+            y[n] = h;
+        }
     }
 }
 
@@ -323,7 +328,7 @@ int stripe_launch_one(const StripeParams &p, hipStream_t s) {
         }
     }
     hipLaunchKernelGGL(kern, dim3(p.N / 16), dim3(STRIPE_NW * 64), lds, s, p.x, p.R, p.tab, p.y, p.K, p.K / 128, p.G, p.gq_shift, p.bias,
-                       p.norm_w, p.norm_eps, p.xperm);
+                       p.norm_w, p.norm_eps, p.xperm, p.y32);
     return (int)hipGetLastError();
 }
 

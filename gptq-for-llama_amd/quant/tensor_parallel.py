@@ -95,8 +95,35 @@ def _default_matmul(x2, s):
     return matmul248(x2, s.qweight, s.scales, s.qzeros, s.g_idx, s.bits, s.maxq, bias=s.bias)
 
 
+def _default_partial(x2, s):
+    """fp32 partial [M, N] of a K-shard: the stripe16 kernel stores its fp32 sums unrounded at M == 1
+    (gptq_stripe_matvec_partial_f32); other shapes go through the fp16 kernels (one extra rounding per shard)."""
+    from . import _native
+    from .quant_linear import _as_rows, _int32c, act_order_sorted, stripe_copy
+    if x2.shape[0] == 1 and s.bits == 4 and x2.is_cuda:
+        K, N = s.qweight.shape[0] * 8, s.qweight.shape[1]
+        gs = s.groupsize if s.groupsize != -1 else K
+        qw, perm = _int32c(s.qweight), None
+        if not g_idx_is_trivial(s.g_idx, K, gs):
+            srt = act_order_sorted(qw, _int32c(s.g_idx[:K]), K, gs, 4)
+            qw, perm = (srt if srt is not None else (None, None))
+        st = stripe_copy(qw, s.scales, _int32c(s.qzeros), 4, gs) if qw is not None else None
+        if st is not None:
+            x = _as_rows(x2)
+            with torch.cuda.device(x.device):
+                part = torch.empty((1, N), dtype=torch.float32, device=x.device)
+                rc = _native.lib().gptq_stripe_matvec_partial_f32(x.data_ptr(), st.data_ptr(), st.numel(), part.data_ptr(), K, N, 4, gs, 1,
+                                                                  _native.ptr(perm), _native.stream_ptr(x.device))
+            _native.check(rc, 'gptq_stripe_matvec_partial_f32')
+            return part
+    return matmul248(x2, s.qweight, s.scales, s.qzeros, s.g_idx, s.bits, s.maxq).float()
+
+
 class RowShardedQuantLinear(nn.Module):
-    """This rank's K-slice of a QuantLinear + one all-reduce per forward."""
+    """This rank's K-slice of a QuantLinear + ONE all-reduce per forward (BASELINE config 5).  The partial sums travel in
+    fp32 and are rounded to fp16 once, after the reduce -- the same rounding order as the unsharded layer (fp16 partials
+    would add one rounding per shard: ~2e-3 instead of the 1e-3 budget); the bias is added after that, as in
+    QuantLinear.forward (reference quant_linear.py:376)."""
 
     def __init__(self, layer, rank=None, world=None, group=None, matmul_fn=None):
         super().__init__()
@@ -106,18 +133,23 @@ class RowShardedQuantLinear(nn.Module):
         self.world = dist.get_world_size(group) if world is None else world
         trivial = g_idx_is_trivial(layer.g_idx, layer.infeatures, layer.groupsize)   # act-order shards keep every group
         self.shard, (self.k0, self.k1) = shard_rows(layer, self.rank, self.world, trivial_g_idx=trivial)
+        self.shard.bias = None              # added once, after the reduce
+        self.bias = layer.bias
         self.outfeatures = layer.outfeatures
         self.infeatures = layer.infeatures
-        self._matmul = matmul_fn or _default_matmul
+        self._partial = matmul_fn or _default_partial
 
     def forward(self, x):
         import torch.distributed as dist
         out_shape = x.shape[:-1] + (self.outfeatures, )
         x2 = x.reshape(-1, x.shape[-1])[:, self.k0:self.k1]
-        part = self._matmul(x2, self.shard)
+        part = self._partial(x2, self.shard).float()
         if self.world > 1:
             dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
-        return part.reshape(out_shape)
+        y = part.half()
+        if self.bias is not None:
+            y = y + self.bias
+        return y.reshape(out_shape)
 
 
 class ColShardedQuantLinear(nn.Module):

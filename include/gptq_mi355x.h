@@ -261,6 +261,12 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
                        gptq_stream_t stream);
 int gptq_stripe_matvec_f16(const void *x, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int K, int N, int bits,
                            int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm, gptq_stream_t stream);
+/* The same matvec with the fp32 sums stored unrounded: the per-rank PARTIAL of a row-(K-)sharded layer (BASELINE config 5,
+ * quant/tensor_parallel.py) -- the shards are summed by ONE all-reduce and rounded to fp16 once, like the unsharded layer.
+ * y_partial is fp32 [nsets][N]: with nsets == 2 the gate and the up sums are stored separately (no SiLU: it needs the
+ * complete sums). */
+int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t stripes_bytes, float *y_partial, int K, int N, int bits,
+                                   int groupsize, int nsets, const int32_t *perm, gptq_stream_t stream);
 
 /* ---- GPTQ solver (the caller that PRODUCES the weights; reference gptq.py:128-228) -------------------------------
  * One column block [i1, i1 + count), count <= 128, of the sequential quantise / error-feedback loop (gptq.py:177-199)

@@ -434,21 +434,43 @@ def test_linearity_property_full_size():
     assert np.abs(ys - lin).max() / np.abs(lin).max() < 3e-3
 
 
-def test_row_shards_sum_to_full():
-    """BASELINE config 5 emulated on one GPU: 8 K-shards' partials sum to the full product."""
+@pytest.mark.parametrize('K,N,world,M', [(8192, 512, 8, 1), (22016, 256, 8, 1), (1024, 512, 8, 2), (4096, 11008, 4, 1)])
+def test_row_shards_sum_to_full(K, N, world, M):
+    """BASELINE config 5 emulated on one GPU: the fp32 partials of the K-shards (stripe16 kernel, unrounded sums at M == 1;
+    uneven group counts for K = 22016: 22,22,22,22,21,21,21,21) sum to the full product, rounded to fp16 ONCE: 1e-3 vs the
+    oracle like the unsharded layer."""
     from quant import tensor_parallel as tp
-    K, N = 1024, 512
     L = make_random_layer(4, 128, K, N, seed=3)
     layer = quant.QuantLinear(4, 128, K, N, False)
     layer.qweight, layer.qzeros, layer.scales, layer.g_idx = (dev(L['qweight']), dev(L['qzeros']), dev(L['scales']),
                                                                dev(L['g_idx']))
-    x = dev(np.random.default_rng(0).standard_normal((2, K)).astype(np.float16))
-    full = layer(x).float()
-    acc = torch.zeros_like(full)
-    for r in range(8):
-        shard, (k0, k1) = tp.shard_rows(layer, r, 8)
-        acc += tp._default_matmul(x[:, k0:k1].contiguous(), shard).float()
-    assert rel_err(acc.cpu().numpy(), full.cpu().numpy()) < 2e-3
+    xh = np.random.default_rng(0).standard_normal((M, K)).astype(np.float16)
+    x = dev(xh)
+    acc = torch.zeros((M, N), dtype=torch.float32, device=DEV)
+    for r in range(world):
+        shard, (k0, k1) = tp.shard_rows(layer, r, world)
+        shard.bias = None
+        part = tp._default_partial(x[:, k0:k1].contiguous(), shard)
+        assert part.dtype == torch.float32
+        acc += part
+    ref = oracle_forward(xh, L)
+    assert rel_err(acc.half().cpu().numpy(), ref) < TOL
+
+
+def test_stripe_partial_f32_gate_up_pair():
+    """nsets = 2: the gate and the up sums of a K-shard leave separately ([2][N] fp32, no SiLU)"""
+    K, N = 1024, 288
+    A, B = make_random_layer(4, 128, K, N, seed=61), make_random_layer(4, 128, K, N, seed=62)
+    st, _ = _stripe_image([A, B], 128)
+    x = (np.random.default_rng(9).standard_normal((1, K))).astype(np.float16)
+    part = torch.empty((2, N), dtype=torch.float32, device=DEV)
+    rc = _native.lib().gptq_stripe_matvec_partial_f32(dev(x).data_ptr(), st.data_ptr(), st.numel(), part.data_ptr(), K, N, 4, 128, 2, None,
+                                                      _native.stream_ptr(torch.device(DEV)))
+    _native.check(rc, 'gptq_stripe_matvec_partial_f32')
+    torch.cuda.synchronize()
+    for i, L in enumerate((A, B)):
+        ref = oracle.matmul248_exact(x, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)
+        assert rel_err(part[i:i + 1].cpu().numpy(), ref) < 2e-4         # fp32 result vs the float64 oracle: no fp16 rounding left
 
 
 def test_gpu_pack_bit_exact():
@@ -841,3 +863,57 @@ def test_3bit_fused_mlp_rowwave(gs, K, N):
         c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 3, K if gs == -1 else gs)
         ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), 3)
         assert rel_err(c.cpu().numpy(), ref) < TOL
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE config 5 with REAL kernels and a REAL collective on the one GPU of the test box: two processes share cuda:0
+# and all-reduce their fp32 partials through gloo (RCCL refuses two ranks on one device; on an 8-GPU node the same
+# module runs on "nccl" = RCCL over xGMI)
+# ---------------------------------------------------------------------------------------
+def _tp_gpu_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from quant import tensor_parallel as tp
+        torch.cuda.set_device(0)
+        ok = True
+        for K, N, M, act in [(8192, 512, 1, False), (2816 * 2, 256, 1, False), (1024 + 128, 256, 3, False), (2048, 288, 1, True)]:
+            L = make_random_layer(4, 128, K, N, act_order=act, seed=K + N)
+            bias = np.random.default_rng(1).standard_normal(N).astype(np.float16)
+            layer = quant.QuantLinear(4, 128, K, N, True)
+            layer.qweight, layer.qzeros, layer.scales, layer.g_idx, layer.bias = (dev(L['qweight']), dev(L['qzeros']), dev(L['scales']),
+                                                                                  dev(L['g_idx']), dev(bias))
+            xh = np.random.default_rng(2).standard_normal((M, K)).astype(np.float16)
+            row = tp.RowShardedQuantLinear(layer)
+            y = row(dev(xh)).cpu().numpy()
+            ref = oracle.matmul248(xh, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4, bias=bias)
+            ok = ok and rel_err(y, ref) < 2 * TOL              # bias: two fp16 roundings, see test_stripe_matvec_vs_oracle
+            y0 = row.forward(dev(xh)) - dev(bias)
+            ok = ok and rel_err(y0.cpu().numpy(), oracle.matmul248(xh, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)) < 2 * TOL
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            ret.put(int(t.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_linear_two_processes_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_tp_gpu_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == 1

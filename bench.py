@@ -94,7 +94,7 @@ class DecodeLinears:
         self.launches_per_step = 4 * layers
 
     def _stripe(self, x, st, y, K, N, nsets, stream):
-        rc = self.lib.gptq_stripe_matvec_f16(x.data_ptr(), st.data_ptr(), st.numel(), None, y.data_ptr(), K, N, BITS, GS, nsets,
+        rc = self.lib.gptq_stripe_matvec_f16(x.data_ptr(), K, st.data_ptr(), st.numel(), None, y.data_ptr(), N, 1, K, N, BITS, GS, nsets,
                                              None, 0.0, None, stream)
         self.native.check(rc, 'gptq_stripe_matvec_f16')
 
@@ -181,8 +181,8 @@ def larger_model_shapes(dev, reps=5):
 
         def launch(i):
             st = sts[i]
-            rc = lib.gptq_stripe_matvec_f16(x.data_ptr(), st.data_ptr(), st.numel(), None, y.data_ptr(), K, N, BITS, GS, 2 if fused else 1,
-                                            None, 0.0, None, torch.cuda.current_stream().cuda_stream)
+            rc = lib.gptq_stripe_matvec_f16(x.data_ptr(), K, st.data_ptr(), st.numel(), None, y.data_ptr(), N, 1, K, N, BITS, GS,
+                                            2 if fused else 1, None, 0.0, None, torch.cuda.current_stream().cuda_stream)
             _native.check(rc, name)
         for i in range(nsets):
             launch(i)
@@ -274,8 +274,8 @@ class TPLayers:
         self.native.check(rc, 'gptq_stripe_matvec_partial_f32')
 
     def _full(self, x, st, out16, K, N, nsets):
-        rc = self.lib.gptq_stripe_matvec_f16(x.data_ptr(), st.data_ptr(), st.numel(), None, out16.data_ptr(), K, N, BITS, GS, nsets, None, 0.0,
-                                             None, torch.cuda.current_stream().cuda_stream)
+        rc = self.lib.gptq_stripe_matvec_f16(x.data_ptr(), K, st.data_ptr(), st.numel(), None, out16.data_ptr(), N, 1, K, N, BITS, GS, nsets, None,
+                                             0.0, None, torch.cuda.current_stream().cuda_stream)
         self.native.check(rc, 'gptq_stripe_matvec_f16')
 
     def _reduce(self, t):

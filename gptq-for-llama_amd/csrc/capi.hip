@@ -666,7 +666,7 @@ int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k
                                     (float *)workspace, heads, t_max, base, scale, (hipStream_t)stream);
 }
 
-// ---- stripe16: no-split-K decode GEMV on a load-time repacked copy (stripe.hip) ----
+// ---- stripe16: no-split-K decode GEMV on a load-time repacked copy (stripe*.hip) ----
 size_t gptq_stripe_bytes(int K, int N, int bits, int groupsize, int nsets) { return stripe_total_bytes(K, N, bits, groupsize, nsets); }
 
 int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *qweight_up, const void *scales_up,
@@ -682,48 +682,56 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
     if (stripes_bytes < need) return GPTQ_E_WORKSPACE;
     if (!aligned(qweight, 4) || !aligned(scales, 2) || !aligned(qzeros, 4) || !aligned(stripes, 16)) return GPTQ_E_ALIGN;
     return stripe_repack_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, (const uint32_t *)qweight_up,
-                                (const half_t *)scales_up, qzeros_up, stripes, K, N, groupsize, (hipStream_t)stream);
+                                (const half_t *)scales_up, qzeros_up, stripes, K, N, bits, groupsize, (hipStream_t)stream);
 }
 
-static int stripe_matvec(const void *x, const void *stripes, size_t stripes_bytes, const void *bias, void *y, float *y32, int K, int N, int bits,
-                         int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm, gptq_stream_t stream) {
+static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, float *y32,
+                         int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm,
+                         gptq_stream_t stream) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
-    if (K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
+    if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
     const int gq = stripe_gq_shift(K, N, bits, groupsize);
-    if (gq == -2 || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
+    if (gq == -2 || M > 4 || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
+    if (M > 1 && (norm_weight || perm || y32)) return GPTQ_E_VARIANT;
     if (stripes_bytes < stripe_total_bytes(K, N, bits, groupsize, nsets)) return GPTQ_E_WORKSPACE;
     if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || !aligned(y32, 4) || (norm_weight && !aligned(norm_weight, 16)) ||
-        (perm && !aligned(perm, 16)))
+        (perm && !aligned(perm, 16)) || (M > 1 && (ldx % 8 != 0 || ldy < N)))
         return GPTQ_E_ALIGN;
+    if (M == 0) return 0;
     StripeParams p{};
     p.x = (const half_t *)x;
+    p.ldx = ldx;
+    p.ldy = ldy;
     p.R = (const uint32_t *)stripes;
-    p.tab = (const uint32_t *)((const char *)stripes + stripe_tab_offset(K, N, nsets));
+    p.tab = (const uint32_t *)((const char *)stripes + stripe_tab_offset(K, N, bits, nsets));
     p.y = (half_t *)y;
     p.y32 = y32;
     p.bias = (const half_t *)bias;
     p.norm_w = (const half_t *)norm_weight;
     p.norm_eps = norm_eps;
     p.xperm = perm;
+    p.M = M;
     p.K = K;
     p.N = N;
     p.G = groupsize >= K ? 1 : K / groupsize;
     p.NS = nsets;
     p.gq_shift = gq;
+    p.bits = bits;
     return stripe_gemv_dispatch(p, (hipStream_t)stream);
 }
 
-int gptq_stripe_matvec_f16(const void *x, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int K, int N, int bits,
-                           int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm, gptq_stream_t stream) {
+int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
+                           int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm,
+                           gptq_stream_t stream) {
     if (!y) return GPTQ_E_NULL;
-    return stripe_matvec(x, stripes, stripes_bytes, bias, y, nullptr, K, N, bits, groupsize, nsets, norm_weight, norm_eps, perm, stream);
+    return stripe_matvec(x, ldx, stripes, stripes_bytes, bias, y, ldy, nullptr, M, K, N, bits, groupsize, nsets, norm_weight, norm_eps, perm, stream);
 }
 
 int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t stripes_bytes, float *y_partial, int K, int N, int bits,
                                    int groupsize, int nsets, const int32_t *perm, gptq_stream_t stream) {
     if (!y_partial) return GPTQ_E_NULL;
-    return stripe_matvec(x, stripes, stripes_bytes, nullptr, nullptr, y_partial, K, N, bits, groupsize, nsets, nullptr, 0.f, perm, stream);
+    return stripe_matvec(x, K, stripes, stripes_bytes, nullptr, nullptr, N, y_partial, 1, K, N, bits, groupsize, nsets, nullptr, 0.f, perm, stream);
 }
 
 // ---- GPTQ solver: the sequential loop of one column block (gptq_solver.hip) ----

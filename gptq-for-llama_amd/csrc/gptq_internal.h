@@ -67,21 +67,22 @@ int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out
 // ---- stripe16: no-split-K GEMV on a load-time repacked copy (stripe.hip) ----
 struct StripeParams {
     const half_t *x;
-    const uint32_t *R;     // [N/16][K/128][NS][64][4]
+    int64_t ldx, ldy;      // row strides of x / y (elements); M = 1: unused
+    const uint32_t *R;     // [N/16][K/(16 KPW)][NS][64][4]
     const uint32_t *tab;   // half2 [N/16][NS][G][16] {scale, zero + 1}
     half_t *y;
     const half_t *bias;
-    const half_t *norm_w;  // non-NULL: RMS-normalise x while it is staged
+    const half_t *norm_w;  // non-NULL: RMS-normalise x while it is staged (M == 1)
     float norm_eps;
-    const int32_t *xperm;  // non-NULL: x (and norm_w) gathered through this permutation
-    float *y32;            // non-NULL: store the fp32 sums here instead of fp16 y (no bias): partial of a K-sharded layer
-    int K, N, G, NS, gq_shift;
+    const int32_t *xperm;  // non-NULL: x (and norm_w) gathered through this permutation (M == 1)
+    float *y32;            // non-NULL: store the fp32 sums here instead of fp16 y (no bias): partial of a K-sharded layer (M == 1)
+    int M, K, N, G, NS, gq_shift, bits;
 };
-int stripe_gq_shift(int K, int N, int bits, int groupsize);            // log2(groupsize / 32), -1 one group, -2 ineligible
-size_t stripe_tab_offset(int K, int N, int nsets);
+int stripe_gq_shift(int K, int N, int bits, int groupsize);            // log2(groupsize / (4 KPW)), -1 one group, -2 ineligible
+size_t stripe_tab_offset(int K, int N, int bits, int nsets);
 size_t stripe_total_bytes(int K, int N, int bits, int groupsize, int nsets);
 int stripe_repack_launch(const uint32_t *qw0, const half_t *sc0, const int32_t *qz0, const uint32_t *qw1, const half_t *sc1,
-                         const int32_t *qz1, void *out, int K, int N, int groupsize, hipStream_t s);
+                         const int32_t *qz1, void *out, int K, int N, int bits, int groupsize, hipStream_t s);
 int stripe_gemv_dispatch(const StripeParams &p, hipStream_t s);
 
 int gptq_block_launch(const float *W, int64_t ldw, const float *Hinv, int64_t ldh, int rows, int i1, int count, int groupsize, int maxq,

@@ -70,8 +70,8 @@ _SIGNATURES = {
     'gptq_stripe_bytes': [c_int, c_int, c_int, c_int, c_int],
     'gptq_stripe_repack': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
                            c_void_p],
-    'gptq_stripe_matvec_f16': [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float,
-                               c_void_p, c_void_p],
+    'gptq_stripe_matvec_f16': [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,
+                               c_void_p, c_float, c_void_p, c_void_p],
     'gptq_stripe_matvec_partial_f32': [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
 }
 

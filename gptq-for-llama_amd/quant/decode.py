@@ -196,7 +196,7 @@ class DecodeEngine:
             g, u = L['gate'], L['up']
             g['pair_sorted'] = (g['srt'] is not None and u['srt'] is not None and bool(torch.equal(g['srt'][1], u['srt'][1])))
             g['st2'] = None     # gate and up in ONE stripe16 image (silu(gate) * up in the kernel epilogue)
-            if g['bits'] == 4 and ((g['gi'] is None and u['gi'] is None) or g['pair_sorted']):
+            if g['bits'] in (2, 4, 8) and ((g['gi'] is None and u['gi'] is None) or g['pair_sorted']):
                 a, b = (g['srt'][0], u['srt'][0]) if g['pair_sorted'] else (g['qw'], u['qw'])
                 g['st2'] = quant_linear.stripe_copy(a, g['sc'], g['qz'], g['bits'], g['gs'], up=(b, u['sc'], u['qz']))
         H, I = self.hidden, cfg.intermediate_size
@@ -225,7 +225,7 @@ class DecodeEngine:
         if g_idx is not None and not quant_linear.g_idx_is_trivial(g_idx, K, groupsize):
             gi = quant_linear._int32c(g_idx[:K])
         qw = quant_linear._int32c(qweight)
-        srt = quant_linear.act_order_sorted(qw, gi, K, groupsize, bits) if (gi is not None and bits == 4) else None
+        srt = quant_linear.act_order_sorted(qw, gi, K, groupsize, bits) if (gi is not None and bits in (2, 4, 8)) else None
         qz = quant_linear._int32c(qzeros)
         # stripe16 image (csrc/stripe.hip) of the layer, or of its group-sorted rows for an act-order layer: the decode kernel
         st = quant_linear.stripe_copy(srt[0] if srt is not None else qw, scales, qz, bits, groupsize) if (gi is None or srt is not None) else None

@@ -39,16 +39,16 @@ def fused_gate_up(x, gate, up, bits, groupsize):
     gis = []
     for (qw, sc, qz, gi) in (gate, up):
         gis.append(None if (gi is None or g_idx_is_trivial(gi, K, groupsize)) else _int32c(gi[:K]))
-    if M == 1 and bits == 4 and all(gi is None for gi in gis):
-        # decode: gate and up packed into ONE stripe16 image, silu(gate) * up in the kernel epilogue
+    if 1 <= M <= 4 and bits in (2, 4, 8) and all(gi is None for gi in gis):
+        # decode (and batches of up to 4 rows): gate and up packed into ONE stripe16 image, silu(gate) * up in the kernel epilogue
         from .quant_linear import stripe_copy, stripe_matvec
         st = stripe_copy(_int32c(gate[0]), gate[1], _int32c(gate[2]), bits, groupsize, up=(_int32c(up[0]), up[1], _int32c(up[2])))
         if st is not None:
             with torch.cuda.device(x.device):
                 c = torch.empty((M, N), device=x.device, dtype=torch.float16)
-                stripe_matvec(x2, st, c, K, N, bits, groupsize, nsets=2)
-            return c
-    if M == 1 and bits == 4 and all(gi is not None for gi in gis):
+                if stripe_matvec(x2, st, c, K, N, bits, groupsize, nsets=2, strict=False):
+                    return c
+    if M == 1 and bits in (2, 4, 8) and all(gi is not None for gi in gis):
         # act-order MLP at decode: gate and up share their input, hence their act-order permutation -> one x gather,
         # two group-sorted weight copies (cached on the tensors), the trivial-g_idx fused kernel
         from .quant_linear import act_order_sorted, stripe_copy, stripe_matvec

@@ -119,8 +119,8 @@ STRIPE = _os.environ.get('GPTQ_STRIPE', '1') != '0'
 def stripe_copy(qweight, scales, qzeros, bits, groupsize, up=None):
     """uint8 tensor holding the stripe16 image of (qweight, scales, qzeros) -- or of the pair with
     ``up = (qweight, scales, qzeros)`` for the fused gate/up matvec -- or None when the shape is not served
-    (bits != 4, K % 128, group size not a power-of-two multiple of 32 ...)."""
-    if not STRIPE or bits != 4 or not qweight.is_cuda:
+    (3-bit, K not a multiple of 16 * 32 / bits, group size not a power-of-two multiple of 4 * 32 / bits ...)."""
+    if not STRIPE or bits not in (2, 4, 8) or not qweight.is_cuda:
         return None
     K, N = qweight.shape[0] * 32 // bits, qweight.shape[1]
     lib = _native.lib()
@@ -148,12 +148,21 @@ def stripe_copy(qweight, scales, qzeros, bits, groupsize, up=None):
     return st
 
 
-def stripe_matvec(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, norm_weight=None, eps=0.0, perm=None):
-    """out[1, N] = x[1, K] through a stripe16 image (gptq_stripe_matvec_f16) on the current stream."""
-    rc = _native.lib().gptq_stripe_matvec_f16(x.data_ptr(), st.data_ptr(), st.numel(), _native.ptr(bias), out.data_ptr(), K, N, bits,
-                                              groupsize, nsets, _native.ptr(norm_weight), float(eps), _native.ptr(perm),
-                                              _native.stream_ptr(x.device))
+def stripe_matvec(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, norm_weight=None, eps=0.0, perm=None, strict=True):
+    """out[M, N] = x[M, K] (1 <= M <= 4) through a stripe16 image (gptq_stripe_matvec_f16) on the current stream.
+    strict=False: return False instead of raising when the kernel does not serve the call (GPTQ_E_VARIANT: e.g. four rows of a
+    very long K do not fit in LDS) so that the caller can take another kernel family."""
+    M = x.shape[0]
+    rc = _native.lib().gptq_stripe_matvec_f16(x.data_ptr(), x.stride(0) if M > 1 else K, st.data_ptr(), st.numel(), _native.ptr(bias),
+                                              out.data_ptr(), out.stride(0) if M > 1 else N, M, K, N, bits, groupsize, nsets,
+                                              _native.ptr(norm_weight), float(eps), _native.ptr(perm), _native.stream_ptr(x.device))
+    if rc == -6 and not strict:
+        return False
     _native.check(rc, 'gptq_stripe_matvec_f16')
+    return True
+
+
+STRIPE_MAX_M = 4   # rows of x one stripe16 launch serves (the MFMA 4x4x4 computes four rows at the price of one)
 
 
 def _as_rows(t):
@@ -262,14 +271,14 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
             return out
         ws = _native.workspace(x.device)
         srt = act_order_sorted(qweight, gi, K, groupsize, bits) if gi is not None else None
-        if M == 1 and family in (None, 'stripe') and (gi is None or srt is not None):
+        if family in (None, 'stripe') and ((M == 1 and (gi is None or srt is not None)) or (M <= STRIPE_MAX_M and gi is None)):
             # decode: no-split-K kernel on the stripe16 copy (of the group-sorted rows for an act-order layer)
             st = stripe_copy(srt[0] if srt is not None else qweight, scales, qzeros, bits, groupsize)
-            if st is not None:
-                stripe_matvec(x, st, out, K, N, bits, groupsize, bias=bias, perm=srt[1] if srt is not None else None)
+            if st is not None and stripe_matvec(x, st, out, K, N, bits, groupsize, bias=bias, perm=srt[1] if srt is not None else None,
+                                                strict=family == 'stripe'):
                 return out
         if family == 'stripe':
-            raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M == 1, 4-bit, K % 128 == 0 ...)')
+            raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M <= 4, bits in 2/4/8, K a multiple of the row block ...)')
         if srt is not None:
             _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family)
             return out

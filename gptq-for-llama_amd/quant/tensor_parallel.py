@@ -100,19 +100,19 @@ def _default_partial(x2, s):
     (gptq_stripe_matvec_partial_f32); other shapes go through the fp16 kernels (one extra rounding per shard)."""
     from . import _native
     from .quant_linear import _as_rows, _int32c, act_order_sorted, stripe_copy
-    if x2.shape[0] == 1 and s.bits == 4 and x2.is_cuda:
-        K, N = s.qweight.shape[0] * 8, s.qweight.shape[1]
+    if x2.shape[0] == 1 and s.bits in (2, 4, 8) and x2.is_cuda:
+        K, N = s.qweight.shape[0] * 32 // s.bits, s.qweight.shape[1]
         gs = s.groupsize if s.groupsize != -1 else K
         qw, perm = _int32c(s.qweight), None
         if not g_idx_is_trivial(s.g_idx, K, gs):
-            srt = act_order_sorted(qw, _int32c(s.g_idx[:K]), K, gs, 4)
+            srt = act_order_sorted(qw, _int32c(s.g_idx[:K]), K, gs, s.bits)
             qw, perm = (srt if srt is not None else (None, None))
-        st = stripe_copy(qw, s.scales, _int32c(s.qzeros), 4, gs) if qw is not None else None
+        st = stripe_copy(qw, s.scales, _int32c(s.qzeros), s.bits, gs) if qw is not None else None
         if st is not None:
             x = _as_rows(x2)
             with torch.cuda.device(x.device):
                 part = torch.empty((1, N), dtype=torch.float32, device=x.device)
-                rc = _native.lib().gptq_stripe_matvec_partial_f32(x.data_ptr(), st.data_ptr(), st.numel(), part.data_ptr(), K, N, 4, gs, 1,
+                rc = _native.lib().gptq_stripe_matvec_partial_f32(x.data_ptr(), st.data_ptr(), st.numel(), part.data_ptr(), K, N, s.bits, gs, 1,
                                                                   _native.ptr(perm), _native.stream_ptr(x.device))
             _native.check(rc, 'gptq_stripe_matvec_partial_f32')
             return part

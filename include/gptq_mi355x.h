@@ -245,22 +245,25 @@ int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k
  * Replaces, for M == 1, the launch of matmul_248_kernel (quant/quant_linear.py:263-269) / fusedmatmul_248_kernel
  * (quant/fused_mlp.py:206-218) on a layout the library owns: the checkpoint buffers are repacked ONCE at load time
  * (the reference has no counterpart; its load path ends at load_state_dict, llama_inference.py:57-60) into
- *   R   uint32 [N/16][K/128][nsets][64][4]  every workgroup's 16 columns contiguous, 1 KiB per wave load, nibbles
+ *   R   uint32 [N/16][K/128][nsets][64][4]  (4-bit) every workgroup's 16 columns contiguous, 1 KiB per wave load, fields
  *                                            re-ordered for a one-shift unpack (see csrc/stripe.hip)
  *   tab half2  [N/16][nsets][G][16]          {scale, zero + 1} per (group, column)
- * stored back to back in ONE buffer of gptq_stripe_bytes() bytes (0 = shape not eligible: bits must be 4,
- * K % 128 == 0, K <= 24576, groupsize a power-of-two multiple of 32 that divides K, or >= K).  The checkpoint buffers are not
- * modified and stay the owner of the state_dict.  nsets == 2 packs gate and up together and the matvec returns
- * silu(x Wg) * (x Wu).  norm_weight != NULL fuses the RMSNorm of x (rms_norm_fwd_fused, quant/triton_norm.py:22-39)
- * in front; perm != NULL reads x (and norm_weight) through a permutation (an act-order layer whose qweight rows were
- * sorted by group with gptq_act_order_repack BEFORE gptq_stripe_repack).  No workspace, no atomics: results are
- * bit-identical run to run. */
+ * stored back to back in ONE buffer of gptq_stripe_bytes() bytes (0 = shape not eligible: bits in {2, 4, 8}; K a multiple of
+ * 16 * (32 / bits) = 256 / 128 / 64 and at most 24576 / 24576 / 22528; groupsize a power-of-two multiple of 4 * (32 / bits)
+ * that divides K, or >= K).  For 8 and 2 bits the same geometry holds with 32 / bits k per word; see csrc/stripe.hip.  The
+ * checkpoint buffers are not modified and stay the owner of the state_dict.  nsets == 2 packs gate and up together and the
+ * matvec returns silu(x Wg) * (x Wu).  1 <= M <= 4 rows of x (row strides ldx / ldy) cost the same weight stream as one: the
+ * MFMA computes four rows anyway.  M == 1 only: norm_weight != NULL fuses the RMSNorm of x (rms_norm_fwd_fused,
+ * quant/triton_norm.py:22-39) in front; perm != NULL reads x through a permutation (an act-order layer whose qweight rows were
+ * sorted by group with gptq_act_order_repack BEFORE gptq_stripe_repack).  No workspace, no atomics: results are bit-identical
+ * run to run. */
 size_t gptq_stripe_bytes(int K, int N, int bits, int groupsize, int nsets);
 int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *qweight_up, const void *scales_up,
                        const int32_t *qzeros_up, void *stripes, size_t stripes_bytes, int K, int N, int bits, int groupsize,
                        gptq_stream_t stream);
-int gptq_stripe_matvec_f16(const void *x, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int K, int N, int bits,
-                           int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm, gptq_stream_t stream);
+int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
+                           int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm,
+                           gptq_stream_t stream);
 /* The same matvec with the fp32 sums stored unrounded: the per-rank PARTIAL of a row-(K-)sharded layer (BASELINE config 5,
  * quant/tensor_parallel.py) -- the shards are summed by ONE all-reduce and rounded to fp16 once, like the unsharded layer.
  * y_partial is fp32 [nsets][N]: with nsets == 2 the gate and the up sums are stored separately (no SiLU: it needs the

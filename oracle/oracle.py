@@ -304,52 +304,59 @@ def np_pack_fields_cols(fields, bits):
 # llama_inference.py:57-60); this restatement pins gptq_stripe_repack bit for bit and proves the layout
 # is a bijection of the checkpoint buffers (stripe16_unpack is its inverse).
 # --------------------------------------------------------------------------------------
-STRIPE_K_OF_POS = (0, 2, 4, 6, 1, 3, 5, 7)   # nibble position p (bits 4p..4p+3) of a stripe word holds k = K_OF_POS[p]
+def stripe_k_of_pos(bits):
+    """field position p (bits bits*p ..) of a stripe word holds k = k_of_pos[p] of the packed row: even k low half, odd k high half"""
+    F = 32 // bits
+    return tuple(2 * p if p < F // 2 else 2 * (p - F // 2) + 1 for p in range(F))
 
 
-def stripe16_repack(sets, groupsize):
+def stripe16_repack(sets, groupsize, bits=4):
     """sets = [(qweight, scales, qzeros)] (one set, or gate and up) in the checkpoint format
-    (reference quant_linear.py:316-321) -> uint8 image: R uint32 [N/16][K/128][NS][64][4] followed by
-    tab half2 [N/16][NS][G][16] {scale, zero + 1}."""
+    (reference quant_linear.py:316-321) -> uint8 image: R uint32 [N/16][K/(16 KPW)][NS][64][4] followed by
+    tab half2 [N/16][NS][G][16] {scale, zero + 1}; KPW = 32 / bits."""
     NS = len(sets)
+    kpw = 32 // bits
     qw0 = np.asarray(sets[0][0]).astype(np.int32).view(np.uint32)
     rows, N = qw0.shape
-    K = rows * 8
-    assert K % 128 == 0 and N % 16 == 0
-    nrb, S = K // 128, N // 16
+    K = rows * kpw
+    assert K % (16 * kpw) == 0 and N % 16 == 0
+    nrb, S = rows // 16, N // 16
     gs = K if groupsize in (-1, None) or groupsize >= K else groupsize
     G = K // gs
     R = np.empty((S, nrb, NS, 64, 4), dtype=np.uint32)
     tab = np.empty((S, NS, G, 16), dtype=np.uint32)
+    fm = np.uint32((1 << bits) - 1)
     for si, (qw, sc, qz) in enumerate(sets):
         w = np.asarray(qw).astype(np.int32).view(np.uint32)
         o = np.zeros_like(w)
-        for pos, k in enumerate(STRIPE_K_OF_POS):
-            o |= ((w >> np.uint32(4 * k)) & np.uint32(15)) << np.uint32(4 * pos)
+        for pos, k in enumerate(stripe_k_of_pos(bits)):
+            o |= ((w >> np.uint32(bits * k)) & fm) << np.uint32(bits * pos)
         # row = rb*16 + rq*4 + j, col = s*16 + c  ->  [s][rb][lane = rq*16 + c][j]
         R[:, :, si] = o.reshape(nrb, 4, 4, S, 16).transpose(3, 0, 1, 4, 2).reshape(S, nrb, 64, 4)
-        z = (np_unpack_cols(qz, 4) + 1).astype(np.float16)                    # stored + 1, not re-masked
+        z = (np_unpack_cols(qz, bits) + 1).astype(np.float16)                # stored + 1, not re-masked
         sc16 = np.asarray(sc, dtype=np.float16)
         e = sc16.view(np.uint16).astype(np.uint32) | (z.view(np.uint16).astype(np.uint32) << np.uint32(16))   # half2 {s, z+1}
         tab[:, si] = e.reshape(G, S, 16).transpose(1, 0, 2)
     return np.concatenate([R.reshape(-1).view(np.uint8), tab.reshape(-1).view(np.uint8)])
 
 
-def stripe16_unpack(image, K, N, groupsize, NS):
-    """inverse of stripe16_repack: -> [(qweight int32 [K/8, N], scales fp16 [G, N], zeros+1 int [G, N])] per set."""
-    nrb, S = K // 128, N // 16
+def stripe16_unpack(image, K, N, groupsize, NS, bits=4):
+    """inverse of stripe16_repack: -> [(qweight int32 [K/KPW, N], scales fp16 [G, N], zeros+1 int [G, N])] per set."""
+    kpw = 32 // bits
+    nrb, S = K // (16 * kpw), N // 16
     gs = K if groupsize in (-1, None) or groupsize >= K else groupsize
     G = K // gs
     nR = S * nrb * NS * 256
     img = np.asarray(image, dtype=np.uint8)
     R = img[:nR * 4].view(np.uint32).reshape(S, nrb, NS, 64, 4)
     tab = img[nR * 4:nR * 4 + S * NS * G * 16 * 4].view(np.uint32).reshape(S, NS, G, 16)
+    fm = np.uint32((1 << bits) - 1)
     out = []
     for si in range(NS):
-        o = R[:, :, si].reshape(S, nrb, 4, 16, 4).transpose(1, 2, 4, 0, 3).reshape(K // 8, N)
+        o = R[:, :, si].reshape(S, nrb, 4, 16, 4).transpose(1, 2, 4, 0, 3).reshape(K // kpw, N)
         w = np.zeros_like(o)
-        for pos, k in enumerate(STRIPE_K_OF_POS):
-            w |= ((o >> np.uint32(4 * pos)) & np.uint32(15)) << np.uint32(4 * k)
+        for pos, k in enumerate(stripe_k_of_pos(bits)):
+            w |= ((o >> np.uint32(bits * pos)) & fm) << np.uint32(bits * k)
         e = tab[:, si].transpose(1, 0, 2).reshape(G, N)
         sc = (e & np.uint32(0xFFFF)).astype(np.uint16).view(np.float16)
         z = (e >> np.uint32(16)).astype(np.uint16).view(np.float16).astype(np.int32)

@@ -12,6 +12,7 @@ import torch
 import quant
 from quant import decode as D
 from oracle import oracle
+from util import within
 
 ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_DIR = os.path.join(ROOT_DIR, 'gptq-for-llama_amd')
@@ -19,6 +20,8 @@ GOLDEN_DIR = os.path.join(ROOT_DIR, 'tests', 'golden')
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+TWIN_TOL = 1.2e-2    # logits of a 2-layer model vs its dense fp16 twin with STOCK HF norm / RoPE numerics (observed 0.9e-3 .. 6.3e-3)
+ENGINE_TOL = 5e-3    # DecodeEngine vs the module chain on the same drop-in modules (observed 6e-4 .. 1.8e-3); was 2e-2 for both in round 1
 TINY = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
             vocab_size=512, max_position_embeddings=128)
 
@@ -43,15 +46,19 @@ def dense_twin(qmodel_unfused, cfg_overrides):
 
 
 def run_steps(model, ids, prefill):
+    """the module chain itself, launch by launch: the transparent decode engine (quant/engine_hook.py, tested on its own
+    below) is switched off so that this is an INDEPENDENT expectation for the engine tests."""
     from transformers.cache_utils import DynamicCache
     cache = DynamicCache(config=model.config)
     outs = []
+    model._gptq_engine_disabled = True
     with torch.no_grad():
         out = model(ids[:, :prefill], past_key_values=cache, use_cache=True)
         outs.append(out.logits[:, -1].float().cpu().numpy())
         for i in range(prefill, ids.shape[1]):
             out = model(ids[:, i:i + 1], past_key_values=cache, use_cache=True)
             outs.append(out.logits[:, -1].float().cpu().numpy())
+    model._gptq_engine_disabled = False
     return np.stack(outs)
 
 
@@ -68,11 +75,11 @@ def test_tiny_llama_logits_match_dense_twin(bits, gs):
     a, b, c = run_steps(q, ids, 5), run_steps(q_unfused, ids, 5), run_steps(ref, ids, 5)
     scale = np.abs(c).max()
     assert np.isfinite(a).all()
-    assert np.abs(b - c).max() / scale < 2e-2      # QuantLinear inside stock HF attention / MLP / norm
-    assert np.abs(a - c).max() / scale < 2e-2      # + fused qkv/RoPE, fused MLP, HIP RMSNorm
+    within('twin_unfused_w%d' % bits, np.abs(b - c).max() / scale, TWIN_TOL)      # QuantLinear inside stock HF attention / MLP / norm
+    within('twin_fused_w%d' % bits, np.abs(a - c).max() / scale, TWIN_TOL)      # + fused qkv/RoPE, fused MLP, HIP RMSNorm
     # the winning logit of the twin is (nearly) the winning logit here (argmax itself may flip on near-ties)
     top = np.take_along_axis(a, c.argmax(-1)[..., None], -1)[..., 0]
-    assert np.all(a.max(-1) - top < 2e-2 * scale)
+    within('twin_top_w%d' % bits, (a.max(-1) - top).max() / scale, TWIN_TOL)
 
 
 def test_benchmark_decode_protocol_runs():
@@ -231,9 +238,9 @@ def test_decode_engine_matches_hf_decoder(graph, fuse):
     for i in range(ids.shape[1]):
         got.append(eng.decode(ids[0, i]).float().cpu().numpy()[0])
     got = np.stack(got)[:, None, :]
-    assert np.abs(got - expect).max() / np.abs(expect).max() < 2e-2
+    within('engine_vs_hf_g%d_f%d' % (graph, fuse), np.abs(got - expect).max() / np.abs(expect).max(), ENGINE_TOL)
     top = np.take_along_axis(got, expect.argmax(-1)[..., None], -1)[..., 0]
-    assert np.all(got.max(-1) - top < 2e-2 * np.abs(expect).max())
+    within('engine_top_g%d_f%d' % (graph, fuse), (got.max(-1) - top).max() / np.abs(expect).max(), ENGINE_TOL)
     r = D.benchmark_decode_engine(q, tokens=8, t_max=64, graph=graph, fuse_norm=fuse, fuse_attn=fuse)
     assert r['tokens_per_s'] > 0
 
@@ -253,11 +260,11 @@ def test_engine_generate_continues_the_hf_prefill():
         full = q(seq).logits[0].float().cpu().numpy()
     last = eng.logits.float().cpu().numpy()[0]               # logits after consuming seq[0, 13] -> predicts seq[0, 14]
     ref = full[13]
-    assert np.abs(last - ref).max() / np.abs(ref).max() < 2e-2
+    within('engine_generate_last', np.abs(last - ref).max() / np.abs(ref).max(), ENGINE_TOL)
     # greedy: every generated token is (within fp16 ties) the argmax of the HF logits at the previous position
     for pos in range(9, 15):
         tok = int(seq[0, pos])
-        assert full[pos - 1][tok] >= full[pos - 1].max() - 2e-2 * np.abs(full[pos - 1]).max()
+        within('engine_generate_greedy', (full[pos - 1].max() - full[pos - 1][tok]) / np.abs(full[pos - 1]).max(), ENGINE_TOL)
 
 
 def test_decode_engine_act_order_checkpoint():
@@ -272,7 +279,7 @@ def test_decode_engine_act_order_checkpoint():
     eng = D.DecodeEngine(q, t_max=64).capture()
     assert all(L['gate'].get('pair_sorted') and L['qkv']['srt'] is not None and L['o']['srt'] is not None for L in eng.layers)
     got = np.stack([eng.decode(ids[0, i]).float().cpu().numpy()[0] for i in range(ids.shape[1])])[:, None, :]
-    assert np.abs(got - expect).max() / np.abs(expect).max() < 2e-2
+    within('engine_act_order', np.abs(got - expect).max() / np.abs(expect).max(), ENGINE_TOL)
 
 
 # ---------------------------------------------------------------------------------------

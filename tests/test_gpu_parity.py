@@ -241,6 +241,19 @@ def test_prefill_gemm_rows_independent():
         assert rel_err(y[m:m + 1], ym) < TOL
 
 
+@pytest.mark.parametrize('M,K,N,bits,gs', [(4096, 4096, 4096, 4, 128), (8192, 1024, 4096, 4, 128), (4096, 4096, 1024, 8, 128)])
+def test_prefill_gemm_vs_oracle_at_prefill_sizes(M, K, N, bits, gs):
+    """the MFMA tile GEMM at M >= 4096 and N = 4096 directly against the CPU oracle (reference arithmetic,
+    quant_linear.py:128-130) on 48 sampled rows spread over every 256-row tile band -- not only against our own M = 1 kernel."""
+    L = make_random_layer(bits, gs, K, N, seed=M + K)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    y = hip_forward(x, L, family='abi')
+    rows = np.unique(np.concatenate([np.arange(0, M, M // 32), rng.integers(0, M, 16), [M - 1, 255, 256]]))
+    ref = oracle_forward(x[rows], L)
+    assert rel_err(y[rows], ref) < TOL, rel_err(y[rows], ref)
+
+
 @pytest.mark.parametrize('bits', [2, 3, 4, 8])
 @pytest.mark.parametrize('M', [1, 3, 9])
 def test_act_order_and_3bit(bits, M):
@@ -598,22 +611,77 @@ def test_fuzz_fused_mlp_vs_oracle(case):
 # stripe16 decode path (csrc/stripe.hip): repack bit-exact vs the numpy restatement; matvec vs the oracle on the
 # ORIGINAL checkpoint buffers (the layout must be invisible in the results)
 # ---------------------------------------------------------------------------------------
-def _stripe_image(Ls, gs):
-    K = Ls[0]['qweight'].shape[0] * 8
+def _stripe_image(Ls, gs, bits=4):
+    K = Ls[0]['qweight'].shape[0] * 32 // bits
     t = [(dev(L['qweight']), dev(L['scales']), dev(L['qzeros'])) for L in Ls]
-    st = QL.stripe_copy(t[0][0], t[0][1], t[0][2], 4, K if gs == -1 else gs, up=t[1] if len(t) == 2 else None)
+    st = QL.stripe_copy(t[0][0], t[0][1], t[0][2], bits, K if gs == -1 else gs, up=t[1] if len(t) == 2 else None)
     torch.cuda.synchronize()
     return st, t
 
 
-@pytest.mark.parametrize('K,N,gs,NS', [(4096, 4096, 128, 1), (1024, 288, 64, 2), (384, 64, 32, 1), (512, 64, -1, 2), (2176, 32, 128, 1),
-                                       (4096, 11008, 128, 2)])
-def test_stripe_repack_bit_exact(K, N, gs, NS):
-    Ls = [make_random_layer(4, gs, K, N, seed=K + N + i) for i in range(NS)]
-    st, _ = _stripe_image(Ls, gs)
+@pytest.mark.parametrize('bits,K,N,gs,NS', [(4, 4096, 4096, 128, 1), (4, 1024, 288, 64, 2), (4, 384, 64, 32, 1), (4, 512, 64, -1, 2),
+                                            (4, 2176, 32, 128, 1), (4, 4096, 11008, 128, 2), (8, 4096, 512, 128, 1), (8, 1088, 96, 64, 2),
+                                            (8, 192, 32, 16, 1), (2, 4096, 512, 128, 1), (2, 1280, 64, 64, 2), (2, 512, 32, -1, 1)])
+def test_stripe_repack_bit_exact(bits, K, N, gs, NS):
+    Ls = [make_random_layer(bits, gs, K, N, seed=K + N + i) for i in range(NS)]
+    st, _ = _stripe_image(Ls, gs, bits)
     assert st is not None
-    ref = oracle.stripe16_repack([(L['qweight'], L['scales'], L['qzeros']) for L in Ls], gs)
+    ref = oracle.stripe16_repack([(L['qweight'], L['scales'], L['qzeros']) for L in Ls], gs, bits)
     assert np.array_equal(st.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('M', [1, 3])
+@pytest.mark.parametrize('bits,K,N,gs', [(8, 4096, 4096, 128), (8, 11008, 256, 128), (8, 64, 32, 64), (8, 1088, 96, 16), (8, 2240, 64, 32),
+                                         (8, 22016, 32, 128), (8, 512, 64, -1), (2, 4096, 4096, 128), (2, 11008, 256, 128), (2, 256, 32, 64),
+                                         (2, 2304, 96, 256), (2, 24576, 32, 128), (2, 1024, 64, -1)])
+def test_stripe_2bit_and_8bit_vs_oracle(bits, K, N, gs, M):
+    """the reference's other widths (quant_linear.py:308) on the stripe16 kernel: every unpack position of a word, ragged
+    row-block counts, group sizes from one lane block to all of K; M = 3 rides along for free"""
+    L = make_random_layer(bits, gs, K, N, seed=bits * K + N)
+    x = np.random.default_rng(K + M).standard_normal((M, K)).astype(np.float16)
+    fam = 'stripe' if (M == 1 or K <= 16384) else None      # four rows of a longer K do not fit in LDS: the dispatch falls back
+    y1, ref = check_forward(x, L, family=fam)
+    y2 = hip_forward(x, L, family=fam)
+    assert np.array_equal(y1.view(np.uint16), y2.view(np.uint16))
+    ye = oracle.matmul248_exact(x, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], bits)
+    assert rel_err(y1, ye) < TOL
+    assert rel_err(y1, hip_forward(x, L, family='gemv')) < TOL            # and against round 1's rowwave kernel
+
+
+@pytest.mark.parametrize('M', [2, 3, 4])
+@pytest.mark.parametrize('bias', [False, True])
+@pytest.mark.parametrize('K,N,gs', [(4096, 4096, 128), (11008, 256, 128), (1024, 288, 32), (2176, 96, 64), (512, 64, -1)])
+def test_stripe_small_batch_rows(K, N, gs, M, bias):
+    """2 <= M <= 4: lane l supplies row l % 4 of x to the MFMA, result row i is x row i -- every row against the oracle,
+    strided x, each row equal (bit for bit) to what the M = 1 launch returns for it"""
+    L = make_random_layer(4, gs, K, N, seed=K + N + M)
+    rng = np.random.default_rng(M)
+    xs = rng.standard_normal((M, K + 64)).astype(np.float16)
+    x = xs[:, :K]                                                           # row stride K + 64
+    b = rng.standard_normal(N).astype(np.float16) if bias else None
+    y = hip_forward(np.ascontiguousarray(x), L, b, family='stripe')
+    ref = oracle_forward(np.ascontiguousarray(x), L, b)
+    assert rel_err(y, ref) < (2 * TOL if bias else TOL)
+    xt = dev(xs)[:, :K]
+    ys = QL.matmul248(xt, dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15, bias=None if b is None else dev(b),
+                      family='stripe').cpu().numpy()
+    assert np.array_equal(ys.view(np.uint16), y.view(np.uint16))
+    for m in range(M):
+        y1 = hip_forward(np.ascontiguousarray(x[m:m + 1]), L, b, family='stripe')
+        assert np.array_equal(y1.view(np.uint16), y[m:m + 1].view(np.uint16))
+
+
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 11008, 128), (8, 1024, 288, 64), (2, 1024, 96, 128)])
+@pytest.mark.parametrize('M', [2, 4])
+def test_stripe_fused_mlp_small_batch(bits, K, N, gs, M):
+    A, B = make_random_layer(bits, gs, K, N, seed=71), make_random_layer(bits, gs, K, N, seed=72)
+    x = (np.random.default_rng(M).standard_normal((M, K)) * 0.5).astype(np.float16)
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs).cpu().numpy()
+    assert getattr(gate[0], '_gptq_stripe', None) is not None
+    ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits)
+    assert rel_err(c, ref) < 2e-3
 
 
 @pytest.mark.parametrize('bias', [False, True])
@@ -645,7 +713,9 @@ def test_stripe_is_the_default_decode_path_and_rowwave_still_agrees():
     assert np.array_equal(ys.view(np.uint16), yf.view(np.uint16))
     assert rel_err(ys, yr) < TOL
     with pytest.raises(RuntimeError):            # shapes the stripe kernel does not serve are refused when forced
-        hip_forward(x[:, :1056], make_random_layer(4, 32, 1056, 64, seed=1), family='stripe')
+        hip_forward(x[:, :1056], make_random_layer(4, 32, 1056, 64, seed=1), family='stripe')          # K % 128
+    with pytest.raises(RuntimeError):
+        hip_forward(np.tile(x, (5, 1)), L, family='stripe')                                              # M > 4
 
 
 @pytest.mark.parametrize('K,N,gs', [(4096, 11008, 128), (1024, 2816, 64), (512, 96, 32), (2176, 32, -1)])

@@ -196,22 +196,24 @@ def test_row_and_col_sharded_linear_gloo_world2(act_order):
 
 def test_stripe16_layout_restatement_is_a_bijection():
     """oracle.stripe16_repack (numpy restatement of csrc/stripe.hip's load-time repack) loses nothing: the
-    checkpoint buffers come back bit for bit, for one set and for a gate/up pair, several group sizes."""
-    for K, N, gs, NS in [(256, 32, 128, 1), (1024, 288, 64, 2), (384, 64, 32, 1), (512, 48 + 16, -1, 2)]:
-        Ls = [make_random_layer(4, gs, K, N, seed=K + N + i) for i in range(NS)]
-        img = oracle.stripe16_repack([(L['qweight'], L['scales'], L['qzeros']) for L in Ls], gs)
-        assert img.nbytes == _native.lib().gptq_stripe_bytes(K, N, 4, K if gs == -1 else gs, NS)
-        back = oracle.stripe16_unpack(img, K, N, gs, NS)
+    checkpoint buffers come back bit for bit, for one set and for a gate/up pair, 2 / 4 / 8 bits, several group sizes."""
+    for bits, K, N, gs, NS in [(4, 256, 32, 128, 1), (4, 1024, 288, 64, 2), (4, 384, 64, 32, 1), (4, 512, 64, -1, 2),
+                               (8, 128, 32, 64, 1), (8, 1024, 96, 128, 2), (8, 192, 32, 16, 1), (2, 512, 32, 128, 1), (2, 1024, 64, 64, 2)]:
+        Ls = [make_random_layer(bits, gs, K, N, seed=K + N + i) for i in range(NS)]
+        img = oracle.stripe16_repack([(L['qweight'], L['scales'], L['qzeros']) for L in Ls], gs, bits)
+        assert img.nbytes == _native.lib().gptq_stripe_bytes(K, N, bits, K if gs == -1 else gs, NS)
+        back = oracle.stripe16_unpack(img, K, N, gs, NS, bits)
         for L, (qw, sc, z) in zip(Ls, back):
             assert np.array_equal(qw, L['qweight'])
             assert np.array_equal(sc.view(np.uint16), L['scales'].view(np.uint16))
-            assert np.array_equal(z, oracle.np_unpack_cols(L['qzeros'], 4) + 1)
-    # one hand-checked word: k = 0..7 hold the values 0..7 -> positions (k0 k2 k4 k6 | k1 k3 k5 k7)
-    qw = np.zeros((16, 16), dtype=np.int32)
-    qw[0, 0] = 0x76543210
-    L = dict(qweight=np.tile(qw, (1, 1)), scales=np.ones((1, 16), np.float16), qzeros=np.zeros((1, 2), np.int32))
-    img = oracle.stripe16_repack([(L['qweight'], L['scales'], L['qzeros'])], 128)
-    assert int(img[:4].view(np.uint32)[0]) == 0x75316420
+            assert np.array_equal(z, oracle.np_unpack_cols(L['qzeros'], bits) + 1)
+    # one hand-checked word per width: field k holds the value k -> even k in the low half-word, odd k in the high one
+    for bits, word, want in [(4, 0x76543210, 0x75316420), (8, 0x03020100, 0x03010200), (2, 0xE4E4E4E4, 0xDDDD8888)]:
+        qw = np.zeros((16, 16), dtype=np.int32)
+        qw[0, 0] = np.uint32(word).astype(np.int32)
+        K = 16 * 32 // bits
+        img = oracle.stripe16_repack([(qw, np.ones((1, 16), np.float16), np.zeros((1, 16 * bits // 32 or 1), np.int32))], K, bits)
+        assert int(img[:4].view(np.uint32)[0]) == want, (bits, hex(int(img[:4].view(np.uint32)[0])))
 
 
 def test_stripe_abi_validation_needs_no_gpu():
@@ -219,21 +221,33 @@ def test_stripe_abi_validation_needs_no_gpu():
     one = 16
     assert lib.gptq_stripe_bytes(4096, 4096, 4, 128, 1) == 4096 // 8 * 4096 * 4 + 32 * 4096 * 4
     assert lib.gptq_stripe_bytes(4096, 11008, 4, 128, 2) == 2 * (4096 // 8 * 11008 * 4 + 32 * 11008 * 4)
-    assert lib.gptq_stripe_bytes(4096, 4096, 8, 128, 1) == 0          # 4-bit only
-    assert lib.gptq_stripe_bytes(4096 + 64, 4096, 4, 128, 1) == 0     # K % 128
+    assert lib.gptq_stripe_bytes(4096, 4096, 8, 128, 1) == 4096 // 4 * 4096 * 4 + 32 * 4096 * 4
+    assert lib.gptq_stripe_bytes(4096, 4096, 2, 128, 1) == 4096 // 16 * 4096 * 4 + 32 * 4096 * 4
+    assert lib.gptq_stripe_bytes(4096, 4096, 3, 128, 1) == 0          # no 3-bit stripes
+    assert lib.gptq_stripe_bytes(4096 + 64, 4096, 4, 128, 1) == 0     # K % 128 (4-bit row block)
+    assert lib.gptq_stripe_bytes(4096 + 64, 4096, 8, 64, 1) > 0       # ... but a whole number of 8-bit row blocks (64 k)
     assert lib.gptq_stripe_bytes(4096, 4096, 4, 96, 1) == 0           # group not a power-of-two multiple of 32
+    assert lib.gptq_stripe_bytes(4096, 4096, 2, 32, 1) == 0           # 2-bit: a lane block is 64 k
     assert lib.gptq_stripe_bytes(32768, 4096, 4, 128, 1) == 0         # more than 24 row blocks per wave
+    assert lib.gptq_stripe_bytes(22016, 8192, 8, 128, 1) > 0           # 8-bit 65B down_proj: 43 row blocks per wave
     assert lib.gptq_stripe_bytes(4096, 4096, 4, 4096, 1) > 0          # one group
     nb = lib.gptq_stripe_bytes(256, 64, 4, 128, 1)
     assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb, 256, 64, 5, 128, None) == -1
     assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb - 1, 256, 64, 4, 128, None) == -5
     assert lib.gptq_stripe_repack(None, one, one, None, None, None, one, nb, 256, 64, 4, 128, None) == -4
-    assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb, 256, 64, 8, 128, None) == -6
-    assert lib.gptq_stripe_matvec_f16(one, one, nb, None, one, 256, 64, 4, 128, 3, None, 0.0, None, None) == -2   # nsets
-    assert lib.gptq_stripe_matvec_f16(one, one, nb - 1, None, one, 256, 64, 4, 128, 1, None, 0.0, None, None) == -5
-    assert lib.gptq_stripe_matvec_f16(one, one, nb, None, one, 256, 64, 2, 128, 1, None, 0.0, None, None) == -6
-    assert lib.gptq_stripe_matvec_f16(None, one, nb, None, one, 256, 64, 4, 128, 1, None, 0.0, None, None) == -4
-    assert lib.gptq_stripe_matvec_f16(2, one, nb, None, one, 256, 64, 4, 128, 1, None, 0.0, None, None) == -3
+    assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb, 256, 64, 3, 128, None) == -6
+
+    def mv(x=one, st=one, nbytes=nb, y=one, M=1, bits=4, nsets=1, norm=None, ldx=256, ldy=64):
+        return lib.gptq_stripe_matvec_f16(x, ldx, st, nbytes, None, y, ldy, M, 256, 64, bits, 128, nsets, norm, 0.0, None, None)
+    assert mv(nsets=3) == -2
+    assert mv(nbytes=nb - 1) == -5
+    assert mv(bits=3) == -6
+    assert mv(M=5) == -6                                              # four rows per launch
+    assert mv(M=2, norm=one) == -6                                     # fused RMSNorm is an M == 1 feature
+    assert mv(M=2, ldx=252) == -3
+    assert mv(x=None) == -4
+    assert mv(x=2) == -3
+    assert mv(M=0) == 0
 
 
 def test_byte_model_matches_survey_8d():

@@ -40,3 +40,12 @@ def rel_err(a, b):
 
 
 TOL = 1e-3
+
+
+def within(name, err, tol):
+    """assert err < tol; with GPTQ_TEST_ERRLOG=<file> the observed error is logged (used to set the model-level tolerances)."""
+    path = os.environ.get('GPTQ_TEST_ERRLOG')
+    if path:
+        with open(path, 'a') as f:
+            f.write('%s %.3e %.1e\n' % (name, float(err), tol))
+    assert err < tol, (name, float(err), tol)

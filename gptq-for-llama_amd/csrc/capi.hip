@@ -692,7 +692,7 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
     const int gq = stripe_gq_shift(K, N, bits, groupsize);
-    if (gq == -2 || M > 4 || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
+    if (gq == -2 || M > 16 || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
     if (M > 1 && (norm_weight || perm || y32)) return GPTQ_E_VARIANT;
     if (stripes_bytes < stripe_total_bytes(K, N, bits, groupsize, nsets)) return GPTQ_E_WORKSPACE;
     if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || !aligned(y32, 4) || (norm_weight && !aligned(norm_weight, 16)) ||

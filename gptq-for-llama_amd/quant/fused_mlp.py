@@ -30,8 +30,9 @@ def _same_perm(a, b):
     return memo[2]
 
 
-def fused_gate_up(x, gate, up, bits, groupsize):
-    """c = silu(x . deq(gate)) * (x . deq(up)); gate/up = (qweight, scales, qzeros, g_idx)."""
+def fused_gate_up(x, gate, up, bits, groupsize, family=None):
+    """c = silu(x . deq(gate)) * (x . deq(up)); gate/up = (qweight, scales, qzeros, g_idx).
+    family='abi' (tests / A-B runs) skips the stripe16 images and calls gptq_fused_mlp_f16 on the checkpoint layout."""
     _native.require_device(x, 'fused_gate_up')
     x2 = _as_rows(x.reshape(-1, x.shape[-1]))
     M, K = x2.shape
@@ -39,7 +40,8 @@ def fused_gate_up(x, gate, up, bits, groupsize):
     gis = []
     for (qw, sc, qz, gi) in (gate, up):
         gis.append(None if (gi is None or g_idx_is_trivial(gi, K, groupsize)) else _int32c(gi[:K]))
-    if 1 <= M <= 4 and bits in (2, 4, 8) and all(gi is None for gi in gis):
+    stripe_rows = 8      # M <= 8: the stripe kernel wins while M rows of x fit in LDS; wider batches -> weight-streaming MFMA kernel
+    if family is None and 1 <= M <= stripe_rows and bits in (2, 4, 8) and all(gi is None for gi in gis):
         # decode (and batches of up to 4 rows): gate and up packed into ONE stripe16 image, silu(gate) * up in the kernel epilogue
         from .quant_linear import stripe_copy, stripe_matvec
         st = stripe_copy(_int32c(gate[0]), gate[1], _int32c(gate[2]), bits, groupsize, up=(_int32c(up[0]), up[1], _int32c(up[2])))
@@ -48,7 +50,7 @@ def fused_gate_up(x, gate, up, bits, groupsize):
                 c = torch.empty((M, N), device=x.device, dtype=torch.float16)
                 if stripe_matvec(x2, st, c, K, N, bits, groupsize, nsets=2, strict=False):
                     return c
-    if M == 1 and bits in (2, 4, 8) and all(gi is not None for gi in gis):
+    if family is None and M == 1 and bits in (2, 4, 8) and all(gi is not None for gi in gis):
         # act-order MLP at decode: gate and up share their input, hence their act-order permutation -> one x gather,
         # two group-sorted weight copies (cached on the tensors), the trivial-g_idx fused kernel
         from .quant_linear import act_order_sorted, stripe_copy, stripe_matvec

@@ -162,7 +162,7 @@ def stripe_matvec(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, norm_we
     return True
 
 
-STRIPE_MAX_M = 4   # rows of x one stripe16 launch serves (the MFMA 4x4x4 computes four rows at the price of one)
+STRIPE_MAX_M = 16  # rows of x one stripe16 launch serves (four per MFMA row group; 8 / 16 rows only while they fit in LDS)
 
 
 def _as_rows(t):
@@ -271,7 +271,10 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
             return out
         ws = _native.workspace(x.device)
         srt = act_order_sorted(qweight, gi, K, groupsize, bits) if gi is not None else None
-        if family in (None, 'stripe') and ((M == 1 and (gi is None or srt is not None)) or (M <= STRIPE_MAX_M and gi is None)):
+        # stripe16 serves M == 1 always, M <= 8 while M rows of x fit in LDS, 9..16 only when the grid is one workgroup per CU
+        # (N <= 4096: 128 KiB of x per workgroup leaves room for one; measured 7.6 vs 9.1 us at 4096^2, 20 vs 17 us at N = 12288)
+        stripe_m = M == 1 or (gi is None and (M <= 8 or (M <= STRIPE_MAX_M and (N <= 4096 or family == 'stripe'))))
+        if family in (None, 'stripe') and stripe_m and (gi is None or srt is not None):
             # decode: no-split-K kernel on the stripe16 copy (of the group-sorted rows for an act-order layer)
             st = stripe_copy(srt[0] if srt is not None else qweight, scales, qzeros, bits, groupsize)
             if st is not None and stripe_matvec(x, st, out, K, N, bits, groupsize, bias=bias, perm=srt[1] if srt is not None else None,

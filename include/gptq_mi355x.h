@@ -252,8 +252,9 @@ int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k
  * 16 * (32 / bits) = 256 / 128 / 64 and at most 24576 / 24576 / 22528; groupsize a power-of-two multiple of 4 * (32 / bits)
  * that divides K, or >= K).  For 8 and 2 bits the same geometry holds with 32 / bits k per word; see csrc/stripe.hip.  The
  * checkpoint buffers are not modified and stay the owner of the state_dict.  nsets == 2 packs gate and up together and the
- * matvec returns silu(x Wg) * (x Wu).  1 <= M <= 4 rows of x (row strides ldx / ldy) cost the same weight stream as one: the
- * MFMA computes four rows anyway.  M == 1 only: norm_weight != NULL fuses the RMSNorm of x (rms_norm_fwd_fused,
+* matvec returns silu(x Wg) * (x Wu).  1 <= M <= 4 rows of x (row strides ldx / ldy) cost the same weight stream as one: the
+ * MFMA computes four rows anyway; 5 <= M <= 8 / 16 run two / four MFMA row groups on the same unpacked words while M rows of x
+ * fit in LDS (K <= ~9200 / ~4600, else GPTQ_E_VARIANT: the caller takes the weight-streaming MFMA kernel).  M == 1 only: norm_weight != NULL fuses the RMSNorm of x (rms_norm_fwd_fused,
  * quant/triton_norm.py:22-39) in front; perm != NULL reads x through a permutation (an act-order layer whose qweight rows were
  * sorted by group with gptq_act_order_repack BEFORE gptq_stripe_repack).  No workspace, no atomics: results are bit-identical
  * run to run. */

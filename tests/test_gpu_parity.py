@@ -398,8 +398,8 @@ def test_fused_mlp_split_k(split_k):
     lib = _native.lib()
     lib.gptq_set_split_k(split_k)
     try:
-        c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 128).cpu().numpy()
-        c2 = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 128).cpu().numpy()
+        c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 128, family='abi').cpu().numpy()
+        c2 = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 128, family='abi').cpu().numpy()
     finally:
         lib.gptq_set_split_k(-1)
     ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']),
@@ -671,8 +671,31 @@ def test_stripe_small_batch_rows(K, N, gs, M, bias):
         assert np.array_equal(y1.view(np.uint16), y[m:m + 1].view(np.uint16))
 
 
+@pytest.mark.parametrize('M', [5, 8, 9, 13, 16])
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 4096, 128), (4, 4096, 11008, 128), (4, 2176, 96, 64), (8, 2048, 288, 128), (2, 4096, 64, 128)])
+def test_stripe_row_groups_m5_to_16(bits, K, N, gs, M):
+    """5 <= M <= 16: two / four MFMA row groups on the same unpacked words, M rows of x in LDS; every row against the oracle
+    and bit-identical to the M = 1 launch of that row"""
+    L = make_random_layer(bits, gs, K, N, seed=K + N + M)
+    x = np.random.default_rng(M).standard_normal((M, K)).astype(np.float16)
+    y, ref = check_forward(x, L, family='stripe')
+    for m in (0, M // 2, M - 1):
+        y1 = hip_forward(x[m:m + 1], L, family='stripe')
+        assert np.array_equal(y1.view(np.uint16), y[m:m + 1].view(np.uint16))
+
+
+def test_stripe_long_k_small_batch_falls_back():
+    """M rows of x must fit in LDS: M = 8 on K = 11008 is refused by the stripe kernel (GPTQ_E_VARIANT) and the default
+    dispatch takes the weight-streaming MFMA kernel -- same result"""
+    L = make_random_layer(4, 128, 11008, 256, seed=8)
+    x = np.random.default_rng(8).standard_normal((8, 11008)).astype(np.float16)
+    with pytest.raises(RuntimeError):
+        hip_forward(x, L, family='stripe')
+    check_forward(x, L)
+
+
 @pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 11008, 128), (8, 1024, 288, 64), (2, 1024, 96, 128)])
-@pytest.mark.parametrize('M', [2, 4])
+@pytest.mark.parametrize('M', [2, 4, 7, 8])
 def test_stripe_fused_mlp_small_batch(bits, K, N, gs, M):
     A, B = make_random_layer(bits, gs, K, N, seed=71), make_random_layer(bits, gs, K, N, seed=72)
     x = (np.random.default_rng(M).standard_normal((M, K)) * 0.5).astype(np.float16)
@@ -715,7 +738,7 @@ def test_stripe_is_the_default_decode_path_and_rowwave_still_agrees():
     with pytest.raises(RuntimeError):            # shapes the stripe kernel does not serve are refused when forced
         hip_forward(x[:, :1056], make_random_layer(4, 32, 1056, 64, seed=1), family='stripe')          # K % 128
     with pytest.raises(RuntimeError):
-        hip_forward(np.tile(x, (5, 1)), L, family='stripe')                                              # M > 4
+        hip_forward(np.tile(x, (17, 1)), L, family='stripe')                                             # M > 16
 
 
 @pytest.mark.parametrize('K,N,gs', [(4096, 11008, 128), (1024, 2816, 64), (512, 96, 32), (2176, 32, -1)])
@@ -819,7 +842,7 @@ def test_fused_mlp_rowwave_large_partials_are_not_clamped():
     lib = _native.lib()
     lib.gptq_set_split_k(8)
     try:
-        c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 8, 128).cpu().numpy()
+        c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 8, 128, family='abi').cpu().numpy()
     finally:
         lib.gptq_set_split_k(-1)
     ga = oracle.matmul248_exact(x, A['qweight'], A['scales'], A['qzeros'], A['g_idx'], 8)
@@ -852,18 +875,19 @@ def _small_batch_body(gs, K, N, M, plain_family):
     rng = np.random.default_rng(M * K + N)
     x = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
     bias = rng.standard_normal(N).astype(np.float16)
-    check_forward(x, L, bias=bias)
+    yb = hip_forward(x, L, bias=bias, family='abi')                         # the C-ABI dispatch (rowwave / stream kernels): the Python
+    assert rel_err(yb, oracle_forward(x, L, bias)) < 2 * TOL                # default would take the stripe16 image; bias = two roundings
     if plain_family:
         check_forward(x, L, family='gemv')
     # strided rows
     wide = torch.zeros((M, K + 64), dtype=torch.float16, device='cuda:0')
     wide[:, :K] = torch.from_numpy(x).cuda()
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to('cuda:0')
-    y = QL.matmul248(wide[:, :K], dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15)
+    y = QL.matmul248(wide[:, :K], dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15, family='abi')
     assert rel_err(y.cpu().numpy(), oracle_forward(x, L)) < TOL
     gate = tuple(dev(L[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
     up = tuple(dev(U[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
-    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, gs if gs != -1 else K)
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, gs if gs != -1 else K, family='abi')
     ref = oracle.fused_mlp(x, (L['qweight'], L['scales'], L['qzeros'], L['g_idx']), (U['qweight'], U['scales'], U['qzeros'], U['g_idx']), 4)
     assert rel_err(c.cpu().numpy(), ref) < TOL
     ws = _native.workspace(torch.device('cuda:0'))

@@ -191,8 +191,8 @@ def test_default_load_path_with_warmups_then_generate(tmp_path, capsys):
     ids = torch.randint(0, TINY['vocab_size'], (1, 9), generator=torch.Generator().manual_seed(1)).to(DEV)
     with torch.no_grad():
         gen = model.generate(ids, do_sample=True, min_length=10, max_length=24, top_p=0.95, temperature=0.8)
-        greedy = model.generate(ids, do_sample=False, max_new_tokens=12)
-        greedy2 = model.generate(ids, do_sample=False, max_new_tokens=12)
+        greedy = model.generate(ids, do_sample=False, max_new_tokens=12, min_new_tokens=12)     # (a random model may pick EOS at once)
+        greedy2 = model.generate(ids, do_sample=False, max_new_tokens=12, min_new_tokens=12)
     assert gen.shape[0] == 1 and 10 <= gen.shape[1] <= 24 and torch.equal(gen[:, :9], ids)
     assert greedy.shape == (1, 21) and torch.equal(greedy, greedy2)
     assert int(greedy.max()) < TINY['vocab_size']

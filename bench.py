@@ -220,10 +220,14 @@ class TPLayers:
       mode 'megatron' qkv and gate/up N-(column-)sharded (no collective, SiLU fused), o and down K-sharded: 2 all-reduces per layer
     The collective is torch.distributed.all_reduce (RCCL over xGMI on MI355X; gloo in the CPU tests)."""
 
-    def __init__(self, dev, rank, world, mode, layers, seed=0):
+    def __init__(self, dev, rank, world, mode, layers, seed=0, allreduce='rccl'):
         from quant import _native, quant_linear, tensor_parallel as TP
         self.native, self.lib, self.QL = _native, _native.lib(), quant_linear
         self.dev, self.rank, self.world, self.mode = dev, rank, world, mode
+        self.p2p = None
+        if allreduce == 'p2p' and world > 1:       # one-shot exchange through IPC peer mappings (csrc/p2p.hip) instead of RCCL
+            from quant.p2p import P2PAllReduce
+            self.p2p = P2PAllReduce(2 * I65)
         gen = torch.Generator(device=dev)
         gen.manual_seed(1000 + seed)            # every rank draws the same full matrices, then keeps its slice
         kb_h = TP.row_shard_bounds(H65, GS, BITS, world)[rank]
@@ -283,6 +287,14 @@ class TPLayers:
             import torch.distributed as dist
             dist.all_reduce(t)
 
+    def _reduce_round(self, part, out16):
+        """sum over the ranks, then the ONE fp16 rounding"""
+        if self.p2p is not None:
+            self.p2p.allreduce(part, out=out16)      # exchange, rank-ordered sum and rounding in one launch
+        else:
+            self._reduce(part)
+            out16.copy_(part)
+
     def step(self):
         kh = slice(*self.kb_h)
         ki = slice(*self.kb_i)
@@ -290,42 +302,42 @@ class TPLayers:
         for L in self.layers:
             if self.mode == 'row':
                 self._partial(self.x_h[:, kh], L['qkv'], self.p_qkv, Kh, 3 * H65, 1)
-                self._reduce(self.p_qkv)
-                self.y_qkv.copy_(self.p_qkv)                                    # the ONE fp16 rounding
+                self._reduce_round(self.p_qkv, self.y_qkv)
                 self._partial(self.x_h[:, kh], L['o'], self.p_h, Kh, H65, 1)
-                self._reduce(self.p_h)
-                self.y_h.copy_(self.p_h)
+                self._reduce_round(self.p_h, self.y_h)
                 self._partial(self.x_h[:, kh], L['mlp'], self.p_mlp, Kh, I65, 2)
-                self._reduce(self.p_mlp)
-                torch.mul(torch.nn.functional.silu(self.p_mlp[0:1]), self.p_mlp[1:2], out=self.p_mlp[0:1])   # fp32, fused_mlp.py:160-166
-                self.y_i.copy_(self.p_mlp[0:1])
+                if self.p2p is not None:
+                    self.p2p.allreduce_silu_mul(self.p_mlp, out=self.y_i)
+                else:
+                    self._reduce(self.p_mlp)
+                    torch.mul(torch.nn.functional.silu(self.p_mlp[0:1]), self.p_mlp[1:2], out=self.p_mlp[0:1])   # fp32, fused_mlp.py:160-166
+                    self.y_i.copy_(self.p_mlp[0:1])
                 self._partial(self.x_i[:, ki], L['down'], self.p_h, Ki, H65, 1)
-                self._reduce(self.p_h)
-                self.y_h.copy_(self.p_h)
+                self._reduce_round(self.p_h, self.y_h)
             else:
                 self._full(self.x_h, L['qkv'], self.y_qkv_loc, H65, self.nb_qkv[1] - self.nb_qkv[0], 1)     # this rank's heads
                 self._partial(self.x_h[:, kh], L['o'], self.p_h, Kh, H65, 1)
-                self._reduce(self.p_h)
-                self.y_h.copy_(self.p_h)
+                self._reduce_round(self.p_h, self.y_h)
                 self._full(self.x_h, L['mlp'], self.y_i_loc, H65, self.nb_i[1] - self.nb_i[0], 2)           # SiLU fused: columns are local
                 self._partial(self.x_i[:, ki], L['down'], self.p_h, Ki, H65, 1)
-                self._reduce(self.p_h)
-                self.y_h.copy_(self.p_h)
+                self._reduce_round(self.p_h, self.y_h)
 
 
-def allreduce_latency_us(dev, world, nfloats, reps=50):
+def allreduce_latency_us(dev, world, nfloats, reps=50, p2p=None):
     """mean us of one fp32 all-reduce of nfloats elements, back to back on the stream (reported next to the TP line)."""
     if world == 1:
         return 0.0
     import torch.distributed as dist
     t = torch.zeros(nfloats, dtype=torch.float32, device=dev)
+    o = torch.zeros(nfloats, dtype=torch.float16, device=dev)
+    one = (lambda: p2p.allreduce(t, out=o)) if p2p is not None else (lambda: dist.all_reduce(t))
     for _ in range(5):
-        dist.all_reduce(t)
+        one()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        dist.all_reduce(t)
+        one()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
@@ -554,6 +566,8 @@ def main():
                     help='BASELINE config 5 instead of the replica mode: LLaMA-65B-shaped decode linears sharded over the --gpus ranks '
                          '(row = every linear K-sharded, one all-reduce per linear; megatron = N-shard qkv/gate/up, K-shard o/down)')
     ap.add_argument('--tp-layers', type=int, default=16)
+    ap.add_argument('--allreduce', choices=('rccl', 'p2p'), default='rccl',
+                    help='--tp collective: torch.distributed.all_reduce (RCCL) or the one-shot exchange over IPC peer mappings (csrc/p2p.hip)')
     ap.add_argument('--dp', action='store_true', help='N independent replicas of the single-GPU workload (the default)')
     ap.add_argument('--no-prefill', action='store_true')
     ap.add_argument('--no-config4', action='store_true')
@@ -579,14 +593,14 @@ def main():
     dev = 'cuda:%d' % local_rank
 
     if args.tp:
-        work = TPLayers(dev, rank, world, args.tp, args.tp_layers)
+        work = TPLayers(dev, rank, world, args.tp, args.tp_layers, allreduce=args.allreduce)
     else:
         work = DecodeLinears(dev, seed=rank, kernel=args.kernel)
     for _ in range(2):
         work.step()
     torch.cuda.synchronize()
     graph = None
-    capturable = not (args.tp and distributed and os.environ.get('GPTQ_BENCH_BACKEND', 'nccl') != 'nccl')   # gloo collectives cannot be captured
+    capturable = not (args.tp and distributed and args.allreduce == 'rccl' and os.environ.get('GPTQ_BENCH_BACKEND', 'nccl') != 'nccl')   # gloo collectives cannot be captured
     if not args.eager and capturable:
         try:                       # the collectives are captured with the kernels (RCCL supports stream capture)
             graph = torch.cuda.CUDAGraph()
@@ -630,6 +644,11 @@ def main():
     if args.tp:   # collectives: every rank takes part
         tp_lat = {'32KB_fp32_8192': round(allreduce_latency_us(dev, world, H65), 2), '96KB_fp32_24576': round(allreduce_latency_us(dev, world, 3 * H65), 2),
                   '172KB_fp32_2x22016': round(allreduce_latency_us(dev, world, 2 * I65), 2)}
+        if work.p2p is not None:
+            tp_lat.update({'p2p_32KB': round(allreduce_latency_us(dev, world, H65, p2p=work.p2p), 2),
+                           'p2p_96KB': round(allreduce_latency_us(dev, world, 3 * H65, p2p=work.p2p), 2),
+                           'p2p_172KB': round(allreduce_latency_us(dev, world, 2 * I65, p2p=work.p2p), 2),
+                           'p2p_status': work.p2p.status()})
     if rank == 0:
         ms_per_step = wall_max * 1e3 / args.steps
         total_bytes = work.bytes_per_step * world
@@ -648,7 +667,9 @@ def main():
                                        '{qkv 8192x24576, o 8192x8192, gate/up+SiLU 2x8192x22016, down 22016x8192}' %
                                        ('row-sharded linears with one all-reduce per linear' if args.tp == 'row' else
                                         'Megatron pairing (N-shard qkv/gate/up, K-shard o/down: 2 all-reduces per layer)', world, args.tp_layers),
-                           'parallelism': 'tp%d %s' % (world, args.tp), 'collective': 'torch.distributed.all_reduce (RCCL over xGMI), fp32',
+                           'parallelism': 'tp%d %s' % (world, args.tp),
+                           'collective': ('one-shot push + local sum over IPC peer mappings (gptq_p2p_allreduce_f32), fp32' if work.p2p is not None
+                                          else 'torch.distributed.all_reduce (RCCL over xGMI), fp32'),
                            'collectives_per_step': work.collectives_per_step, 'launch_mode': 'hipGraph replay' if graph is not None else 'eager',
                            'algorithmic_bytes_per_step': work.bytes_per_step},
                 'allreduce_us': tp_lat,

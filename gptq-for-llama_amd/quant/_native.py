@@ -72,6 +72,13 @@ _SIGNATURES = {
                            c_void_p],
     'gptq_stripe_matvec_f16': [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,
                                c_void_p, c_float, c_void_p, c_void_p],
+    'gptq_p2p_buffer_bytes': [c_int, c_int],
+    'gptq_p2p_create': [c_int, c_int, c_void_p, c_void_p],
+    'gptq_p2p_open': [c_void_p, c_void_p],
+    'gptq_p2p_close': [c_void_p, c_int],
+    'gptq_p2p_status': [c_void_p, c_int, c_int, c_void_p],
+    'gptq_p2p_allreduce_f32': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    'gptq_p2p_allreduce_silu_mul_f32': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'gptq_stripe_matvec_partial_f32': [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
 }
 
@@ -102,6 +109,7 @@ def lib():
             L.gptq_set_debug_buffer.restype = c_void_p
             L.gptq_decode_attn_workspace_bytes.restype = c_size_t
             L.gptq_stripe_bytes.restype = c_size_t
+            L.gptq_p2p_buffer_bytes.restype = c_size_t
             L.gptq_strerror.argtypes = [c_int]
             L.gptq_strerror.restype = ctypes.c_char_p
             _lib = L
@@ -131,13 +139,21 @@ def stream_ptr(device):
 _workspaces = {}
 
 
-def workspace(device):
-    """Per-device zero-initialised scratch for the split-K kernels (they restore it to zero)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+def workspace(device, stream=None):
+    """Zero-initialised split-K scratch of the rowwave / stream kernels (they restore it to zero), one buffer per
+    (device, stream): the kernels use its words as accumulators between the first and the last K slice of a launch, so two
+    launches that may overlap -- different streams, or a captured graph replaying next to eager work -- must not share it.
+    The stripe16 decode kernels need no workspace at all.  Buffers live as long as the process (a captured hipGraph keeps
+    pointing at the one of its capture stream)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if stream is None:
+        stream = torch.cuda.current_stream(torch.device('cuda', idx)).cuda_stream
+    key = (device.type, idx, int(stream))
     ws = _workspaces.get(key)
     if ws is None:
         nbytes = lib().gptq_query(3)
-        ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        with torch.cuda.device(idx):
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device('cuda', idx))
         _workspaces[key] = ws
     return ws
 

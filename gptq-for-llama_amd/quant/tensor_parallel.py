@@ -125,10 +125,13 @@ class RowShardedQuantLinear(nn.Module):
     would add one rounding per shard: ~2e-3 instead of the 1e-3 budget); the bias is added after that, as in
     QuantLinear.forward (reference quant_linear.py:376)."""
 
-    def __init__(self, layer, rank=None, world=None, group=None, matmul_fn=None):
+    def __init__(self, layer, rank=None, world=None, group=None, matmul_fn=None, p2p=None):
+        """p2p: a quant.p2p.P2PAllReduce shared by the layers of this rank -> the one-shot all-reduce over IPC peer mappings
+        (one launch: push, flag, local sum, fp16 rounding + bias fused) instead of torch.distributed.all_reduce."""
         super().__init__()
         import torch.distributed as dist
         self.group = group
+        self.p2p = p2p
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         trivial = g_idx_is_trivial(layer.g_idx, layer.infeatures, layer.groupsize)   # act-order shards keep every group
@@ -144,6 +147,8 @@ class RowShardedQuantLinear(nn.Module):
         out_shape = x.shape[:-1] + (self.outfeatures, )
         x2 = x.reshape(-1, x.shape[-1])[:, self.k0:self.k1]
         part = self._partial(x2, self.shard).float()
+        if self.world > 1 and self.p2p is not None and part.is_cuda and part.numel() % 4 == 0 and part.numel() <= self.p2p.n_max:
+            return self.p2p.allreduce(part, bias=self.bias).reshape(out_shape)
         if self.world > 1:
             dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
         y = part.half()

@@ -272,6 +272,31 @@ int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size
 int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t stripes_bytes, float *y_partial, int K, int N, int bits,
                                    int groupsize, int nsets, const int32_t *perm, gptq_stream_t stream);
 
+/* ---- one-shot all-reduce for the row-sharded layout (BASELINE config 5; csrc/p2p.hip) ------------------------------
+ * New functionality (the reference has no collective: llama.py:328-382 is layer placement).  The fp32 partials of a
+ * K-sharded QuantLinear are 32-176 KB at batch 1 -- latency-bound -- and MI355X's xGMI is a full mesh, so every rank
+ * WRITES its partial into all peers (memory mapped through HIP IPC), flags, and sums the P slots locally in rank order:
+ * one hop instead of the 2 (P - 1) of a ring, bit-identical results on every rank, fp16 rounding (+ bias) fused.
+ *   gptq_p2p_create   allocates this rank's exchange buffer (gptq_p2p_buffer_bytes: two slot sets [world][n_max] fp32 +
+ *                     flags + per-workgroup epoch counters, zeroed) and exports its 64-byte IPC handle; the caller ships
+ *                     the handle to the other ranks (any channel, e.g. torch.distributed.all_gather_object)
+ *   gptq_p2p_open     maps a peer's buffer into this process (hipIpcOpenMemHandle; needs HSA_ENABLE_IPC_MODE_LEGACY=0)
+ *   gptq_p2p_allreduce_f32  peer_buffers = HOST array of `world` pointers, [rank] = own buffer; n % 4 == 0, n <= n_max;
+ *                     writes y_f16 = fp16(sum) (+ bias) or, when y_f32 != NULL, the fp32 sum.  All ranks must issue the same
+ *                     sequence of calls.  hipGraph-capturable (the epoch lives in device memory).
+ *   gptq_p2p_status   0, or 1 + the rank a workgroup gave up waiting for (every spin is bounded). */
+size_t gptq_p2p_buffer_bytes(int world, int n_max);
+int gptq_p2p_create(int world, int n_max, void **buffer, void *ipc_handle_64);
+int gptq_p2p_open(const void *ipc_handle_64, void **buffer);
+int gptq_p2p_close(void *buffer, int opened);
+int gptq_p2p_status(void *own_buffer, int world, int n_max, gptq_stream_t stream);
+int gptq_p2p_allreduce_f32(const float *partial, void *const *peer_buffers, int rank, int world, int n, int n_max, void *y_f16, float *y_f32,
+                           const void *bias, gptq_stream_t stream);
+/* partial = [2][n_half] fp32, the gate | up partials of a K-sharded fused MLP (gptq_stripe_matvec_partial_f32 with nsets = 2):
+ * y_f16[n_half] = fp16(silu(sum gate) * sum up) -- the epilogue of fusedmatmul_248_kernel (quant/fused_mlp.py:160-166), after the reduce. */
+int gptq_p2p_allreduce_silu_mul_f32(const float *partial, void *const *peer_buffers, int rank, int world, int n_half, int n_max, void *y_f16,
+                                    gptq_stream_t stream);
+
 /* ---- GPTQ solver (the caller that PRODUCES the weights; reference gptq.py:128-228) -------------------------------
  * One column block [i1, i1 + count), count <= 128, of the sequential quantise / error-feedback loop (gptq.py:177-199)
  * for all rows at once, in the reference's own fp32 arithmetic (IEEE division, round-half-even, no contraction).

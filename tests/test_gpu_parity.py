@@ -1011,3 +1011,109 @@ def test_row_sharded_linear_two_processes_one_gpu():
         p.join(300)
         assert p.exitcode == 0
     assert ret.get(timeout=5) == 1
+
+
+# ---------------------------------------------------------------------------------------
+# one-shot all-reduce over HIP IPC peer mappings (csrc/p2p.hip): two processes on cuda:0 map each other's exchange buffer
+# and reduce through it -- the same code path as two GPUs over xGMI (system-scope stores / flags), minus the link
+# ---------------------------------------------------------------------------------------
+def _p2p_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from quant import tensor_parallel as tp
+        from quant.p2p import P2PAllReduce
+        torch.cuda.set_device(0)
+        ar = P2PAllReduce(2 * 22016)
+        ok = True
+        # raw all-reduce: exact fp32 sums in rank order, odd sizes, many calls back to back (slot parity), bias, fp32 output
+        for it, n in enumerate([4096, 16384, 4, 2052, 11008, 8192, 8192, 8192]):
+            parts = [np.random.default_rng(100 * it + r).standard_normal(n).astype(np.float32) for r in range(world)]
+            want = parts[0].copy()
+            for r in range(1, world):
+                want = want + parts[r]
+            bias = np.random.default_rng(it).standard_normal(n).astype(np.float16) if it % 2 else None
+            y = ar.allreduce(dev(parts[rank]), bias=None if bias is None else dev(bias)).cpu().numpy()
+            w16 = want.astype(np.float16)
+            if bias is not None:
+                w16 = (w16.astype(np.float32) + bias.astype(np.float32)).astype(np.float16)
+            ok = ok and np.array_equal(y, w16)
+            y32 = ar.allreduce(dev(parts[rank]), out=torch.empty(n, dtype=torch.float32, device='cuda')).cpu().numpy()
+            ok = ok and np.array_equal(y32, want)
+        # gate | up partials -> silu(sum gate) * sum up, rounded once (fused_mlp.py:160-166 after the reduce)
+        for n in (11008, 22016, 64):
+            parts = [np.random.default_rng(7 * n + r).standard_normal((2, n)).astype(np.float32) for r in range(world)]
+            tot = parts[0].copy()
+            for r in range(1, world):
+                tot = tot + parts[r]
+            y = ar.allreduce_silu_mul(dev(parts[rank])).cpu().numpy()
+            want = (tot[0].astype(np.float64) / (1 + np.exp(-tot[0].astype(np.float64))) * tot[1]).astype(np.float32)
+            ok = ok and y.shape == (1, n) and rel_err(y, want[None]) < TOL
+        # a burst without host synchronisation in between (a rank may run one call ahead of its peer)
+        outs = []
+        for it in range(32):
+            outs.append(ar.allreduce(torch.full((4096,), float(it + rank), dtype=torch.float32, device='cuda')))
+        torch.cuda.synchronize()
+        for it, o in enumerate(outs):
+            ok = ok and bool((o == float(2 * it + 1)).all())
+        # the module: K-sharded QuantLinear, one launch for partial + one for the exchange
+        for K, N, act in [(8192, 512, False), (2048, 288, True)]:
+            L = make_random_layer(4, 128, K, N, act_order=act, seed=K + N)
+            bias = np.random.default_rng(1).standard_normal(N).astype(np.float16)
+            layer = quant.QuantLinear(4, 128, K, N, True)
+            layer.qweight, layer.qzeros, layer.scales, layer.g_idx, layer.bias = (dev(L['qweight']), dev(L['qzeros']), dev(L['scales']),
+                                                                                  dev(L['g_idx']), dev(bias))
+            xh = np.random.default_rng(2).standard_normal((1, K)).astype(np.float16)
+            row = tp.RowShardedQuantLinear(layer, p2p=ar)
+            y = row(dev(xh)).cpu().numpy()
+            y_rccl = tp.RowShardedQuantLinear(layer)(dev(xh)).cpu().numpy()       # gloo all-reduce of the same partials
+            ref = oracle.matmul248(xh, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4, bias=bias)
+            ok = ok and rel_err(y, ref) < 2 * TOL and np.array_equal(y, y_rccl)
+        # hipGraph replay: the epoch is device state, so a captured exchange can be replayed
+        part = torch.zeros(4096, dtype=torch.float32, device='cuda')
+        out = torch.empty(4096, dtype=torch.float16, device='cuda')
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            ar.allreduce(part, out=out)
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                ar.allreduce(part, out=out)
+        torch.cuda.synchronize()
+        for it in range(5):
+            part.fill_(float(it * (rank + 1)))
+            g.replay()
+            torch.cuda.synchronize()
+            ok = ok and bool((out == float(3 * it)).all())
+        ok = ok and ar.status() == 0
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ar.close()
+        if rank == 0:
+            ret.put(int(t.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2p_allreduce_two_processes_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_p2p_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        if p.exitcode is None:
+            p.kill()
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == 1

@@ -249,6 +249,20 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert mv(x=2) == -3
     assert mv(M=0) == 0
 
+    # one-shot all-reduce (csrc/p2p.hip): everything is validated before a launch
+    import ctypes
+    assert lib.gptq_p2p_buffer_bytes(8, 8192) == 2 * 8 * 8192 * 4 + 2 * 8 * 64 * 4 + 64 * 4 + 256
+    assert lib.gptq_p2p_buffer_bytes(17, 8192) == 0 and lib.gptq_p2p_buffer_bytes(0, 8192) == 0 and lib.gptq_p2p_buffer_bytes(2, 8190) == 0
+    peers = (ctypes.c_void_p * 2)(256, 256)
+
+    def ar(part=256, pb=peers, rank=0, world=2, n=64, n_max=64, y16=256, y32=None):
+        return lib.gptq_p2p_allreduce_f32(part, pb, rank, world, n, n_max, y16, y32, None, None)
+    assert ar(part=None) == -4 and ar(y16=None) == -4 and ar(pb=None) == -4
+    assert ar(pb=(ctypes.c_void_p * 2)(256, None)) == -4
+    assert ar(rank=2) == -2 and ar(n=62) == -2 and ar(n=128) == -2 and ar(world=17) == -2
+    assert ar(part=260) == -3 and ar(y16=260) == -3
+    assert lib.gptq_p2p_create(2, 64, None, None) == -4 and lib.gptq_p2p_open(None, None) == -4 and lib.gptq_p2p_close(None, 0) == -4
+
 
 def test_byte_model_matches_survey_8d():
     """the algorithmic-bytes figures `roofline.achieved` is computed from, in bench.py and in the oracle"""

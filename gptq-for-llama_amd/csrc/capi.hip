@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "gptq_internal.h"
+#include "stripe_common.h"
 
 namespace gptq {
 
@@ -386,6 +387,7 @@ int gptq_query(int what) {
         case GPTQ_Q_SKINNY_MAX_M: return SKINNY_MAX_M;
         case GPTQ_Q_WORKSPACE_BYTES: return (int)WS_BYTES;
         case GPTQ_Q_NUM_GEMV_VARIANTS: return GEMV_NUM_VARIANTS;
+        case GPTQ_Q_STRIPE_MM_WORKSPACE_BYTES: return (int)STRIPE_MM_WS_BYTES;
     }
     return -1;
 }
@@ -687,12 +689,12 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
 
 static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, float *y32,
                          int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm,
-                         gptq_stream_t stream) {
+                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
     const int gq = stripe_gq_shift(K, N, bits, groupsize);
-    if (gq == -2 || M > 16 || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
+    if (gq == -2 || M > (mm_ws ? 64 : 16) || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
     if (M > 1 && (norm_weight || perm || y32)) return GPTQ_E_VARIANT;
     if (stripes_bytes < stripe_total_bytes(K, N, bits, groupsize, nsets)) return GPTQ_E_WORKSPACE;
     if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || !aligned(y32, 4) || (norm_weight && !aligned(norm_weight, 16)) ||
@@ -718,6 +720,12 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.NS = nsets;
     p.gq_shift = gq;
     p.bits = bits;
+    if (mm_ws) {   // row tiles on the matrix core (stripe_mm.inc)
+        const int forced = g_force_split_k.load();
+        if (bits == 4) return stripe_mm_dispatch_b4(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
+        if (bits == 8) return stripe_mm_dispatch_b8(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
+        return GPTQ_E_VARIANT;
+    }
     return stripe_gemv_dispatch(p, (hipStream_t)stream);
 }
 
@@ -726,6 +734,14 @@ int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size
                            gptq_stream_t stream) {
     if (!y) return GPTQ_E_NULL;
     return stripe_matvec(x, ldx, stripes, stripes_bytes, bias, y, ldy, nullptr, M, K, N, bits, groupsize, nsets, norm_weight, norm_eps, perm, stream);
+}
+
+int gptq_stripe_matmul_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
+                           int K, int N, int bits, int groupsize, int nsets, void *workspace, size_t workspace_bytes, gptq_stream_t stream) {
+    if (!y || !workspace) return GPTQ_E_NULL;
+    if (!aligned(workspace, 256)) return GPTQ_E_ALIGN;
+    return stripe_matvec(x, ldx, stripes, stripes_bytes, bias, y, ldy, nullptr, M, K, N, bits, groupsize, nsets, nullptr, 0.f, nullptr, stream, workspace,
+                         workspace_bytes);
 }
 
 int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t stripes_bytes, float *y_partial, int K, int N, int bits,

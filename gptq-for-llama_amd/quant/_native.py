@@ -79,6 +79,8 @@ _SIGNATURES = {
     'gptq_p2p_status': [c_void_p, c_int, c_int, c_void_p],
     'gptq_p2p_allreduce_f32': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     'gptq_p2p_allreduce_silu_mul_f32': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    'gptq_stripe_matmul_f16': [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                               c_size_t, c_void_p],
     'gptq_stripe_matvec_partial_f32': [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
 }
 
@@ -155,6 +157,25 @@ def workspace(device, stream=None):
         with torch.cuda.device(idx):
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device('cuda', idx))
         _workspaces[key] = ws
+    return ws
+
+
+_mm_workspaces = {}
+
+
+def mm_workspace(device, stream=None):
+    """Workspace of gptq_stripe_matmul_f16 (counters + fp32 partial tiles of the K slices), one per (device, stream), zeroed once:
+    the kernel returns the counters to zero.  Separate from ``workspace``: the partial tiles are scratch, the split-K words
+    of the rowwave kernels must stay zero."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if stream is None:
+        stream = torch.cuda.current_stream(torch.device('cuda', idx)).cuda_stream
+    key = (device.type, idx, int(stream))
+    ws = _mm_workspaces.get(key)
+    if ws is None:
+        with torch.cuda.device(idx):
+            ws = torch.zeros(lib().gptq_query(5), dtype=torch.uint8, device=torch.device('cuda', idx))
+        _mm_workspaces[key] = ws
     return ws
 
 

@@ -50,6 +50,17 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
                 c = torch.empty((M, N), device=x.device, dtype=torch.float16)
                 if stripe_matvec(x2, st, c, K, N, bits, groupsize, nsets=2, strict=False):
                     return c
+    if family in (None, 'stripe_mm') and 4 < M <= 64 and bits in (4, 8) and all(gi is None for gi in gis):
+        # small batches: the pair image through 16-row MFMA tiles (csrc/stripe_mm.inc), SiLU pair in the (reduce) epilogue
+        from .quant_linear import stripe_copy, stripe_matmul
+        st = stripe_copy(_int32c(gate[0]), gate[1], _int32c(gate[2]), bits, groupsize, up=(_int32c(up[0]), up[1], _int32c(up[2])))
+        if st is not None:
+            with torch.cuda.device(x.device):
+                c = torch.empty((M, N), device=x.device, dtype=torch.float16)
+                if stripe_matmul(x2, st, c, K, N, bits, groupsize, nsets=2, strict=False):
+                    return c
+    if family == 'stripe_mm':
+        raise RuntimeError('fused_gate_up: the stripe16 MFMA kernel does not serve this shape')
     if family is None and M == 1 and bits in (2, 4, 8) and all(gi is not None for gi in gis):
         # act-order MLP at decode: gate and up share their input, hence their act-order permutation -> one x gather,
         # two group-sorted weight copies (cached on the tensors), the trivial-g_idx fused kernel

@@ -162,7 +162,23 @@ def stripe_matvec(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, norm_we
     return True
 
 
-STRIPE_MAX_M = 16  # rows of x one stripe16 launch serves (four per MFMA row group; 8 / 16 rows only while they fit in LDS)
+def stripe_matmul(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, strict=True):
+    """out[M, N] = x[M, K] (1 <= M <= 64) through a stripe16 image with 16-row MFMA tiles (gptq_stripe_matmul_f16, csrc/stripe_mm.inc):
+    exact q - z on the matrix core, fp32 group scales; bits 4 / 8, group size a multiple of the row block.  strict=False: False
+    instead of raising on GPTQ_E_VARIANT (the caller takes another kernel family)."""
+    M = x.shape[0]
+    ws = _native.mm_workspace(x.device)
+    rc = _native.lib().gptq_stripe_matmul_f16(x.data_ptr(), x.stride(0) if M > 1 else K, st.data_ptr(), st.numel(), _native.ptr(bias),
+                                              out.data_ptr(), out.stride(0) if M > 1 else N, M, K, N, bits, groupsize, nsets,
+                                              ws.data_ptr(), ws.numel(), _native.stream_ptr(x.device))
+    if rc == -6 and not strict:
+        return False
+    _native.check(rc, 'gptq_stripe_matmul_f16')
+    return True
+
+
+STRIPE_MAX_M = 16  # rows of x one stripe16 decode launch serves (four per MFMA row group; 8 / 16 rows only while they fit in LDS)
+STRIPE_MM_MAX_M = 64  # rows of the 16-row-tile MFMA kernel on the same image (gptq_stripe_matmul_f16)
 
 
 def _as_rows(t):
@@ -246,7 +262,7 @@ def dequantize(qweight, scales, qzeros, g_idx, bits, groupsize=None):
 
 
 _FAMILIES = {None: 'gptq_matmul248_f16', 'abi': 'gptq_matmul248_f16', 'gemv': 'gptq_gemv_f16', 'skinny': 'gptq_skinny_f16',
-             'stripe': 'gptq_matmul248_f16'}
+             'stripe': 'gptq_matmul248_f16', 'stripe_mm': 'gptq_matmul248_f16'}
 
 
 def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, family=None):
@@ -271,15 +287,22 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
             return out
         ws = _native.workspace(x.device)
         srt = act_order_sorted(qweight, gi, K, groupsize, bits) if gi is not None else None
-        # stripe16 serves M == 1 always, M <= 8 while M rows of x fit in LDS, 9..16 only when the grid is one workgroup per CU
-        # (N <= 4096: 128 KiB of x per workgroup leaves room for one; measured 7.6 vs 9.1 us at 4096^2, 20 vs 17 us at N = 12288)
-        stripe_m = M == 1 or (gi is None and (M <= 8 or (M <= STRIPE_MAX_M and (N <= 4096 or family == 'stripe'))))
+        # stripe16 image: M <= 4 rows share the decode launch for free; 5..8 rows = two 4x4x4 row groups while x fits in LDS;
+        # 5..64 rows otherwise = 16-row MFMA tiles (stripe_mm.inc); profiles/r2c_mm has the three measured side by side.
+        # family='stripe' pins the decode kernel (row groups up to 16 rows), 'stripe_mm' the MFMA-tile kernel.
+        stripe_m = M == 1 or (gi is None and M <= (STRIPE_MAX_M if family == 'stripe' else 8))
         if family in (None, 'stripe') and stripe_m and (gi is None or srt is not None):
             # decode: no-split-K kernel on the stripe16 copy (of the group-sorted rows for an act-order layer)
             st = stripe_copy(srt[0] if srt is not None else qweight, scales, qzeros, bits, groupsize)
             if st is not None and stripe_matvec(x, st, out, K, N, bits, groupsize, bias=bias, perm=srt[1] if srt is not None else None,
                                                 strict=family == 'stripe'):
                 return out
+        if family in (None, 'stripe_mm') and gi is None and bits in (4, 8) and (4 < M or family == 'stripe_mm') and M <= STRIPE_MM_MAX_M:
+            st = stripe_copy(qweight, scales, qzeros, bits, groupsize)
+            if st is not None and stripe_matmul(x, st, out, K, N, bits, groupsize, bias=bias, strict=False):
+                return out
+        if family == 'stripe_mm':
+            raise RuntimeError('matmul248: the stripe16 MFMA kernel does not serve this shape (M <= 64, bits 4 / 8, group >= one row block)')
         if family == 'stripe':
             raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M <= 4, bits in 2/4/8, K a multiple of the row block ...)')
         if srt is not None:

@@ -684,6 +684,53 @@ def test_stripe_row_groups_m5_to_16(bits, K, N, gs, M):
         assert np.array_equal(y1.view(np.uint16), y[m:m + 1].view(np.uint16))
 
 
+@pytest.mark.parametrize('M', [5, 16, 17, 33, 48, 64])
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 4096, 128), (4, 4096, 11008, 128), (4, 11008, 4096, 128), (4, 1152, 288, 128), (4, 2048, 96, -1),
+                                         (4, 3072, 64, 256), (8, 2048, 288, 64), (8, 4096, 4096, 128), (8, 1088, 96, -1)])
+def test_stripe_mm_vs_oracle(bits, K, N, gs, M):
+    """5 <= M <= 64 on the stripe16 image through 16-row MFMA tiles (gptq_stripe_matmul_f16): one launch (x streamed through LDS)
+    or K slices + the reduce kernel, ragged row-block counts, column groups that are not full (N % 128), one group; against the
+    oracle, run twice (bit-reproducible), and every row independent of its position in the batch"""
+    L = make_random_layer(bits, gs, K, N, seed=K + N + M)
+    x = np.random.default_rng(M).standard_normal((M, K)).astype(np.float16)
+    y, ref = check_forward(x, L, family='stripe_mm')
+    y2 = hip_forward(x, L, family='stripe_mm')
+    assert np.array_equal(y.view(np.uint16), y2.view(np.uint16))
+    perm = np.random.default_rng(1).permutation(M)
+    yp = hip_forward(np.ascontiguousarray(x[perm]), L, family='stripe_mm')
+    assert np.array_equal(yp.view(np.uint16), y[perm].view(np.uint16))
+
+
+@pytest.mark.parametrize('slices', [0, 4, 7, 16])
+@pytest.mark.parametrize('M', [16, 64])
+def test_stripe_mm_forced_variants(M, slices):
+    """both schedules on the same problem: one launch (0) and S K slices; with a bias (two fp16 roundings: 2e-3)"""
+    L = make_random_layer(4, 128, 4096 + 128, 512, seed=M)
+    x = np.random.default_rng(M).standard_normal((M, 4096 + 128)).astype(np.float16)
+    b = np.random.default_rng(3).standard_normal(512).astype(np.float16)
+    lib = quant._native.lib()
+    prev = lib.gptq_set_split_k(slices)
+    try:
+        y = hip_forward(x, L, b, family='stripe_mm')
+    finally:
+        lib.gptq_set_split_k(prev)
+    assert rel_err(y, oracle_forward(x, L, b)) < 2 * TOL
+
+
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 11008, 128), (8, 1024, 288, 64), (4, 11008 // 2, 256, 128)])
+@pytest.mark.parametrize('M', [9, 16, 40, 64])
+def test_stripe_mm_fused_mlp(bits, K, N, gs, M):
+    A, B = make_random_layer(bits, gs, K, N, seed=81), make_random_layer(bits, gs, K, N, seed=82)
+    x = (np.random.default_rng(M).standard_normal((M, K)) * 0.5).astype(np.float16)
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs, family='stripe_mm').cpu().numpy()
+    ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits)
+    assert rel_err(c, ref) < 2e-3
+    c2 = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs).cpu().numpy()     # the default dispatch takes the same kernel
+    assert np.array_equal(c.view(np.uint16), c2.view(np.uint16))
+
+
 def test_stripe_long_k_small_batch_falls_back():
     """M rows of x must fit in LDS: M = 8 on K = 11008 is refused by the stripe kernel (GPTQ_E_VARIANT) and the default
     dispatch takes the weight-streaming MFMA kernel -- same result"""

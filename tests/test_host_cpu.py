@@ -242,7 +242,7 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert mv(nsets=3) == -2
     assert mv(nbytes=nb - 1) == -5
     assert mv(bits=3) == -6
-    assert mv(M=17) == -6                                             # at most sixteen rows per launch
+    assert mv(M=17) == -6                                             # at most sixteen rows per launch (gptq_stripe_matmul_f16 serves up to 64)
     assert mv(M=2, norm=one) == -6                                     # fused RMSNorm is an M == 1 feature
     assert mv(M=2, ldx=252) == -3
     assert mv(x=None) == -4

@@ -404,6 +404,32 @@ def prefill_leg(dev, M=65536, reps=3):
     return out
 
 
+def small_batch_leg(dev):
+    """Decode batches of 2 .. 128 rows (reported only; reference forward for every M: quant_linear.py:415-419) through the
+    drop-in matmul248 on the four LLaMA-7B shapes, cold weights: M <= 4 share the stripe16 decode launch, 5 .. 8 its row
+    groups, above that the 16-row MFMA tiles of csrc/stripe_mm.inc (one launch or K slices + reduce kernel; no atomics)."""
+    from quant import quant_linear as QL
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(6)
+    out = {'unit': 'us per launch (hipGraph, cold weights)', 'shapes': {}}
+    for K, N in [(HIDDEN, HIDDEN), (HIDDEN, 3 * HIDDEN), (HIDDEN, INTER), (INTER, HIDDEN)]:
+        nsets = int(300e6 // alg_bytes(1, K, N)) + 1
+        sets = [PackedSet(K, N, dev, gen) for _ in range(nsets)]
+        gi = (torch.arange(K, device=dev) // GS).to(torch.int32)
+        row = {}
+        for M in (1, 4, 8, 16, 32, 64, 128):
+            x = torch.randn((M, K), device=dev, generator=gen).half()
+
+            def run(i):
+                w = sets[i]
+                QL.matmul248(x, w.qweight, w.scales, w.qzeros, gi, BITS, 15)
+            us = _time_cold(run, nsets, reps=3)
+            row['M%d' % M] = {'us': round(us, 2), 'TFLOPs': round(2.0 * M * K * N / us / 1e6, 1), 'GBps': round(alg_bytes(M, K, N) / us / 1e3, 1)}
+        out['shapes']['%dx%d' % (K, N)] = row
+        del sets
+    return out
+
+
 def config4_leg(dev):
     """BASELINE config 4 (reported only): LLaMA-7B-shaped 3-bit no-group and 4-bit g128 act-order, batch 1, cold weights,
     through the drop-in matmul248 (3-bit: rowwave3 kernel, an extension -- the reference raises for bits == 3,
@@ -571,6 +597,7 @@ def main():
     ap.add_argument('--dp', action='store_true', help='N independent replicas of the single-GPU workload (the default)')
     ap.add_argument('--no-prefill', action='store_true')
     ap.add_argument('--no-config4', action='store_true')
+    ap.add_argument('--no-small-batch', action='store_true')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -711,6 +738,11 @@ def main():
                 out['prefill_config3_reported_only'] = prefill_leg(dev)
             except Exception as e:
                 out['prefill_config3_reported_only'] = {'error': repr(e)[:200]}
+        if not args.no_small_batch and world == 1:
+            try:
+                out['small_batch_reported_only'] = small_batch_leg(dev)
+            except Exception as e:
+                out['small_batch_reported_only'] = {'error': repr(e)[:200]}
         if not args.no_config4 and world == 1:
             try:
                 out['config4_reported_only'] = config4_leg(dev)

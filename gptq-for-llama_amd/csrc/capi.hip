@@ -694,7 +694,7 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
     const int gq = stripe_gq_shift(K, N, bits, groupsize);
-    if (gq == -2 || M > (mm_ws ? 64 : 16) || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
+    if (gq == -2 || M > (mm_ws ? 256 : 16) || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
     if (M > 1 && (norm_weight || perm || y32)) return GPTQ_E_VARIANT;
     if (stripes_bytes < stripe_total_bytes(K, N, bits, groupsize, nsets)) return GPTQ_E_WORKSPACE;
     if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || !aligned(y32, 4) || (norm_weight && !aligned(norm_weight, 16)) ||
@@ -720,11 +720,18 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.NS = nsets;
     p.gq_shift = gq;
     p.bits = bits;
-    if (mm_ws) {   // row tiles on the matrix core (stripe_mm.inc)
+    if (mm_ws) {   // row tiles on the matrix core (stripe_mm.inc): passes of up to 64 rows, each streams the weights once
         const int forced = g_force_split_k.load();
-        if (bits == 4) return stripe_mm_dispatch_b4(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
-        if (bits == 8) return stripe_mm_dispatch_b8(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
-        return GPTQ_E_VARIANT;
+        if (bits != 4 && bits != 8) return GPTQ_E_VARIANT;
+        for (int m0 = 0; m0 < M; m0 += 64) {
+            p.x = (const half_t *)x + (size_t)m0 * ldx;
+            p.y = (half_t *)y + (size_t)m0 * ldy;
+            p.M = std::min(64, M - m0);
+            const int rc = bits == 4 ? stripe_mm_dispatch_b4(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream)
+                                     : stripe_mm_dispatch_b8(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
+            if (rc != 0) return rc;
+        }
+        return 0;
     }
     return stripe_gemv_dispatch(p, (hipStream_t)stream);
 }

@@ -164,9 +164,9 @@ _mm_workspaces = {}
 
 
 def mm_workspace(device, stream=None):
-    """Workspace of gptq_stripe_matmul_f16 (counters + fp32 partial tiles of the K slices), one per (device, stream), zeroed once:
-    the kernel returns the counters to zero.  Separate from ``workspace``: the partial tiles are scratch, the split-K words
-    of the rowwave kernels must stay zero."""
+    """Scratch of gptq_stripe_matmul_f16 (fp32 partial tiles of the K slices; no state survives a launch), one per (device, stream)
+    so that launches that may overlap never share it.  Separate from ``workspace``: the split-K words of the rowwave kernels
+    must stay zero, these tiles are overwritten freely."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if stream is None:
         stream = torch.cuda.current_stream(torch.device('cuda', idx)).cuda_stream
@@ -174,7 +174,7 @@ def mm_workspace(device, stream=None):
     ws = _mm_workspaces.get(key)
     if ws is None:
         with torch.cuda.device(idx):
-            ws = torch.zeros(lib().gptq_query(5), dtype=torch.uint8, device=torch.device('cuda', idx))
+            ws = torch.empty(lib().gptq_query(5), dtype=torch.uint8, device=torch.device('cuda', idx))
         _mm_workspaces[key] = ws
     return ws
 

@@ -50,7 +50,7 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
                 c = torch.empty((M, N), device=x.device, dtype=torch.float16)
                 if stripe_matvec(x2, st, c, K, N, bits, groupsize, nsets=2, strict=False):
                     return c
-    if family in (None, 'stripe_mm') and 4 < M <= 64 and bits in (4, 8) and all(gi is None for gi in gis):
+    if family in (None, 'stripe_mm') and 4 < M <= 128 and bits in (4, 8) and all(gi is None for gi in gis):
         # small batches: the pair image through 16-row MFMA tiles (csrc/stripe_mm.inc), SiLU pair in the (reduce) epilogue
         from .quant_linear import stripe_copy, stripe_matmul
         st = stripe_copy(_int32c(gate[0]), gate[1], _int32c(gate[2]), bits, groupsize, up=(_int32c(up[0]), up[1], _int32c(up[2])))

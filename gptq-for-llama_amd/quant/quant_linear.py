@@ -178,7 +178,8 @@ def stripe_matmul(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, strict=
 
 
 STRIPE_MAX_M = 16  # rows of x one stripe16 decode launch serves (four per MFMA row group; 8 / 16 rows only while they fit in LDS)
-STRIPE_MM_MAX_M = 64  # rows of the 16-row-tile MFMA kernel on the same image (gptq_stripe_matmul_f16)
+STRIPE_MM_MAX_M = 128  # rows served by the 16-row-tile MFMA kernel on the same image (gptq_stripe_matmul_f16: passes of 64 rows; the C ABI
+# takes up to 256, where dequantise + dense GEMM is already faster: profiles/r2c_mm/mid_m.txt)
 
 
 def _as_rows(t):
@@ -279,14 +280,8 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
         out = torch.empty((M, N), device=x.device, dtype=torch.float16)
         if M == 0:
             return out
-        if family is None and _mid_m(M, N):
-            W = dequantize(qweight, scales, qzeros, gi, bits, groupsize)
-            torch.matmul(x, W, out=out)
-            if bias is not None:
-                out += bias
-            return out
         ws = _native.workspace(x.device)
-        srt = act_order_sorted(qweight, gi, K, groupsize, bits) if gi is not None else None
+        srt = act_order_sorted(qweight, gi, K, groupsize, bits) if (gi is not None and not (family is None and _mid_m(M, N))) else None
         # stripe16 image: M <= 4 rows share the decode launch for free; 5..8 rows = two 4x4x4 row groups while x fits in LDS;
         # 5..64 rows otherwise = 16-row MFMA tiles (stripe_mm.inc); profiles/r2c_mm has the three measured side by side.
         # family='stripe' pins the decode kernel (row groups up to 16 rows), 'stripe_mm' the MFMA-tile kernel.
@@ -297,12 +292,18 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
             if st is not None and stripe_matvec(x, st, out, K, N, bits, groupsize, bias=bias, perm=srt[1] if srt is not None else None,
                                                 strict=family == 'stripe'):
                 return out
-        if family in (None, 'stripe_mm') and gi is None and bits in (4, 8) and (4 < M or family == 'stripe_mm') and M <= STRIPE_MM_MAX_M:
+        if family in (None, 'stripe_mm') and gi is None and bits in (4, 8) and (4 < M or family == 'stripe_mm') and M <= (256 if family == 'stripe_mm' else STRIPE_MM_MAX_M):
             st = stripe_copy(qweight, scales, qzeros, bits, groupsize)
             if st is not None and stripe_matmul(x, st, out, K, N, bits, groupsize, bias=bias, strict=False):
                 return out
         if family == 'stripe_mm':
-            raise RuntimeError('matmul248: the stripe16 MFMA kernel does not serve this shape (M <= 64, bits 4 / 8, group >= one row block)')
+            raise RuntimeError('matmul248: the stripe16 MFMA kernel does not serve this shape (M <= 256, bits 4 / 8, group >= one row block)')
+        if family is None and _mid_m(M, N):
+            W = dequantize(qweight, scales, qzeros, gi, bits, groupsize)
+            torch.matmul(x, W, out=out)
+            if bias is not None:
+                out += bias
+            return out
         if family == 'stripe':
             raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M <= 4, bits in 2/4/8, K a multiple of the row block ...)')
         if srt is not None:

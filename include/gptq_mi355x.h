@@ -58,7 +58,7 @@ enum {
     GPTQ_Q_SKINNY_MAX_M = 2,      /* largest M served by the weight-streaming MFMA kernel    */
     GPTQ_Q_WORKSPACE_BYTES = 3,   /* bytes of zero-initialised workspace split-K needs       */
     GPTQ_Q_NUM_GEMV_VARIANTS = 4,
-    GPTQ_Q_STRIPE_MM_WORKSPACE_BYTES = 5   /* bytes of the (separate, zero-initialised) workspace of gptq_stripe_matmul_f16 */
+    GPTQ_Q_STRIPE_MM_WORKSPACE_BYTES = 5   /* bytes of the (separate, scratch) workspace of gptq_stripe_matmul_f16 */
 };
 
 int gptq_query(int what);
@@ -272,12 +272,14 @@ int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size
  * complete sums). */
 int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t stripes_bytes, float *y_partial, int K, int N, int bits,
                                    int groupsize, int nsets, const int32_t *perm, gptq_stream_t stream);
-/* Small decode batches, 1 <= M <= 64, on the same image (csrc/stripe_mm.inc): 16-row MFMA tiles (v_mfma_f32_16x16x32_f16) on exactly
- * dequantised q - z, fp32 group scales; a workgroup owns 128 columns x one K slice, the K slices meet through fp32 partial
- * tiles in `workspace` (one counter increment per workgroup, summed in slice order: bit-reproducible).  bits 4 / 8, group size a
+/* Small decode batches, 1 <= M <= 256 (passes of up to 64 rows, each streams the weights once), on the same image (csrc/stripe_mm.inc): 16-row MFMA tiles (v_mfma_f32_16x16x32_f16) on exactly
+ * dequantised q - z, fp32 group scales; either one launch (a stripe x whole K per workgroup, x streamed through LDS) or K slices
+ * (128 columns x one slice per workgroup) that meet through fp32 partial tiles in `workspace` and a reduce kernel (summed in
+ * slice order: bit-reproducible; no atomics).  bits 4 / 8, group size a
  * multiple of 128 / 64 k or one group; GPTQ_E_VARIANT otherwise (callers fall back to gptq_matmul248_f16).  The workspace
- * (gptq_query(GPTQ_Q_STRIPE_MM_WORKSPACE_BYTES), 256-byte aligned, zero-initialised ONCE, not shared with concurrent launches or
- * with the split-K workspace of the rowwave kernels) returns to its initial state.  Reference semantics:
+ * (gptq_query(GPTQ_Q_STRIPE_MM_WORKSPACE_BYTES), 256-byte aligned) is pure scratch for the partial tiles: no initialisation, no state
+ * between launches; do not share it between launches that may overlap, nor with the zero-invariant split-K workspace of the
+ * rowwave kernels.  Reference semantics:
  * quant/quant_linear.py:103-137, :415-419; nsets = 2: quant/fused_mlp.py:128-168 (no bias). */
 int gptq_stripe_matmul_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
                            int K, int N, int bits, int groupsize, int nsets, void *workspace, size_t workspace_bytes, gptq_stream_t stream);

@@ -684,7 +684,7 @@ def test_stripe_row_groups_m5_to_16(bits, K, N, gs, M):
         assert np.array_equal(y1.view(np.uint16), y[m:m + 1].view(np.uint16))
 
 
-@pytest.mark.parametrize('M', [5, 16, 17, 33, 48, 64])
+@pytest.mark.parametrize('M', [5, 16, 17, 33, 48, 64, 65, 100, 128])
 @pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 4096, 128), (4, 4096, 11008, 128), (4, 11008, 4096, 128), (4, 1152, 288, 128), (4, 2048, 96, -1),
                                          (4, 3072, 64, 256), (8, 2048, 288, 64), (8, 4096, 4096, 128), (8, 1088, 96, -1)])
 def test_stripe_mm_vs_oracle(bits, K, N, gs, M):

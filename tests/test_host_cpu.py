@@ -249,6 +249,16 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert mv(x=2) == -3
     assert mv(M=0) == 0
 
+    # small-batch MFMA kernel on the same image (csrc/stripe_mm.inc): scratch workspace required, up to 256 rows
+    def mm(x=one, st=one, nbytes=nb, y=one, M=16, bits=4, nsets=1, ws=256, wsb=1 << 20, ldx=256, ldy=64, gs=128):
+        return lib.gptq_stripe_matmul_f16(x, ldx, st, nbytes, None, y, ldy, M, 256, 64, bits, gs, nsets, ws, wsb, None)
+    assert lib.gptq_query(5) == 64 << 20
+    assert mm(ws=None) == -4 and mm(y=None) == -4 and mm(x=None) == -4
+    assert mm(ws=260) == -3 and mm(ldx=252) == -3
+    assert mm(M=257) == -6 and mm(bits=3) == -6
+    assert mm(nbytes=nb - 1) == -5
+    assert mm(M=0) == 0
+
     # one-shot all-reduce (csrc/p2p.hip): everything is validated before a launch
     import ctypes
     assert lib.gptq_p2p_buffer_bytes(8, 8192) == 2 * 8 * 8192 * 4 + 2 * 8 * 64 * 4 + 64 * 4 + 256

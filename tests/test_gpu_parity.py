@@ -698,7 +698,10 @@ def test_stripe_mm_vs_oracle(bits, K, N, gs, M):
     assert np.array_equal(y.view(np.uint16), y2.view(np.uint16))
     perm = np.random.default_rng(1).permutation(M)
     yp = hip_forward(np.ascontiguousarray(x[perm]), L, family='stripe_mm')
-    assert np.array_equal(yp.view(np.uint16), y[perm].view(np.uint16))
+    if M <= 64:     # one pass, one schedule: a row's result does not depend on where it sits in the batch
+        assert np.array_equal(yp.view(np.uint16), y[perm].view(np.uint16))
+    else:           # passes of 64 rows may take different schedules (one launch vs K slices): same value up to fp32 summation order
+        assert rel_err(yp, y[perm]) < TOL
 
 
 @pytest.mark.parametrize('slices', [0, 4, 7, 16])

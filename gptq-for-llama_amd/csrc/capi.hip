@@ -665,7 +665,25 @@ int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k
     if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4)) return GPTQ_E_ALIGN;
     if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
     return decode_attn_fused_launch((const half_t *)qkv, position, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out,
-                                    (float *)workspace, heads, t_max, base, scale, (hipStream_t)stream);
+                                    (float *)workspace, heads, t_max, base, scale, nullptr, (hipStream_t)stream);
+}
+
+int gptq_rope_table_f32(float *table, int t_max, int head_dim, float base, gptq_stream_t stream) {
+    if (!table) return GPTQ_E_NULL;
+    if (t_max <= 0 || head_dim != 128) return GPTQ_E_SHAPE;
+    if (!aligned(table, 8)) return GPTQ_E_ALIGN;
+    return rope_table_launch(table, t_max, head_dim, base, (hipStream_t)stream);
+}
+
+int gptq_decode_attn_fused_table_f16(const void *qkv, const int64_t *position, void *k_cache, void *v_cache, void *out, void *workspace,
+                                     size_t workspace_bytes, int heads, int head_dim, int t_max, float base, float scale,
+                                     const float *rope_table, gptq_stream_t stream) {
+    if (!qkv || !k_cache || !v_cache || !position || !out || !workspace || !rope_table) return GPTQ_E_NULL;
+    if (heads <= 0 || head_dim != 128 || t_max <= 0) return GPTQ_E_SHAPE;
+    if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4) || !aligned(rope_table, 8)) return GPTQ_E_ALIGN;
+    if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
+    return decode_attn_fused_launch((const half_t *)qkv, position, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out,
+                                    (float *)workspace, heads, t_max, base, scale, rope_table, (hipStream_t)stream);
 }
 
 // ---- stripe16: no-split-K decode GEMV on a load-time repacked copy (stripe*.hip) ----

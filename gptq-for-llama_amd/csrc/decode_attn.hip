@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(ATT_HD) attn_combine_kernel(const float *__res
 __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__restrict__ qkv, const int64_t *__restrict__ pos_ptr,
                                                                 half_t *__restrict__ kc, half_t *__restrict__ vc,
                                                                 half_t *__restrict__ out, float *__restrict__ ws, int heads, int t_max,
-                                                                float inv_base, float scale) {
+                                                                float inv_base, float scale, const float2 *__restrict__ rope_tab) {
     __shared__ float qs[ATT_HD];
     __shared__ __attribute__((aligned(16))) half_t knew[ATT_HD];
     __shared__ __attribute__((aligned(16))) half_t vnew[ATT_HD];
@@ -199,8 +199,16 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
 
     if (tid < ATT_HD / 2) {
         const int c = tid;
-        const float freq = expf((float)c * inv_base) * (float)pos;
-        const float cs = cosf(freq), sn = sinf(freq);
+        float cs, sn;
+        if (rope_tab) {   // {cos, sin} of (pos, c) from the table rope_table_kernel filled with the SAME instructions: one load under
+            const float2 e = rope_tab[(size_t)pos * (ATT_HD / 2) + c];   // the K/V latency instead of ~1 us of accurate-libm range reduction
+            cs = e.x;
+            sn = e.y;
+        } else {
+            const float freq = expf((float)c * inv_base) * (float)pos;
+            cs = cosf(freq);
+            sn = sinf(freq);
+        }
         const half_t *q = qkv + (size_t)h * ATT_HD + c;
         const float qx = (float)q[0], qy = (float)q[ATT_HD / 2];
         qs[c] = (float)(half_t)(qx * cs - qy * sn);       // rounded to fp16 like the in-place reference RoPE
@@ -340,11 +348,25 @@ int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, cons
 }
 
 int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
-                             float base, float scale, hipStream_t s) {
+                             float base, float scale, const float *rope_table, hipStream_t s) {
     const int nsplit = (t_max + ATT_TS - 1) / ATT_TS;
     const float inv_base = -2.0f * logf(base) / (float)ATT_HD;
     hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(heads, nsplit), dim3(256), 0, s, qkv, pos, kc, vc, out, ws, heads, t_max, inv_base,
-                       scale);
+                       scale, (const float2 *)rope_table);
+    return (int)hipGetLastError();
+}
+
+// {cos, sin}(pos * base^(-2c / head_dim)) for pos < t_max, c < head_dim / 2: the arithmetic of the in-kernel RoPE above, once
+__global__ void __launch_bounds__(64) rope_table_kernel(float2 *__restrict__ tab, int half, float inv_base) {
+    const int pos = blockIdx.x, c = threadIdx.x;
+    if (c >= half) return;
+    const float freq = expf((float)c * inv_base) * (float)pos;
+    tab[(size_t)pos * half + c] = float2{cosf(freq), sinf(freq)};
+}
+
+int rope_table_launch(float *table, int t_max, int head_dim, float base, hipStream_t s) {
+    const float inv_base = -2.0f * logf(base) / (float)head_dim;
+    hipLaunchKernelGGL(rope_table_kernel, dim3(t_max), dim3(64), 0, s, (float2 *)table, head_dim / 2, inv_base);
     return (int)hipGetLastError();
 }
 

@@ -61,6 +61,9 @@ _SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
     'gptq_decode_rope_kv_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p],
     'gptq_decode_attn_workspace_bytes': [c_int, c_int, c_int],
+    'gptq_rope_table_f32': [c_void_p, c_int, c_int, c_float, c_void_p],
+    'gptq_decode_attn_fused_table_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
+                                         c_float, c_float, c_void_p, c_void_p],
     'gptq_decode_attn_fused_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,
                                    c_float, c_float, c_void_p],
     'gptq_decode_attn_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int,

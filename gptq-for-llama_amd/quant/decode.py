@@ -10,6 +10,7 @@ buffers are filled with the synthetic distribution of SURVEY 8(d) directly on th
 import time
 
 import numpy as np
+import os
 import torch
 
 from . import fused_attn, fused_mlp, quant_linear, triton_norm
@@ -158,6 +159,9 @@ def benchmark_generate(model, prompt_len=16, new_tokens=128, seed=0):
 # RMSNorm, fused gate/up, down GEMV + residual) -- so that ONE hipGraph replay is one token.
 # The position lives in device memory and is advanced inside the graph.
 # ----------------------------------------------------------------------------------------------
+ROPE_TABLE = os.environ.get('GPTQ_ROPE_TABLE', '1') != '0'
+
+
 class DecodeEngine:
 
     def __init__(self, model, t_max=2048, fuse_norm=True, fuse_attn=True):
@@ -328,6 +332,19 @@ class DecodeEngine:
                                          g['K'], g['N'], g['bits'], g['gs'], self.ws.data_ptr(), self.ws.numel(), s)
         self.native.check(rc, 'gptq_fused_mlp_f16')
 
+    def _rope_table(self, theta, s):
+        """{cos, sin}[t_max][head_dim / 2] fp32 per rope base (one for a LLaMA), filled once by the kernel that would otherwise
+        evaluate them per token and head.  GPTQ_ROPE_TABLE=0: compute in the attention kernel (A/B runs)."""
+        if not ROPE_TABLE:
+            return None
+        tabs = self.__dict__.setdefault('_rope_tabs', {})
+        t = tabs.get(float(theta))
+        if t is None:
+            t = torch.empty((self.t_max, self.head_dim // 2, 2), dtype=torch.float32, device=self.dev)
+            self.native.check(self.lib.gptq_rope_table_f32(t.data_ptr(), self.t_max, self.head_dim, float(theta), s), 'gptq_rope_table_f32')
+            tabs[float(theta)] = t
+        return t
+
     def _step(self):
         lib, ptr = self.lib, self.native.ptr
         s = torch.cuda.current_stream(self.dev).cuda_stream
@@ -337,9 +354,16 @@ class DecodeEngine:
         for li, L in enumerate(self.layers):
             self._norm_gemv(self.x, L['ln1'], L['qkv'], self.qkvb, s)       # qkv = qkv_proj(rmsnorm(x))
             if self.fuse_attn:
-                rc = lib.gptq_decode_attn_fused_f16(self.qkvb.data_ptr(), self.pos.data_ptr(), self.kc[li].data_ptr(),
-                                                    self.vc[li].data_ptr(), self.ab.data_ptr(), self.attn_ws.data_ptr(),
-                                                    self.attn_ws.numel(), self.heads, self.head_dim, self.t_max, L['theta'], scale, s)
+                tab = self._rope_table(L['theta'], s)
+                if tab is not None:
+                    rc = lib.gptq_decode_attn_fused_table_f16(self.qkvb.data_ptr(), self.pos.data_ptr(), self.kc[li].data_ptr(),
+                                                              self.vc[li].data_ptr(), self.ab.data_ptr(), self.attn_ws.data_ptr(),
+                                                              self.attn_ws.numel(), self.heads, self.head_dim, self.t_max, L['theta'], scale,
+                                                              tab.data_ptr(), s)
+                else:
+                    rc = lib.gptq_decode_attn_fused_f16(self.qkvb.data_ptr(), self.pos.data_ptr(), self.kc[li].data_ptr(),
+                                                        self.vc[li].data_ptr(), self.ab.data_ptr(), self.attn_ws.data_ptr(),
+                                                        self.attn_ws.numel(), self.heads, self.head_dim, self.t_max, L['theta'], scale, s)
                 self.native.check(rc, 'gptq_decode_attn_fused_f16')
             else:
                 rc = lib.gptq_decode_rope_kv_f16(self.qkvb.data_ptr(), self.pos.data_ptr(), self.kc[li].data_ptr(),

@@ -241,6 +241,12 @@ int gptq_decode_attn_f16(const void *q, const void *k_cache, const void *v_cache
 int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k_cache, void *v_cache, void *out,
                                void *workspace, size_t workspace_bytes, int heads, int head_dim, int t_max,
                                float base, float scale, gptq_stream_t stream);
+/* The same launch with {cos, sin} read from a table gptq_rope_table_f32 filled once ([t_max][head_dim / 2][2] fp32, the identical
+ * instruction sequence: bit-identical results): the accurate-libm range reduction leaves the per-token critical path. */
+int gptq_rope_table_f32(float *table, int t_max, int head_dim, float base, gptq_stream_t stream);
+int gptq_decode_attn_fused_table_f16(const void *qkv, const int64_t *position, void *k_cache, void *v_cache, void *out, void *workspace,
+                                     size_t workspace_bytes, int heads, int head_dim, int t_max, float base, float scale,
+                                     const float *rope_table, gptq_stream_t stream);
 
 /* ---- stripe16: the batch-1 decode matvec WITHOUT a K split, on a load-time repacked copy (csrc/stripe.hip) --------
  * Replaces, for M == 1, the launch of matmul_248_kernel (quant/quant_linear.py:263-269) / fusedmatmul_248_kernel

@@ -301,6 +301,50 @@ template <int NU, int NS, int NW, int DU, int MODE, int MATH>
 static void launch(const SP &p, hipStream_t s) {
     hipLaunchKernelGGL((k_stripe16<NU, NS, NW, DU, MODE, MATH>), dim3(p.N / 16), dim3(NW * 64), lds_bytes(p, NS, NW), s, p);
 }
+
+// LDS-DMA loads only: every wave streams its row blocks into a PRIVATE LDS region (global_load_lds_dwordx4, nt), DEPTH blocks
+// in flight, reads one dword of each landed block back (xor) -- the floor of an LDS-DMA version of the kernel above.
+template <int NU, int NS, int NW, int DEPTH>
+__global__ void __launch_bounds__(NW * 64) k_glds_only(const SP p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int stripe = blockIdx.x, nrb = p.nrb;
+    unsigned char *mine = smem + wave * (DEPTH * NS * 1024);
+    const uint32_t *wbase = p.R + ((size_t)stripe * nrb * NS * 64 + lane) * 4;
+    auto issue = [&](int u) {
+        const int rb = min(wave + NW * u, nrb - 1);
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wbase + ((size_t)rb * NS + s) * 256), (lptr_t)(mine + ((u % DEPTH) * NS + s) * 1024), 16, 0, 2);
+    };
+#pragma unroll
+    for (int u = 0; u < (DEPTH < NU ? DEPTH : NU); u++) issue(u);
+    uint32_t xo = 0;
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+        // blocks u+1 .. min(u+DEPTH, NU)-1 may stay in flight
+        constexpr int dummy = 0; (void)dummy;
+        const int left = (u + DEPTH < NU ? DEPTH : NU - u) - 1;
+        if (left >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NS) : "memory");
+        else if (left == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS) : "memory");
+        else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * NS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < NS; s++) xo ^= *(const uint32_t *)(mine + ((u % DEPTH) * NS + s) * 1024 + lane * 16);
+        if (u + DEPTH < NU) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue(u + DEPTH);
+        }
+    }
+    if (xo == 0x9e3779b9u) p.part[blockIdx.x] = 1.f;
+}
+template <int NU, int NS, int NW, int DEPTH>
+static void launch_glds(const SP &p, hipStream_t s) {
+    hipLaunchKernelGGL((k_glds_only<NU, NS, NW, DEPTH>), dim3(p.N / 16), dim3(NW * 64), NW * DEPTH * NS * 1024, s, p);
+}
 typedef void (*launch_fn)(const SP &, hipStream_t);
 struct WSet { uint32_t *R; uint32_t *tab; };
 
@@ -388,6 +432,14 @@ static void run_config(const char *name, SP base, const std::vector<WSet> &sets,
     const float t3 = best_of(launch<NU, NS, NW, DU, 3, 0>, base, sets, c.s);
     const float t5 = best_of(launch<NU, NS, NW, DU, 5, 0>, base, sets, c.s);
     printf("  %-22s NU%-2d NS%d NW%-2d DU%d wgs %5d lds %5zu | loadsonly %6.2f | +stage %6.2f | +stage+store %6.2f\n", name, NU, NS, NW, DU, base.N / 16, lds, t3, t2, t5);
+    {
+        constexpr int D4 = NU < 4 ? NU : 4;
+        CK(hipFuncSetAttribute((const void *)k_glds_only<NU, NS, NW, D4>, hipFuncAttributeMaxDynamicSharedMemorySize, NW * D4 * NS * 1024));
+        CK(hipFuncSetAttribute((const void *)k_glds_only<NU, NS, NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, NW * 2 * NS * 1024));
+        const float g4 = best_of(launch_glds<NU, NS, NW, D4>, base, sets, c.s);
+        const float g2 = best_of(launch_glds<NU, NS, NW, 2>, base, sets, c.s);
+        printf("    LDS-DMA loads only: depth %d %6.2f us | depth 2 %6.2f us\n", D4, g4, g2);
+    }
     run_math<NU, NS, NW, DU, 0>(base, sets, c);
     run_math<NU, NS, NW, DU, 2>(base, sets, c);
 }

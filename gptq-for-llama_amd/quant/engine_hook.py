@@ -92,9 +92,12 @@ def _sync_in(st, cache, T):
 def _engine_forward(model, st, input_ids, cache, attention_mask, kw):
     """one token through the DecodeEngine, or None when this call has to go the eager way."""
     from .decode import DecodeEngine
-    if not _eligible_model(model):
-        return None
     sig = _signature(model)
+    if st.sig != sig or st.engine is None:
+        if not _eligible_model(model):      # (walks all layers: only when the weights changed identity, not once per token)
+            return None
+    elif model.training:
+        return None
     if st.engine is None or st.sig != sig:
         t_max = int(min(max(getattr(model.config, 'max_position_embeddings', 2048), 256), 8192))
         st.engine = DecodeEngine(model, t_max=t_max).capture()

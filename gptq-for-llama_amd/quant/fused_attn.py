@@ -80,6 +80,8 @@ class QuantLlamaAttention(nn.Module):
             else:
                 position_ids = torch.arange(past_len, past_len + q_len, device=hidden_states.device).view(1, -1).expand(
                     bsz, -1).contiguous()
+        elif position_ids.dim() == 2 and position_ids.shape[0] == 1 and bsz > 1:
+            position_ids = position_ids.expand(bsz, -1).contiguous()     # current transformers hands one row for the whole batch
         elif position_ids.stride(-1) != 1:
             position_ids = position_ids.contiguous()
 

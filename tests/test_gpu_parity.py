@@ -721,7 +721,7 @@ def test_stripe_mm_forced_variants(M, slices):
 
 
 @pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 11008, 128), (8, 1024, 288, 64), (4, 11008 // 2, 256, 128)])
-@pytest.mark.parametrize('M', [9, 16, 40, 64])
+@pytest.mark.parametrize('M', [9, 16, 40, 64, 100])
 def test_stripe_mm_fused_mlp(bits, K, N, gs, M):
     A, B = make_random_layer(bits, gs, K, N, seed=81), make_random_layer(bits, gs, K, N, seed=82)
     x = (np.random.default_rng(M).standard_normal((M, K)) * 0.5).astype(np.float16)

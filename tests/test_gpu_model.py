@@ -420,6 +420,26 @@ def test_generate_goes_through_the_decode_engine_and_matches_the_module_chain():
     assert s.shape[1] <= 40 and torch.equal(s[:, :7], ids)
 
 
+def test_batched_generate_runs_eagerly_through_the_small_batch_kernels():
+    """model.generate on a BATCH of prompts (padding mask, batch 4 and 12): the hook leaves batches to the module chain, whose
+    linears then run at M = batch; greedy tokens of the fused model equal those of the unfused one (QuantLinear inside stock HF
+    blocks) up to the first near-tie, and the prompts come back untouched"""
+    from quant.engine_hook import engine_steps
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=13, fused=True, **HOOK_CFG)
+    plain = D.build_random_llama(DEV, bits=4, groupsize=128, seed=13, fused=False, **HOOK_CFG)
+    for batch in (4, 12):
+        ids = torch.randint(1, 512, (batch, 6), device=DEV, generator=torch.Generator(device=DEV).manual_seed(batch))
+        mask = torch.ones_like(ids)
+        before = engine_steps(model)
+        with torch.no_grad():
+            out = model.generate(ids, attention_mask=mask, do_sample=False, max_new_tokens=8, min_new_tokens=8, pad_token_id=0)
+            ref = plain.generate(ids, attention_mask=mask, do_sample=False, max_new_tokens=8, min_new_tokens=8, pad_token_id=0)
+        assert engine_steps(model) == before                      # batches are not the engine's business
+        assert out.shape == (batch, 14) and torch.equal(out[:, :6], ids)
+        agree = (out[:, 6] == ref[:, 6]).float().mean().item()    # the first new token of (nearly) every row: fp16 near-ties may flip a few
+        assert agree >= 0.75, agree
+
+
 def test_engine_hook_keeps_the_callers_cache_consistent():
     """tokens only the engine has seen are appended to the caller's cache before any eager call touches it: a multi-token
     forward after engine steps gives the logits of a run that never used the engine."""

@@ -665,7 +665,7 @@ int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k
     if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4)) return GPTQ_E_ALIGN;
     if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
     return decode_attn_fused_launch((const half_t *)qkv, position, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out,
-                                    (float *)workspace, heads, t_max, base, scale, nullptr, (hipStream_t)stream);
+                                    (float *)workspace, heads, t_max, base, scale, nullptr, (u64_t *)g_debug_buffer.load(), (hipStream_t)stream);
 }
 
 int gptq_rope_table_f32(float *table, int t_max, int head_dim, float base, gptq_stream_t stream) {
@@ -683,7 +683,7 @@ int gptq_decode_attn_fused_table_f16(const void *qkv, const int64_t *position, v
     if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4) || !aligned(rope_table, 8)) return GPTQ_E_ALIGN;
     if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
     return decode_attn_fused_launch((const half_t *)qkv, position, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out,
-                                    (float *)workspace, heads, t_max, base, scale, rope_table, (hipStream_t)stream);
+                                    (float *)workspace, heads, t_max, base, scale, rope_table, (u64_t *)g_debug_buffer.load(), (hipStream_t)stream);
 }
 
 // ---- stripe16: no-split-K decode GEMV on a load-time repacked copy (stripe*.hip) ----

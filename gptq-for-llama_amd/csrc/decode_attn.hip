@@ -11,6 +11,48 @@
 
 namespace gptq {
 
+
+// Cross-lane reductions on the VALU (DPP row operations + gfx950 permlane swaps) instead of __shfl_xor, which hipcc lowers to
+// ds_bpermute_b32: ~120 cycles of LDS round trip per dependent step -- the per-wave stamps (tools/timeline_attn.py) showed 3500
+// cycles in the 32 dependent shuffles of the score loop alone, 6500 of the launch's 10 000.  Same operand pairs as the xor
+// butterfly: bit-identical results.
+template <int CTRL>
+GPTQ_DEV float att_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+GPTQ_DEV float att_sum16(float v) {   // every lane of a 16-lane row ends with the row's sum (xor 1, 2, 4, 8)
+    v += att_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += att_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += att_dpp<0x141>(v);  // row_half_mirror
+    v += att_dpp<0x140>(v);  // row_mirror
+    return v;
+}
+GPTQ_DEV float att_max16(float v) {
+    v = fmaxf(v, att_dpp<0xB1>(v));
+    v = fmaxf(v, att_dpp<0x4E>(v));
+    v = fmaxf(v, att_dpp<0x141>(v));
+    v = fmaxf(v, att_dpp<0x140>(v));
+    return v;
+}
+GPTQ_DEV float att_rows_sum(float v) {   // sum over the four 16-lane rows of the wave (xor 16, 32)
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float s16 = __builtin_bit_cast(float, (uint32_t)a[0]) + __builtin_bit_cast(float, (uint32_t)a[1]);
+    const uint32_t u2 = __builtin_bit_cast(uint32_t, s16);
+    auto b = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+    return __builtin_bit_cast(float, (uint32_t)b[0]) + __builtin_bit_cast(float, (uint32_t)b[1]);
+}
+GPTQ_DEV float att_rows_max(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m16 = fmaxf(__builtin_bit_cast(float, (uint32_t)a[0]), __builtin_bit_cast(float, (uint32_t)a[1]));
+    const uint32_t u2 = __builtin_bit_cast(uint32_t, m16);
+    auto b = __builtin_amdgcn_permlane32_swap(u2, u2, false, false);
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)b[0]), __builtin_bit_cast(float, (uint32_t)b[1]));
+}
+GPTQ_DEV float att_wave_sum(float v) { return att_rows_sum(att_sum16(v)); }
+GPTQ_DEV float att_wave_max(float v) { return att_rows_max(att_max16(v)); }
+
 // ---------------------------------------------------------------------------------------
 // RoPE (rotate-half, fp32 trig exactly like rope_kernel / reference :43-57) on q (in place) and
 // k, then k,v -> cache row `pos`.  grid = heads, block = head_dim/2 threads.
@@ -79,10 +121,7 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const half_t *__restr
 #pragma unroll
             for (int j = 0; j < 8; j++) dot += qf[j] * (float)k8[j];
         }
-        dot += __shfl_xor(dot, 1, 64);
-        dot += __shfl_xor(dot, 2, 64);
-        dot += __shfl_xor(dot, 4, 64);
-        dot += __shfl_xor(dot, 8, 64);
+        dot = att_sum16(dot);
         if (d8 == 0) sc[tl] = (tl < nact) ? dot * scale : -INFINITY;
     }
     __syncthreads();
@@ -90,15 +129,13 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const half_t *__restr
     // ---- softmax statistics of the chunk ------------------------------------------------------
     float sv = (tid < ATT_TS) ? sc[tid] : -INFINITY;
     float m = sv;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    m = att_wave_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float p = (tid < nact) ? __expf(sv - m) : 0.f;
     float l = p;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) l += __shfl_xor(l, off, 64);
+    l = att_wave_sum(l);
     __syncthreads();                 // everyone has read sc[] and red[0..3]
     if (tid < ATT_TS) sc[tid] = p;
     if (lane == 0) red[4 + wave] = l;
@@ -158,7 +195,11 @@ __global__ void __launch_bounds__(ATT_HD) attn_combine_kernel(const float *__res
 __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__restrict__ qkv, const int64_t *__restrict__ pos_ptr,
                                                                 half_t *__restrict__ kc, half_t *__restrict__ vc,
                                                                 half_t *__restrict__ out, float *__restrict__ ws, int heads, int t_max,
-                                                                float inv_base, float scale, const float2 *__restrict__ rope_tab) {
+                                                                float inv_base, float scale, const float2 *__restrict__ rope_tab,
+                                                                u64_t *__restrict__ dbg) {
+    u64_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64_t sx_[4] = {0, 0, 0, 0};   // development stamps (gptq_set_debug_buffer, tools/timeline_attn.py)
+    if (dbg) { st_[0] = stamp_realtime(); st_[1] = stamp_cycles(0); }
     __shared__ float qs[ATT_HD];
     __shared__ __attribute__((aligned(16))) half_t knew[ATT_HD];
     __shared__ __attribute__((aligned(16))) half_t vnew[ATT_HD];
@@ -169,6 +210,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     const int h = blockIdx.x, s = blockIdx.y, nsplit = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t pos = pos_ptr[0];
+    if (dbg) st_[2] = stamp_cycles((uint32_t)pos);
     if (pos < 0 || pos >= t_max) return;
     const int len = (int)pos + 1;
     const int t0 = s * ATT_TS;
@@ -197,6 +239,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
                                               : (half8_t)(half_t)0;
     }
 
+    half_t nk0 = (half_t)0, nk1 = (half_t)0, nv0 = (half_t)0, nv1 = (half_t)0;   // the new token's K / V halves of this thread
     if (tid < ATT_HD / 2) {
         const int c = tid;
         float cs, sn;
@@ -218,25 +261,30 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
             const half_t *v = qkv + 2 * hd + (size_t)h * ATT_HD + c;
             const float kx = (float)k[0], ky = (float)k[ATT_HD / 2];
             const half_t k0 = (half_t)(kx * cs - ky * sn), k1 = (half_t)(kx * sn + ky * cs);
-            knew[c] = k0;
-            knew[c + ATT_HD / 2] = k1;
-            vnew[c] = v[0];
-            vnew[c + ATT_HD / 2] = v[ATT_HD / 2];
-            half_t *kd = kc + (size_t)pos * hd + (size_t)h * ATT_HD + c;
-            half_t *vd = vc + (size_t)pos * hd + (size_t)h * ATT_HD + c;
-            kd[0] = k0;
-            kd[ATT_HD / 2] = k1;
-            vd[0] = v[0];
-            vd[ATT_HD / 2] = v[ATT_HD / 2];
+            nk0 = k0; nk1 = k1; nv0 = v[0]; nv1 = v[ATT_HD / 2];
+            knew[c] = nk0;
+            knew[c + ATT_HD / 2] = nk1;
+            vnew[c] = nv0;
+            vnew[c + ATT_HD / 2] = nv1;
+            // the cache row itself is written AFTER the last load of this launch has been consumed (below): hipcc waits vmcnt(0)
+            // before every use of the prefetched rows (they sit behind branches), and a store in flight made each of those waits
+            // a full write latency -- 1500 of the launch's 8000 cycles (tools/timeline_attn.py)
         }
     }
     __syncthreads();
+    if (dbg) st_[3] = stamp_cycles(0);
     float qf[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) qf[j] = qs[d8 * 8 + j];
+    if (dbg) sx_[0] = stamp_cycles(__builtin_bit_cast(uint32_t, qf[7]));
+    const int nit = (nact + 15) / 16;   // 16-timestep groups that hold anything: a short context does not pay for 128 rows
 #pragma unroll
     for (int it = 0; it < ATT_TS / 16; it++) {
         const int tl = it * 16 + tsub;
+        if (it >= nit) {                // wave-uniform
+            if (d8 == 0) sc[tl] = -INFINITY;
+            continue;
+        }
         float dot = 0.f;
         if (tl < nact) {
             half8_t k8 = kpre[it];
@@ -244,29 +292,27 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
 #pragma unroll
             for (int j = 0; j < 8; j++) dot += qf[j] * (float)k8[j];
         }
-        dot += __shfl_xor(dot, 1, 64);
-        dot += __shfl_xor(dot, 2, 64);
-        dot += __shfl_xor(dot, 4, 64);
-        dot += __shfl_xor(dot, 8, 64);
+        dot = att_sum16(dot);
         if (d8 == 0) sc[tl] = (tl < nact) ? dot * scale : -INFINITY;
     }
+    if (dbg) sx_[1] = stamp_cycles(0);
     __syncthreads();
+    if (dbg) st_[4] = stamp_cycles(0);
     float sv = (tid < ATT_TS) ? sc[tid] : -INFINITY;
     float m = sv;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    m = att_wave_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float p = (tid < nact) ? __expf(sv - m) : 0.f;
     float l = p;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) l += __shfl_xor(l, off, 64);
+    l = att_wave_sum(l);
     __syncthreads();
     if (tid < ATT_TS) sc[tid] = p;
     if (lane == 0) red[4 + wave] = l;
     __syncthreads();
     l = red[4] + red[5] + red[6] + red[7];
+    if (dbg) st_[5] = stamp_cycles(__builtin_bit_cast(uint32_t, l));
 
     float av[8];
 #pragma unroll
@@ -274,7 +320,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
 #pragma unroll
     for (int it = 0; it < ATT_TS / 16; it++) {
         const int tl = it * 16 + tsub;
-        if (tl < nact) {
+        if (it < nit && tl < nact) {
             half8_t v8 = vpre[it];
             if (tl == tnew) v8 = *(const half8_t *)(vnew + d8 * 8);
             const float pt = sc[tl];
@@ -282,11 +328,19 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
             for (int j = 0; j < 8; j++) av[j] += pt * (float)v8[j];
         }
     }
+    if (dbg) sx_[2] = stamp_cycles(__builtin_bit_cast(uint32_t, av[0]));
+    if (own_new && tid < ATT_HD / 2) {   // append the new token's row to the cache (nothing in this launch reads it back: it came from LDS)
+        half_t *kd = kc + (size_t)pos * hd + (size_t)h * ATT_HD + tid;
+        half_t *vd = vc + (size_t)pos * hd + (size_t)h * ATT_HD + tid;
+        kd[0] = nk0;
+        kd[ATT_HD / 2] = nk1;
+        vd[0] = nv0;
+        vd[ATT_HD / 2] = nv1;
+    }
     // the 4 timestep groups of a wave (lane >> 4), then the 4 waves through LDS
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        av[j] += __shfl_xor(av[j], 16, 64);
-        av[j] += __shfl_xor(av[j], 32, 64);
+        av[j] = att_rows_sum(av[j]);
     }
     if (lane < 16) {
 #pragma unroll
@@ -298,6 +352,15 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
 
     if (nsp == 1) {  // short context: this workgroup is the whole head
         if (tid < ATT_HD) out[(size_t)h * ATT_HD + tid] = (half_t)(acc / l);
+        if (dbg && lane == 0) {
+            st_[6] = stamp_cycles(__builtin_bit_cast(uint32_t, acc));
+            const u64_t te = stamp_realtime();
+            u64_t *d = dbg + ((size_t)h * 4 + wave) * 10;
+#pragma unroll
+            for (int i = 0; i < 7; i++) d[i] = st_[i];
+            d[8] = te;
+            d[7] = sx_[0] - st_[1]; d[9] = ((sx_[1] - st_[1]) << 32) | (uint32_t)(sx_[2] - st_[1]);
+        }
         return;
     }
     float *rec = ws + ((size_t)h * nsplit + s) * ATT_REC;
@@ -368,11 +431,11 @@ int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, cons
 }
 
 int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
-                             float base, float scale, const float *rope_table, hipStream_t s) {
+                             float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s) {
     const int nsplit = (t_max + ATT_TS - 1) / ATT_TS;
     const float inv_base = -2.0f * logf(base) / (float)ATT_HD;
     hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(heads, nsplit), dim3(256), 0, s, qkv, pos, kc, vc, out, ws, heads, t_max, inv_base,
-                       scale, (const float2 *)rope_table);
+                       scale, (const float2 *)rope_table, dbg);
     return (int)hipGetLastError();
 }
 

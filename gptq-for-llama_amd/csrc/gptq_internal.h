@@ -95,7 +95,7 @@ int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, cons
                        int t_max, float scale, hipStream_t s);
 size_t decode_attn_ws_bytes(int heads, int t_max);
 int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
-                             float base, float scale, const float *rope_table, hipStream_t s);
+                             float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s);
 int rope_table_launch(float *table, int t_max, int head_dim, float base, hipStream_t s);
 
 }  // namespace gptq

@@ -143,9 +143,34 @@ GPTQ_DEV int zero_of(const int32_t *zrow, int n) {
     }
 }
 
+// sum over the xor butterfly offsets from, 2 from, ... 32.  __shfl_xor lowers to ds_bpermute_b32 (an LDS round trip, ~120 cycles per
+// dependent step); the offsets inside a 16-lane row run as DPP row operations and 16 / 32 as gfx950 permlane swaps instead -- same
+// operand pairs, bit-identical sums.  (from = 2, 4, 8 keep the shuffle for the in-row steps: the mirror patterns only equal the
+// xor pairs when the finer steps ran first.)
+template <int CTRL>
+GPTQ_DEV float dpp_row_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 GPTQ_DEV float wave_sum_xor(float v, int from) {
+    if (from == 1) {
+        v += dpp_row_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+        v += dpp_row_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+        v += dpp_row_f32<0x141>(v);   // row_half_mirror
+        v += dpp_row_f32<0x140>(v);   // row_mirror
+    } else {
 #pragma unroll
-    for (int off = from; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+        for (int off = from; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+    }
+    if (from <= 16) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, v);
+        auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (uint32_t)a[0]) + __builtin_bit_cast(float, (uint32_t)a[1]);
+    }
+    if (from <= 32) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, v);
+        auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (uint32_t)b[0]) + __builtin_bit_cast(float, (uint32_t)b[1]);
+    }
     return v;
 }
 

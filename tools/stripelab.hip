@@ -610,7 +610,13 @@ struct WSet { uint32_t *R; uint32_t *tab; };
 static float time_graph(launch_fn fn, SP base, const std::vector<WSet> &sets, hipStream_t s, int reps) {
     hipGraph_t g; hipGraphExec_t ge;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
-    for (auto &w : sets) { SP p = base; p.R = w.R; p.tab = w.tab; fn(p, s); }
+    static const bool freshx = getenv("LAB_FRESHX") != nullptr;   // x rewritten by a producer launch before every kernel (as in a real decode chain)
+    int it = 0;
+    for (auto &w : sets) {
+        SP p = base; p.R = w.R; p.tab = w.tab;
+        if (freshx) hipLaunchKernelGGL(fill_x, dim3(64), dim3(256), 0, s, (half_t *)base.x, (size_t)base.K, 77u + (it++ % 2));
+        fn(p, s);
+    }
     CK(hipStreamEndCapture(s, &g));
     CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     CK(hipGraphLaunch(ge, s)); CK(hipStreamSynchronize(s));

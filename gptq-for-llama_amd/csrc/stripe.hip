@@ -14,6 +14,8 @@
 // the high one) so that ONE mask per field position yields a natural k pair against an fp16 magic whose ulp equals the field's
 // bit weight: 8-bit 0x00FF00FF|1024 on w and w>>8 (1 shift + 2 and_or per 4 weights); 2-bit five positions [1:0]..[9:8] with the
 // magics 1024, 256, 64, 16, 4 on w and three more on w>>6 (1 shift + 8 and_or per 16 weights).
+// 3 bits: 32 k per lane = a dwordx3 (768-byte wave loads); ten fields per word at half-word bits [2:0] .. [14:12] (magics 1024, 128, 16 on
+// w and 1024, 128 on w >> 9: 1 shift + 5 and_or per 10 weights), k 30 / k 31 assembled from the spare bits 15 / 31 of the three words.
 // MR = 4 (2 <= M <= 4 rows of x): the MFMA computes four rows anyway -- lane l supplies row l%4 of x as the A operand and reads
 // result row i -- so a small decode batch costs the same weight stream, unpack and MFMA count as M = 1.
 //
@@ -61,6 +63,35 @@ __global__ void __launch_bounds__(256) stripe_repack_kernel(const uint32_t *__re
     }
 }
 
+// 3-bit: a lane's 32 k = three words.  Word j holds k = 10 j .. 10 j + 9 as five 3-bit fields per half-word (even k low, odd k
+// high: pair p = bits [3p+2:3p] of both halves) and bit j of k 30 / k 31 in its spare bits 15 / 31.  Source: the reference's
+// 96-bit blocks (rows 3 b .. 3 b + 2 of qweight hold the 32 k of block b, fields straddling the word boundaries).
+__global__ void __launch_bounds__(256) stripe_repack3_kernel(const uint32_t *__restrict__ qw0, const uint32_t *__restrict__ qw1,
+                                                             uint32_t *__restrict__ R, int N, int nrb, int NS) {
+    const size_t total = (size_t)(N / 16) * nrb * NS * 64;   // one thread per (stripe, row block, set, lane): three output words
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(i & 63);
+        size_t b = i >> 6;
+        const int set = (int)(b % NS); b /= NS;
+        const int rb = (int)(b % nrb);
+        const int stripe = (int)(b / nrb);
+        const int blk = rb * 4 + (l >> 4), col = 16 * stripe + (l & 15);
+        const uint32_t *src = (set ? qw1 : qw0) + (size_t)blk * 3 * N + col;
+        const uint32_t c3[3] = {src[0], src[N], src[2 * (size_t)N]};
+        const uint32_t q30 = (uint32_t)field_of_block<3>(c3, 30), q31 = (uint32_t)field_of_block<3>(c3, 31);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            uint32_t o = (((q30 >> j) & 1u) << 15) | (((q31 >> j) & 1u) << 31);
+#pragma unroll
+            for (int pp = 0; pp < 5; pp++) {
+                o |= (uint32_t)field_of_block<3>(c3, 10 * j + 2 * pp) << (3 * pp);
+                o |= (uint32_t)field_of_block<3>(c3, 10 * j + 2 * pp + 1) << (16 + 3 * pp);
+            }
+            R[i * 3 + j] = o;
+        }
+    }
+}
+
 template <int BITS>
 __global__ void __launch_bounds__(256) stripe_table_kernel(const half_t *__restrict__ sc0, const int32_t *__restrict__ qz0,
                                                            const half_t *__restrict__ sc1, const int32_t *__restrict__ qz1,
@@ -84,13 +115,13 @@ __global__ void __launch_bounds__(256) stripe_table_kernel(const half_t *__restr
 
 // groupsize is the effective one (K for the reference's -1).  Returns log2(groupsize / (4 KPW)), -1 for one group, -2 if ineligible.
 int stripe_gq_shift(int K, int N, int bits, int groupsize) {
-    if ((bits != 2 && bits != 4 && bits != 8) || K <= 0 || N <= 0 || N % 16 != 0) return -2;
-    const int kpw = 32 / bits, blk = 16 * kpw;
+    if ((bits != 2 && bits != 3 && bits != 4 && bits != 8) || K <= 0 || N <= 0 || N % 16 != 0) return -2;
+    const int lk = stripe_lk(bits), blk = 4 * lk;
     if (K % blk != 0) return -2;
     if ((K / blk + STRIPE_NW - 1) / STRIPE_NW > stripe_max_nu(bits)) return -2;
     if (groupsize >= K) return -1;
-    if (groupsize < 4 * kpw || groupsize % (4 * kpw) != 0 || K % groupsize != 0) return -2;
-    const int q = groupsize / (4 * kpw);
+    if (groupsize < lk || groupsize % lk != 0 || K % groupsize != 0) return -2;
+    const int q = groupsize / lk;
     for (int sft = 0; sft < 16; sft++)
         if ((1 << sft) == q) return sft;
     return -2;
@@ -110,8 +141,10 @@ int stripe_repack_launch(const uint32_t *qw0, const half_t *sc0, const int32_t *
     const int G = groupsize >= K ? 1 : K / groupsize;
     uint32_t *R = (uint32_t *)out;
     uint32_t *tab = (uint32_t *)((char *)out + stripe_tab_offset(K, N, bits, NS));
-    hipLaunchKernelGGL(stripe_repack_kernel, dim3(2048), dim3(256), 0, s, qw0, qw1, R, N, K / (16 * (32 / bits)), NS, bits);
-    if (bits == 2) hipLaunchKernelGGL(stripe_table_kernel<2>, dim3(512), dim3(256), 0, s, sc0, qz0, sc1, qz1, tab, N, G, NS);
+    if (bits == 3) hipLaunchKernelGGL(stripe_repack3_kernel, dim3(2048), dim3(256), 0, s, qw0, qw1, R, N, K / 128, NS);
+    else hipLaunchKernelGGL(stripe_repack_kernel, dim3(2048), dim3(256), 0, s, qw0, qw1, R, N, K / (16 * (32 / bits)), NS, bits);
+    if (bits == 3) hipLaunchKernelGGL(stripe_table_kernel<3>, dim3(512), dim3(256), 0, s, sc0, qz0, sc1, qz1, tab, N, G, NS);
+    else if (bits == 2) hipLaunchKernelGGL(stripe_table_kernel<2>, dim3(512), dim3(256), 0, s, sc0, qz0, sc1, qz1, tab, N, G, NS);
     else if (bits == 4) hipLaunchKernelGGL(stripe_table_kernel<4>, dim3(512), dim3(256), 0, s, sc0, qz0, sc1, qz1, tab, N, G, NS);
     else hipLaunchKernelGGL(stripe_table_kernel<8>, dim3(512), dim3(256), 0, s, sc0, qz0, sc1, qz1, tab, N, G, NS);
     return (int)hipGetLastError();
@@ -120,6 +153,7 @@ int stripe_repack_launch(const uint32_t *qw0, const half_t *sc0, const int32_t *
 int stripe_gemv_dispatch(const StripeParams &p, hipStream_t s) {
     switch (p.bits) {
         case 2: return stripe_gemv_dispatch_b2(p, s);
+        case 3: return stripe_gemv_dispatch_b3(p, s);
         case 4: return stripe_gemv_dispatch_b4(p, s);
         case 8: return stripe_gemv_dispatch_b8(p, s);
     }

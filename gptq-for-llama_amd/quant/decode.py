@@ -200,7 +200,7 @@ class DecodeEngine:
             g, u = L['gate'], L['up']
             g['pair_sorted'] = (g['srt'] is not None and u['srt'] is not None and bool(torch.equal(g['srt'][1], u['srt'][1])))
             g['st2'] = None     # gate and up in ONE stripe16 image (silu(gate) * up in the kernel epilogue)
-            if g['bits'] in (2, 4, 8) and ((g['gi'] is None and u['gi'] is None) or g['pair_sorted']):
+            if g['bits'] in (2, 3, 4, 8) and ((g['gi'] is None and u['gi'] is None) or g['pair_sorted']):
                 a, b = (g['srt'][0], u['srt'][0]) if g['pair_sorted'] else (g['qw'], u['qw'])
                 g['st2'] = quant_linear.stripe_copy(a, g['sc'], g['qz'], g['bits'], g['gs'], up=(b, u['sc'], u['qz']))
         H, I = self.hidden, cfg.intermediate_size

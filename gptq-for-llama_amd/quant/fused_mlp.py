@@ -41,7 +41,7 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
     for (qw, sc, qz, gi) in (gate, up):
         gis.append(None if (gi is None or g_idx_is_trivial(gi, K, groupsize)) else _int32c(gi[:K]))
     stripe_rows = 8      # M <= 8: the stripe kernel wins while M rows of x fit in LDS; wider batches -> weight-streaming MFMA kernel
-    if family is None and 1 <= M <= (stripe_rows if (N <= 4608 or bits == 2) else 4) and bits in (2, 4, 8) and all(gi is None for gi in gis):
+    if family is None and 1 <= M <= (stripe_rows if (N <= 4608 or bits in (2, 3)) else 4) and bits in (2, 3, 4, 8) and all(gi is None for gi in gis):
         # decode (and batches of up to 4 rows): gate and up packed into ONE stripe16 image, silu(gate) * up in the kernel epilogue
         from .quant_linear import stripe_copy, stripe_matvec
         st = stripe_copy(_int32c(gate[0]), gate[1], _int32c(gate[2]), bits, groupsize, up=(_int32c(up[0]), up[1], _int32c(up[2])))

@@ -119,8 +119,9 @@ STRIPE = _os.environ.get('GPTQ_STRIPE', '1') != '0'
 def stripe_copy(qweight, scales, qzeros, bits, groupsize, up=None):
     """uint8 tensor holding the stripe16 image of (qweight, scales, qzeros) -- or of the pair with
     ``up = (qweight, scales, qzeros)`` for the fused gate/up matvec -- or None when the shape is not served
-    (3-bit, K not a multiple of 16 * 32 / bits, group size not a power-of-two multiple of 4 * 32 / bits ...)."""
-    if not STRIPE or bits not in (2, 4, 8) or not qweight.is_cuda:
+    (K not a multiple of the row block -- 256 / 128 / 128 / 64 k for 2 / 3 / 4 / 8 bits --, group size not a power-of-two multiple of a
+    quarter of it ...)."""
+    if not STRIPE or bits not in (2, 3, 4, 8) or not qweight.is_cuda:
         return None
     K, N = qweight.shape[0] * 32 // bits, qweight.shape[1]
     lib = _native.lib()
@@ -286,7 +287,7 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
         # 5..64 rows otherwise = 16-row MFMA tiles (stripe_mm.inc); profiles/r2c_mm has the three measured side by side.
         # family='stripe' pins the decode kernel (row groups up to 16 rows), 'stripe_mm' the MFMA-tile kernel.
         # (row groups only while ONE round of workgroups covers N: 5.1 vs 5.7 us at 4096^2, but 12.6 vs 11.9 at N = 12288)
-        stripe_m = M == 1 or (gi is None and M <= (STRIPE_MAX_M if family == 'stripe' else (8 if (N <= 4608 or bits == 2) else 4)))
+        stripe_m = M == 1 or (gi is None and M <= (STRIPE_MAX_M if family == 'stripe' else (8 if (N <= 4608 or bits in (2, 3)) else 4)))
         if family in (None, 'stripe') and stripe_m and (gi is None or srt is not None):
             # decode: no-split-K kernel on the stripe16 copy (of the group-sorted rows for an act-order layer)
             st = stripe_copy(srt[0] if srt is not None else qweight, scales, qzeros, bits, groupsize)

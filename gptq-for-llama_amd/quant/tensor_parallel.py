@@ -100,7 +100,7 @@ def _default_partial(x2, s):
     (gptq_stripe_matvec_partial_f32); other shapes go through the fp16 kernels (one extra rounding per shard)."""
     from . import _native
     from .quant_linear import _as_rows, _int32c, act_order_sorted, stripe_copy
-    if x2.shape[0] == 1 and s.bits in (2, 4, 8) and x2.is_cuda:
+    if x2.shape[0] == 1 and s.bits in (2, 3, 4, 8) and x2.is_cuda:
         K, N = s.qweight.shape[0] * 32 // s.bits, s.qweight.shape[1]
         gs = s.groupsize if s.groupsize != -1 else K
         qw, perm = _int32c(s.qweight), None

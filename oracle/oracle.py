@@ -315,6 +315,8 @@ def stripe16_repack(sets, groupsize, bits=4):
     (reference quant_linear.py:316-321) -> uint8 image: R uint32 [N/16][K/(16 KPW)][NS][64][4] followed by
     tab half2 [N/16][NS][G][16] {scale, zero + 1}; KPW = 32 / bits."""
     NS = len(sets)
+    if bits == 3:
+        return _stripe16_repack3(sets, groupsize)
     kpw = 32 // bits
     qw0 = np.asarray(sets[0][0]).astype(np.int32).view(np.uint32)
     rows, N = qw0.shape
@@ -338,6 +340,56 @@ def stripe16_repack(sets, groupsize, bits=4):
         e = sc16.view(np.uint16).astype(np.uint32) | (z.view(np.uint16).astype(np.uint32) << np.uint32(16))   # half2 {s, z+1}
         tab[:, si] = e.reshape(G, S, 16).transpose(1, 0, 2)
     return np.concatenate([R.reshape(-1).view(np.uint8), tab.reshape(-1).view(np.uint8)])
+
+
+def _stripe16_repack3(sets, groupsize):
+    """3-bit image (csrc/stripe.hip stripe_repack3_kernel): R uint32 [N/16][K/128][NS][64 lanes][3]; a lane's 32 k = three words, word j =
+    k 10j .. 10j+9 as five 3-bit fields per half-word (pair p = bits [3p+2:3p] of the low / high half: k 10j+2p / 10j+2p+1) and bit j of
+    k 30 / k 31 in its spare bits 15 / 31; the table as for the other widths."""
+    NS = len(sets)
+    q0 = np_unpack_rows(sets[0][0], 3)
+    K, N = q0.shape
+    assert K % 128 == 0 and N % 16 == 0
+    nrb, S = K // 128, N // 16
+    gs = K if groupsize in (-1, None) or groupsize >= K else groupsize
+    G = K // gs
+    R = np.empty((S, nrb, NS, 64, 3), dtype=np.uint32)
+    tab = np.empty((S, NS, G, 16), dtype=np.uint32)
+    for si, (qw, sc, qz) in enumerate(sets):
+        q = np_unpack_rows(qw, 3).astype(np.uint32).reshape(nrb, 4, 32, S, 16)          # [rb][rq][k in block][s][c]
+        words = np.zeros((nrb, 4, 3, S, 16), dtype=np.uint32)
+        for j in range(3):
+            for p_ in range(5):
+                words[:, :, j] |= q[:, :, 10 * j + 2 * p_] << np.uint32(3 * p_)
+                words[:, :, j] |= q[:, :, 10 * j + 2 * p_ + 1] << np.uint32(16 + 3 * p_)
+            words[:, :, j] |= ((q[:, :, 30] >> np.uint32(j)) & np.uint32(1)) << np.uint32(15)
+            words[:, :, j] |= ((q[:, :, 31] >> np.uint32(j)) & np.uint32(1)) << np.uint32(31)
+        # [rb][rq][j][s][c] -> [s][rb][lane = rq*16 + c][j]
+        R[:, :, si] = words.transpose(3, 0, 1, 4, 2).reshape(S, nrb, 64, 3)
+        z = (np_unpack_cols(qz, 3) + 1).astype(np.float16)
+        sc16 = np.asarray(sc, dtype=np.float16)
+        e = sc16.view(np.uint16).astype(np.uint32) | (z.view(np.uint16).astype(np.uint32) << np.uint32(16))
+        tab[:, si] = e.reshape(G, S, 16).transpose(1, 0, 2)
+    return np.concatenate([R.reshape(-1).view(np.uint8), tab.reshape(-1).view(np.uint8)])
+
+
+def stripe16_unpack3_fields(image, K, N, NS):
+    """the integer fields [K, N] per set of a 3-bit image (inverse of the field placement above)."""
+    nrb, S = K // 128, N // 16
+    nR = S * nrb * NS * 64 * 3
+    R = np.asarray(image, dtype=np.uint8)[:nR * 4].view(np.uint32).reshape(S, nrb, NS, 64, 3)
+    out = []
+    for si in range(NS):
+        w = R[:, :, si].reshape(S, nrb, 4, 16, 3)                                          # [s][rb][rq][c][j]
+        q = np.zeros((S, nrb, 4, 16, 32), dtype=np.uint32)
+        for j in range(3):
+            for p_ in range(5):
+                q[..., 10 * j + 2 * p_] = (w[..., j] >> np.uint32(3 * p_)) & np.uint32(7)
+                q[..., 10 * j + 2 * p_ + 1] = (w[..., j] >> np.uint32(16 + 3 * p_)) & np.uint32(7)
+            q[..., 30] |= ((w[..., j] >> np.uint32(15)) & np.uint32(1)) << np.uint32(j)
+            q[..., 31] |= ((w[..., j] >> np.uint32(31)) & np.uint32(1)) << np.uint32(j)
+        out.append(q.transpose(1, 2, 4, 0, 3).reshape(K, N).astype(np.int32))                # [rb][rq][k][s][c] -> [K][N]
+    return out
 
 
 def stripe16_unpack(image, K, N, groupsize, NS, bits=4):

@@ -621,7 +621,8 @@ def _stripe_image(Ls, gs, bits=4):
 
 @pytest.mark.parametrize('bits,K,N,gs,NS', [(4, 4096, 4096, 128, 1), (4, 1024, 288, 64, 2), (4, 384, 64, 32, 1), (4, 512, 64, -1, 2),
                                             (4, 2176, 32, 128, 1), (4, 4096, 11008, 128, 2), (8, 4096, 512, 128, 1), (8, 1088, 96, 64, 2),
-                                            (8, 192, 32, 16, 1), (2, 4096, 512, 128, 1), (2, 1280, 64, 64, 2), (2, 512, 32, -1, 1)])
+                                            (8, 192, 32, 16, 1), (2, 4096, 512, 128, 1), (2, 1280, 64, 64, 2), (2, 512, 32, -1, 1),
+                                            (3, 4096, 512, -1, 1), (3, 1152, 96, 128, 2), (3, 384, 32, 32, 1)])
 def test_stripe_repack_bit_exact(bits, K, N, gs, NS):
     Ls = [make_random_layer(bits, gs, K, N, seed=K + N + i) for i in range(NS)]
     st, _ = _stripe_image(Ls, gs, bits)
@@ -633,7 +634,9 @@ def test_stripe_repack_bit_exact(bits, K, N, gs, NS):
 @pytest.mark.parametrize('M', [1, 3])
 @pytest.mark.parametrize('bits,K,N,gs', [(8, 4096, 4096, 128), (8, 11008, 256, 128), (8, 64, 32, 64), (8, 1088, 96, 16), (8, 2240, 64, 32),
                                          (8, 22016, 32, 128), (8, 512, 64, -1), (2, 4096, 4096, 128), (2, 11008, 256, 128), (2, 256, 32, 64),
-                                         (2, 2304, 96, 256), (2, 24576, 32, 128), (2, 1024, 64, -1)])
+                                         (2, 2304, 96, 256), (2, 24576, 32, 128), (2, 1024, 64, -1),
+                                         (3, 4096, 4096, -1), (3, 4096, 11008, -1), (3, 11008, 256, -1), (3, 4096, 512, 128), (3, 1152, 96, 32), (3, 2176, 64, 64),
+                                         (3, 24576, 32, 128), (3, 128, 32, -1)])
 def test_stripe_2bit_and_8bit_vs_oracle(bits, K, N, gs, M):
     """the reference's other widths (quant_linear.py:308) on the stripe16 kernel: every unpack position of a word, ragged
     row-block counts, group sizes from one lane block to all of K; M = 3 rides along for free"""
@@ -672,7 +675,7 @@ def test_stripe_small_batch_rows(K, N, gs, M, bias):
 
 
 @pytest.mark.parametrize('M', [5, 8, 9, 13, 16])
-@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 4096, 128), (4, 4096, 11008, 128), (4, 2176, 96, 64), (8, 2048, 288, 128), (2, 4096, 64, 128)])
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 4096, 128), (4, 4096, 11008, 128), (4, 2176, 96, 64), (8, 2048, 288, 128), (2, 4096, 64, 128), (3, 4096, 96, -1)])
 def test_stripe_row_groups_m5_to_16(bits, K, N, gs, M):
     """5 <= M <= 16: two / four MFMA row groups on the same unpacked words, M rows of x in LDS; every row against the oracle
     and bit-identical to the M = 1 launch of that row"""
@@ -744,7 +747,7 @@ def test_stripe_long_k_small_batch_falls_back():
     check_forward(x, L)
 
 
-@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 11008, 128), (8, 1024, 288, 64), (2, 1024, 96, 128)])
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 11008, 128), (8, 1024, 288, 64), (2, 1024, 96, 128), (3, 4096, 11008, 4096), (3, 1152, 96, 128)])
 @pytest.mark.parametrize('M', [2, 4, 7, 8])
 def test_stripe_fused_mlp_small_batch(bits, K, N, gs, M):
     A, B = make_random_layer(bits, gs, K, N, seed=71), make_random_layer(bits, gs, K, N, seed=72)

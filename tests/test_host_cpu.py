@@ -207,6 +207,24 @@ def test_stripe16_layout_restatement_is_a_bijection():
             assert np.array_equal(qw, L['qweight'])
             assert np.array_equal(sc.view(np.uint16), L['scales'].view(np.uint16))
             assert np.array_equal(z, oracle.np_unpack_cols(L['qzeros'], bits) + 1)
+    # 3 bits: the fields of a random layer survive the three-words-per-32-k placement (ten fields per word + the spare bits 15 / 31)
+    for K, N, gs, NS in [(128, 32, 128, 1), (512, 96, -1, 2), (1024, 32, 64, 1)]:
+        Ls = [make_random_layer(3, gs, K, N, seed=3 * K + N + i) for i in range(NS)]
+        img = oracle.stripe16_repack([(L['qweight'], L['scales'], L['qzeros']) for L in Ls], gs, 3)
+        assert img.nbytes == _native.lib().gptq_stripe_bytes(K, N, 3, K if gs == -1 else gs, NS)
+        for L, q in zip(Ls, oracle.stripe16_unpack3_fields(img, K, N, NS)):
+            assert np.array_equal(q, oracle.np_unpack_rows(L['qweight'], 3))
+    # ... and one hand-built block: field k holds k % 8 -> word 0 = k 0..9 (even k low half, odd k high half), bit 0 of k 30 / k 31 in bits 15 / 31
+    f = np.arange(32, dtype=np.uint64) % 8
+    stream = sum(int(v) << (3 * i) for i, v in enumerate(f))
+    qw = np.zeros((12, 32), dtype=np.int32)              # 128 k x 32 columns, only column 0 / block 0 populated
+    for j in range(3):
+        qw[j, 0] = np.uint32((stream >> (32 * j)) & 0xFFFFFFFF).astype(np.int32)
+    img = oracle.stripe16_repack([(qw, np.ones((1, 32), np.float16), np.zeros((1, 3), np.int32))], 128, 3)
+    w0 = int(img[:4].view(np.uint32)[0])
+    low = sum((2 * p % 8) << (3 * p) for p in range(5)) | ((30 % 8 & 1) << 15)
+    high = sum(((2 * p + 1) % 8) << (3 * p) for p in range(5)) | ((31 % 8 & 1) << 15)
+    assert w0 == (low | (high << 16)) == 0x9F590D10, hex(w0)     # low half 0,2,4,6,0 = 0x0D10; high half 1,3,5,7,1 + spare bit = 0x9F59
     # one hand-checked word per width: field k holds the value k -> even k in the low half-word, odd k in the high one
     for bits, word, want in [(4, 0x76543210, 0x75316420), (8, 0x03020100, 0x03010200), (2, 0xE4E4E4E4, 0xDDDD8888)]:
         qw = np.zeros((16, 16), dtype=np.int32)
@@ -223,7 +241,8 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert lib.gptq_stripe_bytes(4096, 11008, 4, 128, 2) == 2 * (4096 // 8 * 11008 * 4 + 32 * 11008 * 4)
     assert lib.gptq_stripe_bytes(4096, 4096, 8, 128, 1) == 4096 // 4 * 4096 * 4 + 32 * 4096 * 4
     assert lib.gptq_stripe_bytes(4096, 4096, 2, 128, 1) == 4096 // 16 * 4096 * 4 + 32 * 4096 * 4
-    assert lib.gptq_stripe_bytes(4096, 4096, 3, 128, 1) == 0          # no 3-bit stripes
+    assert lib.gptq_stripe_bytes(4096, 4096, 3, 128, 1) == 4096 // 32 * 3 * 4096 * 4 + 32 * 4096 * 4   # three words per 32 k
+    assert lib.gptq_stripe_bytes(4096, 4096, 3, 4096, 1) > 0 and lib.gptq_stripe_bytes(4096 + 64, 4096, 3, 128, 1) == 0
     assert lib.gptq_stripe_bytes(4096 + 64, 4096, 4, 128, 1) == 0     # K % 128 (4-bit row block)
     assert lib.gptq_stripe_bytes(4096 + 64, 4096, 8, 64, 1) > 0       # ... but a whole number of 8-bit row blocks (64 k)
     assert lib.gptq_stripe_bytes(4096, 4096, 4, 96, 1) == 0           # group not a power-of-two multiple of 32
@@ -235,13 +254,12 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb, 256, 64, 5, 128, None) == -1
     assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb - 1, 256, 64, 4, 128, None) == -5
     assert lib.gptq_stripe_repack(None, one, one, None, None, None, one, nb, 256, 64, 4, 128, None) == -4
-    assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb, 256, 64, 3, 128, None) == -6
+    assert lib.gptq_stripe_repack(one, one, one, None, None, None, one, nb, 256, 64, 3, 96, None) == -6            # 3-bit groups: multiples of 32
 
     def mv(x=one, st=one, nbytes=nb, y=one, M=1, bits=4, nsets=1, norm=None, ldx=256, ldy=64):
         return lib.gptq_stripe_matvec_f16(x, ldx, st, nbytes, None, y, ldy, M, 256, 64, bits, 128, nsets, norm, 0.0, None, None)
     assert mv(nsets=3) == -2
     assert mv(nbytes=nb - 1) == -5
-    assert mv(bits=3) == -6
     assert mv(M=17) == -6                                             # at most sixteen rows per launch (gptq_stripe_matmul_f16 serves up to 64)
     assert mv(M=2, norm=one) == -6                                     # fused RMSNorm is an M == 1 feature
     assert mv(M=2, ldx=252) == -3

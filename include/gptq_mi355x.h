@@ -255,9 +255,10 @@ int gptq_decode_attn_fused_table_f16(const void *qkv, const int64_t *position, v
  *   R   uint32 [N/16][K/128][nsets][64][4]  (4-bit) every workgroup's 16 columns contiguous, 1 KiB per wave load, fields
  *                                            re-ordered for a one-shift unpack (see csrc/stripe.hip)
  *   tab half2  [N/16][nsets][G][16]          {scale, zero + 1} per (group, column)
- * stored back to back in ONE buffer of gptq_stripe_bytes() bytes (0 = shape not eligible: bits in {2, 4, 8}; K a multiple of
- * 16 * (32 / bits) = 256 / 128 / 64 and at most 24576 / 24576 / 22528; groupsize a power-of-two multiple of 4 * (32 / bits)
- * that divides K, or >= K).  For 8 and 2 bits the same geometry holds with 32 / bits k per word; see csrc/stripe.hip.  The
+ * stored back to back in ONE buffer of gptq_stripe_bytes() bytes (0 = shape not eligible: bits in {2, 3, 4, 8}; K a multiple of
+ * the row block = 256 / 128 / 128 / 64 k and at most 24576 / 24576 / 24576 / 22528; groupsize a power-of-two multiple of a quarter
+ * of the row block that divides K, or >= K).  For 8 and 2 bits the same geometry holds with 32 / bits k per word, for 3 bits a lane
+ * holds its 32 k in three words ([N/16][K/128][nsets][64][3]); see csrc/stripe.hip.  The
  * checkpoint buffers are not modified and stay the owner of the state_dict.  nsets == 2 packs gate and up together and the
 * matvec returns silu(x Wg) * (x Wu).  1 <= M <= 4 rows of x (row strides ldx / ldy) cost the same weight stream as one: the
  * MFMA computes four rows anyway; 5 <= M <= 8 / 16 run two / four MFMA row groups on the same unpacked words while M rows of x

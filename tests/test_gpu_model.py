@@ -265,6 +265,19 @@ def test_decode_engine_matches_hf_decoder(graph, fuse):
     assert r['tokens_per_s'] > 0
 
 
+@pytest.mark.parametrize('bits,gs', [(3, 128), (8, 64), (2, 64)])
+def test_decode_engine_other_widths(bits, gs):
+    """the hipGraph decode step on 3- / 8- / 2-bit checkpoints: every linear on its stripe16 image (fused RMSNorm, fused gate/up,
+    residual epilogue), logits against the HF decoder running the same drop-in modules"""
+    q = D.build_random_llama(DEV, bits=bits, groupsize=gs, seed=5 + bits, **HD128)
+    ids = torch.randint(0, HD128['vocab_size'], (1, 8), device=DEV, generator=torch.Generator(device=DEV).manual_seed(bits))
+    expect = run_steps(q, ids, 1)
+    eng = D.DecodeEngine(q, t_max=64).capture()
+    assert all(L['qkv']['st'] is not None and L['gate'].get('st2') is not None for L in eng.layers)     # stripe images, not the rowwave fallback
+    got = np.stack([eng.decode(ids[0, i]).float().cpu().numpy()[0] for i in range(ids.shape[1])])[:, None, :]
+    within('engine_vs_hf_w%d' % bits, np.abs(got - expect).max() / np.abs(expect).max(), ENGINE_TOL)
+
+
 def test_engine_generate_continues_the_hf_prefill():
     """prompt through the HF model (prefill kernels), KV cache copied into the engine, then one hipGraph replay per
     token: the engine's logits at every generated position match an HF decoder that is fed the same tokens."""

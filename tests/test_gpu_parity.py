@@ -707,6 +707,21 @@ def test_stripe_mm_vs_oracle(bits, K, N, gs, M):
         assert rel_err(yp, y[perm]) < TOL
 
 
+@pytest.mark.parametrize('M', [6, 33, 70])
+def test_stripe_mm_strided_rows(M):
+    """x as a column slice of a wider buffer (row stride K + 64, the way a fused qkv / hidden-state view arrives): same bits as
+    the contiguous copy, on every schedule the dispatch picks for these M (row groups / one launch / K slices / two passes)"""
+    K, N = 2048, 384
+    L = make_random_layer(4, 128, K, N, seed=M)
+    xs = np.random.default_rng(M).standard_normal((M, K + 64)).astype(np.float16)
+    b = np.random.default_rng(2).standard_normal(N).astype(np.float16)
+    args = (dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15)
+    y_view = QL.matmul248(dev(xs)[:, :K], *args, bias=dev(b)).cpu().numpy()
+    y_copy = QL.matmul248(dev(np.ascontiguousarray(xs[:, :K])), *args, bias=dev(b)).cpu().numpy()
+    assert np.array_equal(y_view.view(np.uint16), y_copy.view(np.uint16))
+    assert rel_err(y_view, oracle_forward(np.ascontiguousarray(xs[:, :K]), L, b)) < 2 * TOL
+
+
 @pytest.mark.parametrize('slices', [0, 4, 7, 16])
 @pytest.mark.parametrize('M', [16, 64])
 def test_stripe_mm_forced_variants(M, slices):

@@ -129,19 +129,26 @@ __global__ void __launch_bounds__(NW * 64) k_stripe16(const SP p) {
             xv[i] = *(const u32x4 *)(p.x + (size_t)idx * 8);
         }
         const uint32_t *tsrc = p.tab + (size_t)stripe * NS * G * 16;
+        if constexpr (MATH != 3) {
 #pragma unroll
-        for (int i = 0; i < TP; i++) {
-            const int idx = min(tid + i * T, NS * G * 4 - 1);
-            tv[i] = *(const u32x4 *)(tsrc + (size_t)idx * 4);
+            for (int i = 0; i < TP; i++) {
+                const int idx = min(tid + i * T, NS * G * 4 - 1);
+                tv[i] = *(const u32x4 *)(tsrc + (size_t)idx * 4);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     u32x4 w[NU][NS];
+    uint32_t twg[NU][NS];
     const uint32_t *wbase = p.R + ((size_t)stripe * nrb * NS * 64 + lane) * 4;
+    const uint32_t *tbaseg = p.tab + (size_t)stripe * NS * G * 16 + (lane & 15);
     auto issue = [&](int u) {
         const int rb = min(wave + NW * u, nrb - 1);   // ragged tail: re-read the last block (dropped below)
 #pragma unroll
-        for (int s = 0; s < NS; s++) w[u][s] = __builtin_nontemporal_load((const u32x4 *)(wbase + ((size_t)rb * NS + s) * 256));
+        for (int s = 0; s < NS; s++) {
+            w[u][s] = __builtin_nontemporal_load((const u32x4 *)(wbase + ((size_t)rb * NS + s) * 256));
+            if constexpr (MATH == 3) twg[u][s] = tbaseg[((size_t)s * G + rb) * 16];
+        }
     };
 #pragma unroll
     for (int u = 0; u < (DU < NU ? DU : NU); u++) issue(u);
@@ -172,7 +179,7 @@ __global__ void __launch_bounds__(NW * 64) k_stripe16(const SP p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < TP; i++) {
+        for (int i = 0; i < (MATH == 3 ? 0 : TP); i++) {
             const int idx = tid + i * T;
             if (idx < NS * G * 4) {
                 float4_t a, b;
@@ -242,8 +249,15 @@ __global__ void __launch_bounds__(NW * 64) k_stripe16(const SP p) {
                         }
                     }
                 }
-                if constexpr (MATH == 2) acc = accv[0];
-                float2 e = tabf[((size_t)s * G + rb) * 16 + col];
+                if constexpr (MATH >= 2) acc = accv[0];
+                float2 e;
+                if constexpr (MATH == 3) {
+                    const half2_t eh = as_half2(twg[u][s]);
+                    e.x = (float)eh[0];
+                    e.y = -((float)eh[1] - 64.f) * e.x;
+                } else {
+                    e = tabf[((size_t)s * G + rb) * 16 + col];
+                }
                 if (!valid) e = float2{0.f, 0.f};
                 y[s] = fmaf(e.x, acc - xs.x, y[s]);
                 y[s] = fmaf(e.y, xs.y, y[s]);
@@ -707,6 +721,7 @@ static void run_config(const char *name, SP base, const std::vector<WSet> &sets,
     }
     run_math<NU, NS, NW, DU, 0>(base, sets, c);
     run_math<NU, NS, NW, DU, 2>(base, sets, c);
+    run_math<NU, NS, NW, DU, 3>(base, sets, c);
     {
         const int N = base.N;
         SP p = base; p.R = sets[1 % sets.size()].R; p.tab = sets[1 % sets.size()].tab;
@@ -763,6 +778,7 @@ int main(int argc, char **argv) {
             run_config<4, 1, 8, 2>(sh.name, base, sets, c);
         } else if (K == 4096 && NS == 2) {
             run_config<4, 2, 8, 1>(sh.name, base, sets, c);
+            run_config<4, 2, 8, 2>(sh.name, base, sets, c);
         } else {
             run_config<11, 1, 8, 4>(sh.name, base, sets, c);
             run_config<11, 1, 8, 3>(sh.name, base, sets, c);

@@ -740,13 +740,17 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.bits = bits;
     if (mm_ws) {   // row tiles on the matrix core (stripe_mm.inc): passes of up to 64 rows, each streams the weights once
         const int forced = g_force_split_k.load();
-        if (bits != 4 && bits != 8) return GPTQ_E_VARIANT;
         for (int m0 = 0; m0 < M; m0 += 64) {
             p.x = (const half_t *)x + (size_t)m0 * ldx;
             p.y = (half_t *)y + (size_t)m0 * ldy;
             p.M = std::min(64, M - m0);
-            const int rc = bits == 4 ? stripe_mm_dispatch_b4(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream)
-                                     : stripe_mm_dispatch_b8(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
+            int rc;
+            switch (bits) {
+                case 2: rc = stripe_mm_dispatch_b2(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream); break;
+                case 3: rc = stripe_mm_dispatch_b3(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream); break;
+                case 4: rc = stripe_mm_dispatch_b4(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream); break;
+                default: rc = stripe_mm_dispatch_b8(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream); break;
+            }
             if (rc != 0) return rc;
         }
         return 0;

@@ -18,6 +18,8 @@ int stripe_gemv_dispatch_b3(const StripeParams &p, hipStream_t s);
 int stripe_gemv_dispatch_b4(const StripeParams &p, hipStream_t s);
 int stripe_gemv_dispatch_b8(const StripeParams &p, hipStream_t s);
 // small decode batches through v_mfma_f32_16x16x32_f16 (stripe_mm.inc): 1 <= M <= 64, GPTQ_E_VARIANT when not eligible
+int stripe_mm_dispatch_b2(const StripeParams &p, void *ws, size_t ws_bytes, int forced_slices, hipStream_t s);
+int stripe_mm_dispatch_b3(const StripeParams &p, void *ws, size_t ws_bytes, int forced_slices, hipStream_t s);
 int stripe_mm_dispatch_b4(const StripeParams &p, void *ws, size_t ws_bytes, int forced_slices, hipStream_t s);
 int stripe_mm_dispatch_b8(const StripeParams &p, void *ws, size_t ws_bytes, int forced_slices, hipStream_t s);
 constexpr size_t STRIPE_MM_WS_BYTES = (size_t)64 << 20;   // counters + partial tiles of the largest supported launch

@@ -1,0 +1,3 @@
+// stripe16 small-batch MFMA kernel, 2-bit instantiations (stripe_mm.inc: K slices, prescale where the group is smaller than a row block)
+#define STRIPE_BITS 2
+#include "stripe_mm.inc"

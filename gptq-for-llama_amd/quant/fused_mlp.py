@@ -41,7 +41,7 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
     for (qw, sc, qz, gi) in (gate, up):
         gis.append(None if (gi is None or g_idx_is_trivial(gi, K, groupsize)) else _int32c(gi[:K]))
     stripe_rows = 8      # M <= 8: the stripe kernel wins while M rows of x fit in LDS; wider batches -> weight-streaming MFMA kernel
-    if family is None and 1 <= M <= (stripe_rows if (N <= 4608 or bits in (2, 3)) else 4) and bits in (2, 3, 4, 8) and all(gi is None for gi in gis):
+    if family is None and 1 <= M <= (stripe_rows if N <= 4608 else 4) and bits in (2, 3, 4, 8) and all(gi is None for gi in gis):
         # decode (and batches of up to 4 rows): gate and up packed into ONE stripe16 image, silu(gate) * up in the kernel epilogue
         from .quant_linear import stripe_copy, stripe_matvec
         st = stripe_copy(_int32c(gate[0]), gate[1], _int32c(gate[2]), bits, groupsize, up=(_int32c(up[0]), up[1], _int32c(up[2])))
@@ -50,7 +50,7 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
                 c = torch.empty((M, N), device=x.device, dtype=torch.float16)
                 if stripe_matvec(x2, st, c, K, N, bits, groupsize, nsets=2, strict=False):
                     return c
-    if family in (None, 'stripe_mm') and 4 < M <= 128 and bits in (4, 8) and all(gi is None for gi in gis):
+    if family in (None, 'stripe_mm') and 4 < M <= 128 and bits in (2, 3, 4, 8) and all(gi is None for gi in gis):
         # small batches: the pair image through 16-row MFMA tiles (csrc/stripe_mm.inc), SiLU pair in the (reduce) epilogue
         from .quant_linear import stripe_copy, stripe_matmul
         st = stripe_copy(_int32c(gate[0]), gate[1], _int32c(gate[2]), bits, groupsize, up=(_int32c(up[0]), up[1], _int32c(up[2])))

@@ -287,19 +287,19 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
         # 5..64 rows otherwise = 16-row MFMA tiles (stripe_mm.inc); profiles/r2c_mm has the three measured side by side.
         # family='stripe' pins the decode kernel (row groups up to 16 rows), 'stripe_mm' the MFMA-tile kernel.
         # (row groups only while ONE round of workgroups covers N: 5.1 vs 5.7 us at 4096^2, but 12.6 vs 11.9 at N = 12288)
-        stripe_m = M == 1 or (gi is None and M <= (STRIPE_MAX_M if family == 'stripe' else (8 if (N <= 4608 or bits in (2, 3)) else 4)))
+        stripe_m = M == 1 or (gi is None and M <= (STRIPE_MAX_M if family == 'stripe' else (8 if N <= 4608 else 4)))
         if family in (None, 'stripe') and stripe_m and (gi is None or srt is not None):
             # decode: no-split-K kernel on the stripe16 copy (of the group-sorted rows for an act-order layer)
             st = stripe_copy(srt[0] if srt is not None else qweight, scales, qzeros, bits, groupsize)
             if st is not None and stripe_matvec(x, st, out, K, N, bits, groupsize, bias=bias, perm=srt[1] if srt is not None else None,
                                                 strict=family == 'stripe'):
                 return out
-        if family in (None, 'stripe_mm') and gi is None and bits in (4, 8) and (4 < M or family == 'stripe_mm') and M <= (256 if family == 'stripe_mm' else STRIPE_MM_MAX_M):
+        if family in (None, 'stripe_mm') and gi is None and bits in (2, 3, 4, 8) and (4 < M or family == 'stripe_mm') and M <= (256 if family == 'stripe_mm' else STRIPE_MM_MAX_M):
             st = stripe_copy(qweight, scales, qzeros, bits, groupsize)
             if st is not None and stripe_matmul(x, st, out, K, N, bits, groupsize, bias=bias, strict=False):
                 return out
         if family == 'stripe_mm':
-            raise RuntimeError('matmul248: the stripe16 MFMA kernel does not serve this shape (M <= 256, bits 4 / 8, group >= one row block)')
+            raise RuntimeError('matmul248: the stripe16 MFMA kernel does not serve this shape (M <= 256, a stripe16 image of the layer)')
         if family is None and _mid_m(M, N):
             W = dequantize(qweight, scales, qzeros, gi, bits, groupsize)
             torch.matmul(x, W, out=out)

@@ -689,7 +689,10 @@ def test_stripe_row_groups_m5_to_16(bits, K, N, gs, M):
 
 @pytest.mark.parametrize('M', [5, 16, 17, 33, 48, 64, 65, 100, 128])
 @pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 4096, 128), (4, 4096, 11008, 128), (4, 11008, 4096, 128), (4, 1152, 288, 128), (4, 2048, 96, -1),
-                                         (4, 3072, 64, 256), (8, 2048, 288, 64), (8, 4096, 4096, 128), (8, 1088, 96, -1)])
+                                         (4, 3072, 64, 256), (8, 2048, 288, 64), (8, 4096, 4096, 128), (8, 1088, 96, -1),
+                                         # prescale kernels (group smaller than a row block) and the other widths
+                                         (4, 2048, 96, 32), (4, 4096, 512, 64), (8, 1088, 96, 16), (8, 2048, 160, 32), (2, 4096, 512, 128), (2, 1024, 96, -1),
+                                         (2, 2304, 64, 64), (3, 4096, 512, -1), (3, 1152, 96, 32), (3, 4096, 11008, 128)])
 def test_stripe_mm_vs_oracle(bits, K, N, gs, M):
     """5 <= M <= 64 on the stripe16 image through 16-row MFMA tiles (gptq_stripe_matmul_f16): one launch (x streamed through LDS)
     or K slices + the reduce kernel, ragged row-block counts, column groups that are not full (N % 128), one group; against the
@@ -738,7 +741,8 @@ def test_stripe_mm_forced_variants(M, slices):
     assert rel_err(y, oracle_forward(x, L, b)) < 2 * TOL
 
 
-@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 11008, 128), (8, 1024, 288, 64), (4, 11008 // 2, 256, 128)])
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 11008, 128), (8, 1024, 288, 64), (4, 11008 // 2, 256, 128), (2, 1024, 96, 128), (3, 1152, 96, 128),
+                                         (4, 1024, 160, 32)])
 @pytest.mark.parametrize('M', [9, 16, 40, 64, 100])
 def test_stripe_mm_fused_mlp(bits, K, N, gs, M):
     A, B = make_random_layer(bits, gs, K, N, seed=81), make_random_layer(bits, gs, K, N, seed=82)

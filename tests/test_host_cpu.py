@@ -273,7 +273,7 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert lib.gptq_query(5) == 64 << 20
     assert mm(ws=None) == -4 and mm(y=None) == -4 and mm(x=None) == -4
     assert mm(ws=260) == -3 and mm(ldx=252) == -3
-    assert mm(M=257) == -6 and mm(bits=3) == -6
+    assert mm(M=257) == -6 and mm(bits=5) == -1
     assert mm(nbytes=nb - 1) == -5
     assert mm(M=0) == 0
 

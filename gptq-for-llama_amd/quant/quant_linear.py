@@ -226,7 +226,15 @@ def _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, 
         if rc != -6:
             _native.check(rc, 'gptq_matmul248_sorted_f16')
             return
-    xp = x.index_select(1, perm.to(torch.int64))
+    xp = x.index_select(1, perm)
+    if family is None and M <= STRIPE_MM_MAX_M:
+        # batches of an act-order layer: one gather of x, then the stripe16 kernels on the image of the group-sorted rows
+        st = stripe_copy(qs, scales, qzeros, bits, groupsize)
+        if st is not None:
+            if M <= (8 if N <= 4608 else 4) and stripe_matvec(xp, st, out, K, N, bits, groupsize, bias=bias, strict=False):
+                return
+            if stripe_matmul(xp, st, out, K, N, bits, groupsize, bias=bias, strict=False):
+                return
     rc = getattr(lib, _FAMILIES[family])(xp.data_ptr(), K, qs.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), None, _native.ptr(bias),
                                          out.data_ptr(), N, M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
                                          _native.stream_ptr(x.device))
@@ -282,7 +290,7 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
         if M == 0:
             return out
         ws = _native.workspace(x.device)
-        srt = act_order_sorted(qweight, gi, K, groupsize, bits) if (gi is not None and not (family is None and _mid_m(M, N))) else None
+        srt = act_order_sorted(qweight, gi, K, groupsize, bits) if (gi is not None and not (family is None and _mid_m(M, N) and M > STRIPE_MM_MAX_M)) else None
         # stripe16 image: M <= 4 rows share the decode launch for free; 5..8 rows = two 4x4x4 row groups while x fits in LDS;
         # 5..64 rows otherwise = 16-row MFMA tiles (stripe_mm.inc); profiles/r2c_mm has the three measured side by side.
         # family='stripe' pins the decode kernel (row groups up to 16 rows), 'stripe_mm' the MFMA-tile kernel.
@@ -300,6 +308,9 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
                 return out
         if family == 'stripe_mm':
             raise RuntimeError('matmul248: the stripe16 MFMA kernel does not serve this shape (M <= 256, a stripe16 image of the layer)')
+        if family is None and srt is not None and 1 < M <= STRIPE_MM_MAX_M:
+            _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family)     # gather + stripe kernels (or the C-ABI ones)
+            return out
         if family is None and _mid_m(M, N):
             W = dequantize(qweight, scales, qzeros, gi, bits, groupsize)
             torch.matmul(x, W, out=out)

@@ -290,6 +290,23 @@ def test_act_order_sorted_fast_path(bits, gs, M):
     assert rel_err(y, y_generic) < TOL
 
 
+@pytest.mark.parametrize('bits,gs,K,N', [(4, 128, 4096, 512), (4, 32, 1024, 160), (8, 64, 1024, 96), (2, 128, 1024, 64), (4, 128, 11008, 256)])
+@pytest.mark.parametrize('M', [2, 4, 7, 16, 50, 100])
+def test_act_order_batches_through_stripe_kernels(bits, gs, K, N, M):
+    """batches of an act-order layer: one gather x[:, perm], then the stripe16 decode / MFMA-tile kernels on the image of the
+    group-sorted rows -- against the oracle on the ORIGINAL checkpoint buffers, and run twice"""
+    L = make_random_layer(bits, gs, K, N, act_order=True, seed=bits + gs + M)
+    x = np.random.default_rng(M + 9).standard_normal((M, K)).astype(np.float16)
+    b = np.random.default_rng(4).standard_normal(N).astype(np.float16)
+    qw = dev(L['qweight'])
+    y = QL.matmul248(dev(x), qw, dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), bits, 2**bits - 1, bias=dev(b)).cpu().numpy()
+    srt = QL.act_order_sorted(qw, dev(L['g_idx']), K, gs, bits)
+    assert srt is not None and getattr(srt[0], '_gptq_stripe', None) is not None      # the sorted copy carries the image that served the call
+    assert rel_err(y, oracle_forward(x, L, b)) < 2 * TOL
+    y2 = QL.matmul248(dev(x), qw, dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), bits, 2**bits - 1, bias=dev(b)).cpu().numpy()
+    assert np.array_equal(y.view(np.uint16), y2.view(np.uint16))
+
+
 def test_act_order_irregular_groups_stay_generic():
     """a g_idx whose groups do not all have `groupsize` members cannot be sorted into the trivial
     layout: the generic kernel serves it."""

@@ -1,7 +1,8 @@
-// skinny_mfma.hip -- weight-streaming dequant-matmul for decode and small batches (M <= 64) on
-// gfx950: the primary kernel behind QuantLinear.forward at M = 1 (reference
-// quant/quant_linear.py:72-137) and behind the fused gate/up + SiLU*mul
-// (reference quant/fused_mlp.py:84-168).  Weights are read exactly once; HBM is the roofline.
+// skinny_mfma.hip -- weight-streaming dequant-matmul for small batches (M <= 64) on the CHECKPOINT layout (reference
+// quant/quant_linear.py:72-137, fused gate/up quant/fused_mlp.py:84-168).  Round 1's small-batch kernel; since round 2 the
+// stripe16 kernels (stripe_kernel.inc, stripe_mm.inc) serve every layer that has a stripe image, and this one keeps what they
+// do not take: K or group sizes the image does not cover, 3-bit act-order, family = 'abi' / 'skinny' runs.  Weights are read
+// exactly once; HBM is the roofline.
 //
 //  * a wave owns 64 columns; lane l (cl = l & 15, kg = l >> 4) loads ONE dwordx4 per unit =
 //    4 adjacent columns x the packed row of k-group kg: a wave instruction fetches 4 rows x 256

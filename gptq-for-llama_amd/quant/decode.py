@@ -509,5 +509,6 @@ def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fu
     return {'protocol': 'llama.py:385-438 (one token per step, KV cache, sync per step, median)',
             'mode': 'DecodeEngine, %s' % ('one hipGraph replay per token' if graph else 'eager launches'), 'tokens': tokens,
             't_max': t_max, 'start_pos': start_pos, 'fused_norm': fuse_norm, 'fused_attention': fuse_attn,
-            'launches_per_token': (10 - 2 * int(fuse_norm) - 2 * int(fuse_attn)) * len(eng.layers) + 4, 'median_s_per_token': round(med, 6),
+            # per layer: [norm,] qkv, [rope+append, attention partial, merge | one fused launch], o+residual, [norm,] gate/up, down+residual
+            'launches_per_token': (9 - 2 * int(fuse_norm) - 2 * int(fuse_attn)) * len(eng.layers) + 4, 'median_s_per_token': round(med, 6),
             'tokens_per_s': round(1.0 / med, 1)}

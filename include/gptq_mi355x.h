@@ -282,8 +282,9 @@ int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t st
 /* Small decode batches, 1 <= M <= 256 (passes of up to 64 rows, each streams the weights once), on the same image (csrc/stripe_mm.inc): 16-row MFMA tiles (v_mfma_f32_16x16x32_f16) on exactly
  * dequantised q - z, fp32 group scales; either one launch (a stripe x whole K per workgroup, x streamed through LDS) or K slices
  * (128 columns x one slice per workgroup) that meet through fp32 partial tiles in `workspace` and a reduce kernel (summed in
- * slice order: bit-reproducible; no atomics).  bits 4 / 8, group size a
- * multiple of 128 / 64 k or one group; GPTQ_E_VARIANT otherwise (callers fall back to gptq_matmul248_f16).  The workspace
+ * slice order: bit-reproducible; no atomics).  Every layer with a stripe image (bits 2 / 3 / 4 / 8): groups of at least a row block
+ * keep q - z exact and scale the fp32 accumulator; smaller groups multiply by the lane's fp16 scale before the MFMA (one rounding, the
+ * reference's own dequantisation, quant_linear.py:128); GPTQ_E_VARIANT when there is no image (callers fall back to gptq_matmul248_f16).  The workspace
  * (gptq_query(GPTQ_Q_STRIPE_MM_WORKSPACE_BYTES), 256-byte aligned) is pure scratch for the partial tiles: no initialisation, no state
  * between launches; do not share it between launches that may overlap, nor with the zero-invariant split-K workspace of the
  * rowwave kernels.  Reference semantics:

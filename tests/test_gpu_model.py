@@ -476,3 +476,62 @@ def test_engine_hook_keeps_the_callers_cache_consistent():
     got, len_h = run(True)
     assert len_e == 18 and len_h >= 17          # the last engine token may still be engine-only (it is synced on demand)
     assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE config 5 at the model level: tensor-parallel decode (quant/tp_decode.py), two ranks sharing the one GPU of the test box,
+# the exchanges through the one-shot all-reduce captured in each rank's hipGraph
+# ---------------------------------------------------------------------------------------
+def _tp_engine_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from quant.tp_decode import TPDecodeEngine
+        torch.cuda.set_device(0)
+        cfg = dict(HD128, num_attention_heads=4, num_key_value_heads=4, hidden_size=512, intermediate_size=1024)   # 2 heads per rank, uneven nothing
+        model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=21, **cfg)             # the same weights on every rank
+        ids = torch.randint(0, cfg['vocab_size'], (10,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+        full = D.DecodeEngine(model, t_max=64).capture()
+        expect = np.stack([full.decode(ids[i]).float().cpu().numpy()[0] for i in range(10)])
+        ok = True
+        for graph in (False, True):
+            eng = TPDecodeEngine(model, t_max=64)
+            if graph:
+                eng.capture()
+            got = np.stack([eng.decode(ids[i]).float().cpu().numpy()[0] for i in range(10)])
+            err = np.abs(got - expect).max() / np.abs(expect).max()
+            ok = ok and np.isfinite(got).all() and err < ENGINE_TOL and eng.status() == 0
+            # the replicated state stays replicated: every rank holds the same logits bit for bit
+            mine = torch.from_numpy(got.view(np.uint16).astype(np.int32))
+            both = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            ok = ok and all(torch.equal(both[0], b) for b in both)
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            ret.put(int(t.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tensor_parallel_decode_engine_two_ranks_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_tp_engine_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        if p.exitcode is None:
+            p.kill()
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == 1

@@ -517,7 +517,8 @@ def _tp_engine_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_tensor_parallel_decode_engine_two_ranks_one_gpu():
+@pytest.mark.parametrize('world', [2, 4])
+def test_tensor_parallel_decode_engine_two_ranks_one_gpu(world):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -526,7 +527,7 @@ def test_tensor_parallel_decode_engine_two_ranks_one_gpu():
     s.close()
     ctx = mp.get_context('spawn')
     ret = ctx.Queue()
-    procs = [ctx.Process(target=_tp_engine_worker, args=(r, 2, port, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_tp_engine_worker, args=(r, world, port, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -305,3 +305,26 @@ def test_byte_model_matches_survey_8d():
     assert oracle.algorithmic_bytes(1, 4096, 4096, 4, 128) == 8732672
     assert oracle.algorithmic_bytes(1, 4096, 4096, 4, 128, act_order=True) == 8732672 + 4 * 4096
     assert oracle.algorithmic_bytes(1, 4096, 4096, 3, 4096) == 6317568      # 3-bit, one group (config 4)
+
+
+def test_tp_decode_shard_slicing_is_exact_on_cpu():
+    """the column / row cuts quant/tp_decode.py feeds to stripe_copy (plain tensor slicing, no GPU): dequantising a shard gives the
+    matching slice of the dequantised layer -- uneven group counts over 8 ranks, 4- and 3-bit packing of qzeros along N"""
+    import torch
+    from quant import tp_decode, tensor_parallel as TP
+    for bits, gs, K, N in [(4, 128, 1408, 352), (3, 64, 1024, 256), (8, 32, 320, 96)]:
+        L = make_random_layer(bits, gs, K, N, seed=bits + K)
+        full = oracle.np_dequant(L['qweight'], L['qzeros'], L['scales'], L['g_idx'], bits)
+        qw, sc, qz = (torch.from_numpy(L[k]) for k in ('qweight', 'scales', 'qzeros'))
+        for world in (2, 8):
+            for (k0, k1) in TP.row_shard_bounds(K, gs, bits, world):
+                if k1 == k0:
+                    continue
+                a, b, c = tp_decode._rows(qw, sc, qz, bits, gs, k0, k1)
+                gi = (np.arange(k1 - k0) // gs).astype(np.int32)
+                assert np.array_equal(oracle.np_dequant(a.numpy(), c.numpy(), b.numpy(), gi, bits), full[k0:k1])
+            for (n0, n1) in TP.col_shard_bounds(N, world):
+                if n1 == n0:
+                    continue
+                a, b, c = (t.contiguous() for t in tp_decode._cols(qw, sc, qz, bits, n0, n1))
+                assert np.array_equal(oracle.np_dequant(a.numpy(), c.numpy(), b.numpy(), L['g_idx'], bits), full[:, n0:n1])

@@ -706,7 +706,7 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
 }
 
 static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, float *y32,
-                         int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm,
+                         int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
                          gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
@@ -759,7 +759,7 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
 }
 
 int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
-                           int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm,
+                           int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
                            gptq_stream_t stream) {
     if (!y) return GPTQ_E_NULL;
     return stripe_matvec(x, ldx, stripes, stripes_bytes, bias, y, ldy, nullptr, M, K, N, bits, groupsize, nsets, norm_weight, norm_eps, perm, stream);
@@ -774,7 +774,7 @@ int gptq_stripe_matmul_f16(const void *x, int64_t ldx, const void *stripes, size
 }
 
 int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t stripes_bytes, float *y_partial, int K, int N, int bits,
-                                   int groupsize, int nsets, const int32_t *perm, gptq_stream_t stream) {
+                                   int groupsize, int nsets, const uint16_t *perm, gptq_stream_t stream) {
     if (!y_partial) return GPTQ_E_NULL;
     return stripe_matvec(x, K, stripes, stripes_bytes, nullptr, nullptr, N, y_partial, 1, K, N, bits, groupsize, nsets, nullptr, 0.f, perm, stream);
 }

@@ -74,7 +74,7 @@ struct StripeParams {
     const half_t *bias;
     const half_t *norm_w;  // non-NULL: RMS-normalise x while it is staged (M == 1)
     float norm_eps;
-    const int32_t *xperm;  // non-NULL: x (and norm_w) gathered through this permutation (M == 1)
+    const uint16_t *xperm; // non-NULL: x (and norm_w) gathered through this permutation (M == 1); uint16: K <= 24576 on this path
     float *y32;            // non-NULL: store the fp32 sums here instead of fp16 y (no bias): partial of a K-sharded layer (M == 1)
     int M, K, N, G, NS, gq_shift, bits;
 };

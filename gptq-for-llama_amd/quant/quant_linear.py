@@ -149,6 +149,21 @@ def stripe_copy(qweight, scales, qzeros, bits, groupsize, up=None):
     return st
 
 
+def perm_u16(perm):
+    """the act-order permutation (int32 [K], act_order_sorted) as the uint16 vector the stripe16 kernels read (cached on the tensor;
+    K <= 24576 on that path).  None stays None."""
+    if perm is None:
+        return None
+    p16 = getattr(perm, '_gptq_u16', None)
+    if p16 is None:
+        p16 = perm.to(torch.int16)          # bit pattern of the uint16 value: every index is below 32768
+        try:
+            perm._gptq_u16 = p16
+        except Exception:  # pragma: no cover
+            pass
+    return p16
+
+
 def stripe_matvec(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, norm_weight=None, eps=0.0, perm=None, strict=True):
     """out[M, N] = x[M, K] (1 <= M <= 4) through a stripe16 image (gptq_stripe_matvec_f16) on the current stream.
     strict=False: return False instead of raising when the kernel does not serve the call (GPTQ_E_VARIANT: e.g. four rows of a
@@ -156,7 +171,7 @@ def stripe_matvec(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, norm_we
     M = x.shape[0]
     rc = _native.lib().gptq_stripe_matvec_f16(x.data_ptr(), x.stride(0) if M > 1 else K, st.data_ptr(), st.numel(), _native.ptr(bias),
                                               out.data_ptr(), out.stride(0) if M > 1 else N, M, K, N, bits, groupsize, nsets,
-                                              _native.ptr(norm_weight), float(eps), _native.ptr(perm), _native.stream_ptr(x.device))
+                                              _native.ptr(norm_weight), float(eps), _native.ptr(perm_u16(perm)), _native.stream_ptr(x.device))
     if rc == -6 and not strict:
         return False
     _native.check(rc, 'gptq_stripe_matvec_f16')

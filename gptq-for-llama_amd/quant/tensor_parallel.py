@@ -99,7 +99,7 @@ def _default_partial(x2, s):
     """fp32 partial [M, N] of a K-shard: the stripe16 kernel stores its fp32 sums unrounded at M == 1
     (gptq_stripe_matvec_partial_f32); other shapes go through the fp16 kernels (one extra rounding per shard)."""
     from . import _native
-    from .quant_linear import _as_rows, _int32c, act_order_sorted, stripe_copy
+    from .quant_linear import _as_rows, _int32c, act_order_sorted, perm_u16, stripe_copy
     if x2.shape[0] == 1 and s.bits in (2, 3, 4, 8) and x2.is_cuda:
         K, N = s.qweight.shape[0] * 32 // s.bits, s.qweight.shape[1]
         gs = s.groupsize if s.groupsize != -1 else K
@@ -113,7 +113,7 @@ def _default_partial(x2, s):
             with torch.cuda.device(x.device):
                 part = torch.empty((1, N), dtype=torch.float32, device=x.device)
                 rc = _native.lib().gptq_stripe_matvec_partial_f32(x.data_ptr(), st.data_ptr(), st.numel(), part.data_ptr(), K, N, s.bits, gs, 1,
-                                                                  _native.ptr(perm), _native.stream_ptr(x.device))
+                                                                  _native.ptr(perm_u16(perm)), _native.stream_ptr(x.device))
             _native.check(rc, 'gptq_stripe_matvec_partial_f32')
             return part
     return matmul248(x2, s.qweight, s.scales, s.qzeros, s.g_idx, s.bits, s.maxq).float()

@@ -263,7 +263,8 @@ int gptq_decode_attn_fused_table_f16(const void *qkv, const int64_t *position, v
 * matvec returns silu(x Wg) * (x Wu).  1 <= M <= 4 rows of x (row strides ldx / ldy) cost the same weight stream as one: the
  * MFMA computes four rows anyway; 5 <= M <= 8 / 16 run two / four MFMA row groups on the same unpacked words while M rows of x
  * fit in LDS (K <= ~9200 / ~4600, else GPTQ_E_VARIANT: the caller takes the weight-streaming MFMA kernel).  M == 1 only: norm_weight != NULL fuses the RMSNorm of x (rms_norm_fwd_fused,
- * quant/triton_norm.py:22-39) in front; perm != NULL reads x through a permutation (an act-order layer whose qweight rows were
+ * quant/triton_norm.py:22-39) in front; perm != NULL (uint16 [K]: the same permutation gptq_act_order_repack takes, narrowed -- every
+ * workgroup reads all of it, so its width is load traffic) reads x through a permutation (an act-order layer whose qweight rows were
  * sorted by group with gptq_act_order_repack BEFORE gptq_stripe_repack).  No workspace, no atomics: results are bit-identical
  * run to run. */
 size_t gptq_stripe_bytes(int K, int N, int bits, int groupsize, int nsets);
@@ -271,14 +272,14 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
                        const int32_t *qzeros_up, void *stripes, size_t stripes_bytes, int K, int N, int bits, int groupsize,
                        gptq_stream_t stream);
 int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
-                           int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const int32_t *perm,
+                           int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
                            gptq_stream_t stream);
 /* The same matvec with the fp32 sums stored unrounded: the per-rank PARTIAL of a row-(K-)sharded layer (BASELINE config 5,
  * quant/tensor_parallel.py) -- the shards are summed by ONE all-reduce and rounded to fp16 once, like the unsharded layer.
  * y_partial is fp32 [nsets][N]: with nsets == 2 the gate and the up sums are stored separately (no SiLU: it needs the
  * complete sums). */
 int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t stripes_bytes, float *y_partial, int K, int N, int bits,
-                                   int groupsize, int nsets, const int32_t *perm, gptq_stream_t stream);
+                                   int groupsize, int nsets, const uint16_t *perm, gptq_stream_t stream);
 /* Small decode batches, 1 <= M <= 256 (passes of up to 64 rows, each streams the weights once), on the same image (csrc/stripe_mm.inc): 16-row MFMA tiles (v_mfma_f32_16x16x32_f16) on exactly
  * dequantised q - z, fp32 group scales; either one launch (a stripe x whole K per workgroup, x streamed through LDS) or K slices
  * (128 columns x one slice per workgroup) that meet through fp32 partial tiles in `workspace` and a reduce kernel (summed in

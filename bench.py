@@ -364,20 +364,20 @@ def _time_cold(run, nsets, reps=5):
     return e0.elapsed_time(e1) * 1e3 / (reps * nsets)
 
 
-def prefill_leg(dev, M=65536, reps=3):
+def prefill_leg(dev, M=65536, reps=5):
     """BASELINE config 3 (reported only): LLaMA-7B-shaped 4-bit g128 batched matmul at M = 32 x 2048 through the drop-in
-    matmul248 (hand-written MFMA tile GEMM, csrc/gemm_mfma.hip; reference kernel quant_linear.py:72-137), TFLOP/s =
-    2 M N K / t against the 2.5 PFLOP/s dense fp16 MFMA peak, next to hipBLASLt (torch.matmul) on the dequantised weight."""
+    matmul248 (reference kernel quant_linear.py:72-137), TFLOP/s = 2 M N K / t against the 2.5 PFLOP/s dense fp16 MFMA peak.
+    Three numbers per shape: the product's route (GPTQ_PREFILL, default 'library': our dequantise kernel PER CALL + the library
+    GEMM), the hand-written fused MFMA tile GEMM (csrc/gemm_mfma.hip, family='abi'), and hipBLASLt alone on a weight
+    dequantised beforehand (the ceiling either route can reach)."""
     from quant import quant_linear as QL
     gen = torch.Generator(device=dev)
     gen.manual_seed(3)
-    out = {'M': M, 'peak_TFLOPs': 2500.0, 'shapes': {}}
+    out = {'M': M, 'peak_TFLOPs': 2500.0, 'route': QL.PREFILL_ROUTE, 'shapes': {}}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for K, N in [(HIDDEN, HIDDEN), (HIDDEN, 3 * HIDDEN), (HIDDEN, INTER), (INTER, HIDDEN)]:
-        w = PackedSet(K, N, dev, gen)
-        x = torch.randn((M, K), device=dev, generator=gen).half()
-        gi = (torch.arange(K, device=dev) // GS).to(torch.int32)
-        f = lambda: QL.matmul248(x, w.qweight, w.scales, w.qzeros, gi, BITS, 15)
+
+    def timed(f):
+        f()
         y = f()
         torch.cuda.synchronize()
         e0.record()
@@ -385,22 +385,38 @@ def prefill_leg(dev, M=65536, reps=3):
             y = f()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        return e0.elapsed_time(e1) / reps, y
+
+    for K, N in [(HIDDEN, HIDDEN), (HIDDEN, 3 * HIDDEN), (HIDDEN, INTER), (INTER, HIDDEN)]:
+        w = PackedSet(K, N, dev, gen)
+        x = torch.randn((M, K), device=dev, generator=gen).half()
+        gi = (torch.arange(K, device=dev) // GS).to(torch.int32)
+        ms, y = timed(lambda: QL.matmul248(x, w.qweight, w.scales, w.qzeros, gi, BITS, 15))
+        msf, yf = timed(lambda: QL.matmul248(x, w.qweight, w.scales, w.qzeros, gi, BITS, 15, family='abi'))
         W = QL.dequantize(w.qweight, w.scales, w.qzeros, None, BITS, GS)
-        yd = x @ W
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            yd = x @ W
-        e1.record()
-        torch.cuda.synchronize()
-        msd = e0.elapsed_time(e1) / reps
-        tf, tfd = 2.0 * M * N * K / ms / 1e9, 2.0 * M * N * K / msd / 1e9
+        msd, yd = timed(lambda: x @ W)
+        fl = 2.0 * M * N * K / 1e9
+        tf, tff, tfd = fl / ms, fl / msf, fl / msd
         out['shapes']['%dx%d' % (K, N)] = {'ms': round(ms, 3), 'TFLOPs': round(tf, 1), 'frac_of_2.5PF': round(tf / 2500.0, 4),
-                                           'hipblaslt_dense_TFLOPs': round(tfd, 1), 'vs_hipblaslt': round(tf / tfd, 3),
-                                           'max_abs_diff_vs_dense': float((y.float() - yd.float()).abs().max())}
-        del w, x, y, yd, W
+                                           'fused_kernel_TFLOPs': round(tff, 1), 'hipblaslt_dense_TFLOPs': round(tfd, 1),
+                                           'vs_hipblaslt': round(tf / tfd, 3), 'fused_kernel_vs_hipblaslt': round(tff / tfd, 3),
+                                           'max_abs_diff_vs_dense': float((y.float() - yd.float()).abs().max()),
+                                           'fused_kernel_max_abs_diff_vs_dense': float((yf.float() - yd.float()).abs().max())}
+        del w, x, y, yf, yd, W
         torch.cuda.empty_cache()
+    # the MLP's gate/up pair with SiLU (fused_mlp.fused_gate_up; reference fusedmatmul_248_kernel, fused_mlp.py:84-168)
+    from quant import fused_mlp as FM
+    K, N = HIDDEN, INTER
+    wg, wu = PackedSet(K, N, dev, gen), PackedSet(K, N, dev, gen)
+    x = torch.randn((M, K), device=dev, generator=gen).half()
+    gi = (torch.arange(K, device=dev) // GS).to(torch.int32)
+    ms, c = timed(lambda: FM.fused_gate_up(x, (wg.qweight, wg.scales, wg.qzeros, gi), (wu.qweight, wu.scales, wu.qzeros, gi), BITS, GS))
+    msf, cf = timed(lambda: FM.fused_gate_up(x, (wg.qweight, wg.scales, wg.qzeros, gi), (wu.qweight, wu.scales, wu.qzeros, gi), BITS, GS, family='abi'))
+    fl = 4.0 * M * N * K / 1e9
+    out['gate_up_silu_2x%dx%d' % (K, N)] = {'ms': round(ms, 3), 'TFLOPs': round(fl / ms, 1), 'fused_kernel_TFLOPs': round(fl / msf, 1),
+                                           'max_abs_diff_between_routes': float((c.float() - cf.float()).abs().max())}
+    del wg, wu, x, c, cf
+    torch.cuda.empty_cache()
     return out
 
 

@@ -571,7 +571,24 @@ int gptq_dequant_f16(const int32_t *qweight, const void *scales, const int32_t *
     if (K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0) return GPTQ_E_SHAPE;
     if (!qweight || !scales || !qzeros || !w) return GPTQ_E_NULL;
     return dequant_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits,
-                          (half_t *)w, (hipStream_t)stream);
+                          (half_t *)w, N, (hipStream_t)stream);
+}
+
+int gptq_dequant_ld_f16(const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *g_idx, void *w, int64_t ldw, int K,
+                        int N, int bits, int groupsize, gptq_stream_t stream) {
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || ldw < N) return GPTQ_E_SHAPE;
+    if (!qweight || !scales || !qzeros || !w) return GPTQ_E_NULL;
+    return dequant_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits,
+                          (half_t *)w, ldw, (hipStream_t)stream);
+}
+
+int gptq_silu_mul_f16(const void *gate, int64_t ldg, const void *up, int64_t ldu, void *c, int64_t ldc, int M, int N, gptq_stream_t stream) {
+    if (M < 0 || N <= 0 || N % 8 != 0 || ldg < N || ldu < N || ldc < N || ldg % 8 != 0 || ldu % 8 != 0 || ldc % 8 != 0) return GPTQ_E_SHAPE;
+    if (M == 0) return GPTQ_OK;
+    if (!gate || !up || !c) return GPTQ_E_NULL;
+    if (((uintptr_t)gate | (uintptr_t)up | (uintptr_t)c) % 16 != 0) return GPTQ_E_ALIGN;
+    return silu_mul_launch((const half_t *)gate, ldg, (const half_t *)up, ldu, (half_t *)c, ldc, M, N, (hipStream_t)stream);
 }
 
 int gptq_act_order_repack(const int32_t *qweight, const int32_t *perm, int K, int N, int bits, int32_t *qweight_sorted,

@@ -277,7 +277,7 @@ int pack_launch(const float *weight, const float *scales, const float *zeros, co
 template <int BITS>
 __global__ void __launch_bounds__(256) dequant_kernel(const uint32_t *__restrict__ qw, const half_t *__restrict__ sc,
                                                       const int32_t *__restrict__ qz, const int32_t *__restrict__ gi, int K, int N,
-                                                      int G, int groupsize, half_t *__restrict__ out) {
+                                                      int G, int groupsize, half_t *__restrict__ out, int64_t ldo) {
     const int blk = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const int ldz = N / 32 * BITS;
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(256) dequant_kernel(const uint32_t *__restrict
             z = (half_t)(float)zero_of<BITS>(qz + (size_t)g * ldz, n);
         }
         const int q = field_of_block<BITS>(col, j);
-        out[(size_t)k * N + n] = (half_t)((half_t)(float)q - z) * s;
+        out[(size_t)k * ldo + n] = (half_t)((half_t)(float)q - z) * s;
     }
 }
 
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) dequant_kernel(const uint32_t *__restrict
 // store instructions than the generic kernel's 2-byte stores.
 __global__ void __launch_bounds__(256) dequant4_fast_kernel(const uint32_t *__restrict__ qw, const half_t *__restrict__ sc,
                                                             const int32_t *__restrict__ qz, int K, int N, int groupsize,
-                                                            half_t *__restrict__ out) {
+                                                            half_t *__restrict__ out, int64_t ldo) {
     const int n8 = (blockIdx.x * 256 + threadIdx.x) * 8, r = blockIdx.y;   // packed row r = k / 8
     if (n8 >= N) return;
     const int g = (r * 8) / groupsize;
@@ -322,24 +322,52 @@ __global__ void __launch_bounds__(256) dequant4_fast_kernel(const uint32_t *__re
         half8_t o;
 #pragma unroll
         for (int c = 0; c < 8; c++) o[c] = (half_t)((half_t)(float)((words[c] >> (4 * j)) & 15u) - z[c]) * s8[c];
-        *(half8_t *)(out + (size_t)(r * 8 + j) * N + n8) = o;
+        *(half8_t *)(out + (size_t)(r * 8 + j) * ldo + n8) = o;
     }
 }
 
 int dequant_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, const int32_t *gi, int K, int N, int G, int groupsize,
-                   int bits, half_t *out, hipStream_t s) {
-    if (bits == 4 && !gi && groupsize % 8 == 0 && N % 8 == 0 && ((uintptr_t)qw % 16) == 0 && ((uintptr_t)sc % 16) == 0 &&
+                   int bits, half_t *out, int64_t ldo, hipStream_t s) {
+    if (bits == 4 && !gi && groupsize % 8 == 0 && N % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)qw % 16) == 0 && ((uintptr_t)sc % 16) == 0 &&
         ((uintptr_t)out % 16) == 0) {
-        hipLaunchKernelGGL(dequant4_fast_kernel, dim3((N / 8 + 255) / 256, K / 8), dim3(256), 0, s, qw, sc, qz, K, N, groupsize, out);
+        hipLaunchKernelGGL(dequant4_fast_kernel, dim3((N / 8 + 255) / 256, K / 8), dim3(256), 0, s, qw, sc, qz, K, N, groupsize, out, ldo);
         return (int)hipGetLastError();
     }
     dim3 grid((N + 255) / 256, K / 32), block(256);
     switch (bits) {
-        case 2: hipLaunchKernelGGL(dequant_kernel<2>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out); break;
-        case 3: hipLaunchKernelGGL(dequant_kernel<3>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out); break;
-        case 4: hipLaunchKernelGGL(dequant_kernel<4>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out); break;
-        case 8: hipLaunchKernelGGL(dequant_kernel<8>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out); break;
+        case 2: hipLaunchKernelGGL(dequant_kernel<2>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out, ldo); break;
+        case 3: hipLaunchKernelGGL(dequant_kernel<3>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out, ldo); break;
+        case 4: hipLaunchKernelGGL(dequant_kernel<4>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out, ldo); break;
+        case 8: hipLaunchKernelGGL(dequant_kernel<8>, grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out, ldo); break;
         default: return GPTQ_E_BITS;
+    }
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ silu(gate) * up
+// c[m][n] = fp16(silu(fp32 gate[m][n]) * fp32 up[m][n]) -- the epilogue of the reference's fused MLP kernel (fused_mlp.py:160-165)
+// as a pass of its own, for the route that hands the two products to a library GEMM (prefill).  HBM-bound: 6 B per element,
+// 16-byte accesses, one row of the batch per blockIdx.y.
+__global__ void __launch_bounds__(256) silu_mul_kernel(const half_t *__restrict__ g, int64_t ldg, const half_t *__restrict__ u, int64_t ldu,
+                                                       half_t *__restrict__ c, int64_t ldc, int N) {
+    const int n8 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (n8 >= N) return;
+    const size_t m = blockIdx.y;
+    const half8_t gv = *(const half8_t *)(g + m * ldg + n8), uv = *(const half8_t *)(u + m * ldu + n8);
+    half8_t o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float a = (float)gv[i];
+        o[i] = (half_t)(a * (1.0f / (1.0f + __expf(-a))) * (float)uv[i]);
+    }
+    *(half8_t *)(c + m * ldc + n8) = o;
+}
+
+int silu_mul_launch(const half_t *g, int64_t ldg, const half_t *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s) {
+    for (int m0 = 0; m0 < M; m0 += 65535) {       // gridDim.y limit
+        const int rows = M - m0 < 65535 ? M - m0 : 65535;
+        hipLaunchKernelGGL(silu_mul_kernel, dim3((N / 8 + 255) / 256, rows), dim3(256), 0, s, g + (size_t)m0 * ldg, ldg, u + (size_t)m0 * ldu, ldu,
+                           c + (size_t)m0 * ldc, ldc, N);
     }
     return (int)hipGetLastError();
 }

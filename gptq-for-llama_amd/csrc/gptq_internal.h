@@ -60,7 +60,8 @@ int pack_launch(const float *weight, const float *scales, const float *zeros, co
                 int N, int G, int bits, int groupsize, int32_t *qweight, int32_t *qzeros, half_t *scales16,
                 hipStream_t s);
 int dequant_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, const int32_t *gi, int K, int N, int G, int groupsize,
-                   int bits, half_t *out, hipStream_t s);
+                   int bits, half_t *out, int64_t ldo, hipStream_t s);
+int silu_mul_launch(const half_t *g, int64_t ldg, const half_t *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
 int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 

@@ -48,6 +48,8 @@ _SIGNATURES = {
                       c_void_p, c_void_p, c_void_p],
     'gptq_g_idx_is_trivial': [c_void_p, c_int, c_int, c_void_p, c_void_p],
     'gptq_dequant_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    'gptq_dequant_ld_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
+    'gptq_silu_mul_f16': [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p],
     'gptq_act_order_repack': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     'gptq_matmul248_sorted_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                   c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],

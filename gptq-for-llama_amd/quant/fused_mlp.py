@@ -9,6 +9,7 @@ from .quant_linear import QuantLinear, _as_rows, _int32c, g_idx_is_trivial
 
 
 PREFILL_SPLIT_M = 64
+PREFILL_CHUNK_M = 16384
 
 
 def _same_perm(a, b):
@@ -84,17 +85,25 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
             if rc != -6:   # GPTQ_E_VARIANT: shape not served by the rowwave kernel -> generic path below
                 _native.check(rc, 'gptq_fused_mlp_sorted_f16')
                 return c
-    if M > PREFILL_SPLIT_M and all(gi is None for gi in gis) and bits in (4, 8):
-        from .quant_linear import _mid_m, matmul248
+    if family is None and M > PREFILL_SPLIT_M:
+        from .quant_linear import _mid_m, dequantize, silu_mul
         if _mid_m(M, N):
-            # a prompt of tens to a few thousand tokens: too few 256x256 tiles to fill the GPU -> both products through the
-            # dequantise-once + dense GEMM route of matmul248, SiLU*mul in fp32 (small tensors)
-            g = matmul248(x2, gate[0], gate[1], gate[2], None, bits, 2**bits - 1)
-            u = matmul248(x2, up[0], up[1], up[2], None, bits, 2**bits - 1)
-            gf = g.float()
-            return (gf * torch.sigmoid(gf) * u.float()).half()
-        # large prefill: gptq_fused_mlp_f16 runs two MFMA-tile GEMMs, the second applies silu(gate) * up in place in its
-        # epilogue -- no fp32 intermediates, no extra pass over the [M, N] activations (falls through to the call below)
+            # prefill: gate | up dequantised side by side into ONE [K, 2N] fp16 matrix (our kernel, any width, any g_idx), one
+            # library GEMM per chunk of rows, then silu(gate) * up in fp32 as a pass of its own (gptq_silu_mul_f16).  The
+            # reference's kernel applies SiLU to the fp32 accumulators (fused_mlp.py:160-165); here gate and up are rounded to
+            # fp16 first, like its unfused modules do -- inside the parity budget, tested against the oracle.  Chunks bound the
+            # transient [rows, 2N] product (0.7 GB at 16 384 x 22 016).
+            with torch.cuda.device(x.device):
+                W = torch.empty((K, 2 * N), device=x.device, dtype=torch.float16)
+                dequantize(gate[0], gate[1], gate[2], gis[0], bits, groupsize, out=W[:, :N])
+                dequantize(up[0], up[1], up[2], gis[1], bits, groupsize, out=W[:, N:])
+                c = torch.empty((M, N), device=x.device, dtype=torch.float16)
+                for m0 in range(0, M, PREFILL_CHUNK_M):
+                    y = torch.matmul(x2[m0:m0 + PREFILL_CHUNK_M], W)
+                    silu_mul(y[:, :N], y[:, N:], out=c[m0:m0 + PREFILL_CHUNK_M])
+            return c
+        # GPTQ_PREFILL=fused, large prefill: gptq_fused_mlp_f16 runs two MFMA-tile GEMMs, the second applies silu(gate) * up in
+        # place in its epilogue -- no intermediates, no extra pass over the [M, N] activations (falls through to the call below)
     with torch.cuda.device(x.device):
         c = torch.empty((M, N), device=x.device, dtype=torch.float16)
         if M:

@@ -256,34 +256,59 @@ def _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, 
     _native.check(rc, _FAMILIES[family])
 
 
-# M regimes of the built-in dispatch (DESIGN.md "dispatch"): the C ABI serves every M, but between the
-# weight-streaming kernels (M <= STREAM_MAX_M = 64) and a prefill big enough to fill the GPU with 256 x 256
-# MFMA tiles the product is a small dense GEMM; there the weight is dequantised once (our kernel,
-# reference numerics) and multiplied with the library GEMM.  family= bypasses this.
+# M regimes of the built-in dispatch (DESIGN.md "dispatch"): the C ABI serves every M with its own kernels, but above the
+# weight-streaming kernels (M <= STREAM_MAX_M = 64; stripe16 MFMA tiles up to 128 rows) the product is a dense GEMM whose weight
+# bytes no longer matter.  There the weight is dequantised once per call (our kernel, reference numerics, 10-20 us for a
+# LLaMA-7B layer) and multiplied by the library GEMM: measured 1.12-1.39x the fused MFMA tile kernel of csrc/gemm_mfma.hip at every
+# M from 256 to 65 536 (profiles/r2e_prefill/prefill_routes.txt).  GPTQ_PREFILL=fused keeps the fused tile kernel for grids of
+# >= GEMM_MIN_TILES 256 x 256 tiles (no transient fp16 weight: K N 2 bytes per call); family= bypasses the choice.
 STREAM_MAX_M = 64
 GEMM_MIN_TILES = 192
+PREFILL_ROUTE = _os.environ.get('GPTQ_PREFILL', 'library')
+if PREFILL_ROUTE not in ('library', 'fused'):
+    raise RuntimeError("GPTQ_PREFILL must be 'library' or 'fused', got %r" % PREFILL_ROUTE)
 
 
 def _mid_m(M, N):
-    return M > STREAM_MAX_M and (-(-M // 256)) * (-(-N // 256)) < GEMM_MIN_TILES
+    """True when a batch of M rows goes through dequantise-once + library GEMM"""
+    return M > STREAM_MAX_M and (PREFILL_ROUTE == 'library' or (-(-M // 256)) * (-(-N // 256)) < GEMM_MIN_TILES)
 
 
-def dequantize(qweight, scales, qzeros, g_idx, bits, groupsize=None):
+def dequantize(qweight, scales, qzeros, g_idx, bits, groupsize=None, out=None):
     """dense fp16 [K, N] weight with the reference's own rounding (fp16(q - z) * fp16 scale -> fp16,
     quant_linear.py:128): bit-identical to what the prefill tile GEMM and the generic GEMV multiply with.  The
     decode kernels (stripe16 / rowwave / stream) keep (q - z) * s in fp32 instead, i.e. they are slightly MORE
-    exact than this matrix; all paths sit inside the 1e-3 budget of the parity tests."""
+    exact than this matrix; all paths sit inside the 1e-3 budget of the parity tests.  ``out``: a [K, N] fp16 view with
+    unit column stride (e.g. one half of a [K, 2N] gate | up matrix)."""
     K, N = qweight.shape[0] * 32 // bits, qweight.shape[1]
     groupsize = _infer_groupsize(K, scales.shape[0]) if groupsize is None else groupsize
     gi = None
     if g_idx is not None and not g_idx_is_trivial(g_idx, K, groupsize):
         gi = _int32c(g_idx[:K])
     with torch.cuda.device(qweight.device):
-        W = torch.empty((K, N), dtype=torch.float16, device=qweight.device)
-        rc = _native.lib().gptq_dequant_f16(_int32c(qweight).data_ptr(), scales.data_ptr(), _int32c(qzeros).data_ptr(), _native.ptr(gi),
-                                            W.data_ptr(), K, N, bits, groupsize, _native.stream_ptr(qweight.device))
-    _native.check(rc, 'gptq_dequant_f16')
+        W = torch.empty((K, N), dtype=torch.float16, device=qweight.device) if out is None else out
+        if W.shape != (K, N) or W.dtype != torch.float16 or W.stride(1) != 1 or W.device != qweight.device:
+            raise RuntimeError('dequantize: out must be a [%d, %d] fp16 view with unit column stride on %s' % (K, N, qweight.device))
+        rc = _native.lib().gptq_dequant_ld_f16(_int32c(qweight).data_ptr(), scales.data_ptr(), _int32c(qzeros).data_ptr(), _native.ptr(gi),
+                                               W.data_ptr(), W.stride(0), K, N, bits, groupsize, _native.stream_ptr(qweight.device))
+    _native.check(rc, 'gptq_dequant_ld_f16')
     return W
+
+
+def silu_mul(gate, up, out=None):
+    """out = fp16(silu(gate) * up) in fp32 math (reference fused_mlp.py:160-165) for two [M, N] fp16 matrices with unit column
+    stride (row strides free: the halves of one [M, 2N] product)."""
+    _native.require_device(gate, 'silu_mul')
+    M, N = gate.shape
+    out = torch.empty((M, N), dtype=torch.float16, device=gate.device) if out is None else out
+    for t in (gate, up, out):
+        if t.shape != (M, N) or t.dtype != torch.float16 or t.stride(1) != 1:
+            raise RuntimeError('silu_mul: [M, N] fp16 matrices with unit column stride')
+    with torch.cuda.device(gate.device):
+        rc = _native.lib().gptq_silu_mul_f16(gate.data_ptr(), gate.stride(0), up.data_ptr(), up.stride(0), out.data_ptr(), out.stride(0), M, N,
+                                             _native.stream_ptr(gate.device))
+    _native.check(rc, 'gptq_silu_mul_f16')
+    return out
 
 
 _FAMILIES = {None: 'gptq_matmul248_f16', 'abi': 'gptq_matmul248_f16', 'gemv': 'gptq_gemv_f16', 'skinny': 'gptq_skinny_f16',
@@ -328,9 +353,10 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
             return out
         if family is None and _mid_m(M, N):
             W = dequantize(qweight, scales, qzeros, gi, bits, groupsize)
-            torch.matmul(x, W, out=out)
             if bias is not None:
-                out += bias
+                torch.addmm(bias, x, W, out=out)        # the add rides in the library GEMM's epilogue
+            else:
+                torch.matmul(x, W, out=out)
             return out
         if family == 'stripe':
             raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M <= 4, bits in 2/4/8, K a multiple of the row block ...)')

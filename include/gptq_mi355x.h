@@ -178,6 +178,17 @@ int gptq_g_idx_is_trivial(const int32_t *g_idx, int K, int groupsize, int32_t *o
  */
 int gptq_dequant_f16(const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *g_idx,
                      void *w, int K, int N, int bits, int groupsize, gptq_stream_t stream);
+/* the same with a leading dimension (ldw >= N halves): e.g. gate | up of an MLP side by side in ONE [K, 2N] matrix, so that the
+ * pair is one library GEMM (quant/fused_mlp.py, prefill route). */
+int gptq_dequant_ld_f16(const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *g_idx,
+                        void *w, int64_t ldw, int K, int N, int bits, int groupsize, gptq_stream_t stream);
+/*
+ * c[m][n] = fp16(silu(gate[m][n]) * up[m][n]), fp32 math -- the epilogue of the reference's fused MLP kernel
+ * (quant/fused_mlp.py:160-165) as a pass of its own, for gate / up products that come out of a library GEMM.  N % 8 == 0,
+ * leading dimensions multiples of 8 halves, 16-byte aligned pointers; c may alias gate.
+ */
+int gptq_silu_mul_f16(const void *gate, int64_t ldg, const void *up, int64_t ldu, void *c, int64_t ldc, int M, int N,
+                      gptq_stream_t stream);
 
 /*
  * Act-order fast path (extension; the reference re-gathers g_idx, scales and zeros for every k row

@@ -188,6 +188,68 @@ def test_mid_m_route(M):
     assert rel_err(y, y_abi) < TOL
 
 
+def test_dequantize_into_a_strided_view_and_silu_mul():
+    """the two kernels of the prefill route next to the library GEMM: gptq_dequant_ld_f16 writes gate | up side by side into ONE
+    [K, 2N] matrix (bit-exact halves, nothing outside them), gptq_silu_mul_f16 = fp16(silu(fp32 g) * fp32 u) on strided halves."""
+    import torch
+    K, N = 512, 288
+    A, B = make_random_layer(4, 128, K, N, seed=1), make_random_layer(2, 64, K, N, act_order=True, seed=2)
+    W = torch.full((K, 2 * N + 8), 7.0, dtype=torch.float16, device='cuda:0')
+    QL.dequantize(dev(A['qweight']), dev(A['scales']), dev(A['qzeros']), dev(A['g_idx']), 4, out=W[:, :N])
+    QL.dequantize(dev(B['qweight']), dev(B['scales']), dev(B['qzeros']), dev(B['g_idx']), 2, out=W[:, N:2 * N])
+    Wn = W.cpu().numpy()
+    for L, bits, sl in ((A, 4, slice(0, N)), (B, 2, slice(N, 2 * N))):
+        ref = oracle.dequant(L['qweight'], L['qzeros'], L['scales'], L['g_idx'], bits, faithful=True).astype(np.float16)
+        assert np.array_equal(np.ascontiguousarray(Wn[:, sl]).view(np.uint16), ref.view(np.uint16))
+    assert (Wn[:, 2 * N:] == 7.0).all()
+    with pytest.raises(RuntimeError):
+        QL.dequantize(dev(A['qweight']), dev(A['scales']), dev(A['qzeros']), dev(A['g_idx']), 4, out=W[:, :N + 8])
+    rng = np.random.default_rng(3)
+    for M in (1, 37, 300):
+        y = (rng.standard_normal((M, 2 * N)) * 3).astype(np.float16)
+        dy = dev(y)
+        c = QL.silu_mul(dy[:, :N], dy[:, N:]).cpu().numpy()
+        g, u = y[:, :N].astype(np.float32), y[:, N:].astype(np.float32)
+        ref = (g / (1.0 + np.exp(-g)) * u).astype(np.float16)
+        assert rel_err(c, ref) < 1e-3 and np.abs(c.astype(np.float32) - ref.astype(np.float32)).max() <= 2 * np.spacing(np.abs(ref).max().astype(np.float16))
+    assert _native.lib().gptq_silu_mul_f16(dy.data_ptr(), 2 * N, dy.data_ptr(), 2 * N, dy.data_ptr(), 2 * N, 4, N + 4, None) == -2      # N % 8
+
+
+@pytest.mark.parametrize('route', ['library', 'fused'])
+@pytest.mark.parametrize('bits,gs,act,M,K,N', [(4, 128, False, 4096, 4096, 4096), (4, 128, True, 2100, 1024, 4096), (3, -1, False, 700, 512, 320),
+                                               (2, 64, False, 300, 1024, 512), (8, 128, False, 8192, 512, 4096)])
+def test_prefill_routes_vs_oracle(route, bits, gs, act, M, K, N, monkeypatch):
+    """the built-in dispatch above the streaming kernels, both settings of GPTQ_PREFILL: 'library' = our dequantise kernel + the
+    library GEMM (default), 'fused' = the MFMA tile kernel once the grid has enough tiles; against the CPU oracle on sampled rows."""
+    monkeypatch.setattr(QL, 'PREFILL_ROUTE', route)
+    L = make_random_layer(bits, gs, K, N, act_order=act, seed=M + K + bits)
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float16) if bits == 8 else None
+    y = hip_forward(x, L, bias=bias)
+    rows = np.unique(np.concatenate([np.arange(0, M, max(M // 24, 1)), [M - 1, 63, 64, 255, 256]]))
+    ref = oracle_forward(x[rows], L, bias=bias)
+    assert rel_err(y[rows], ref) < TOL, rel_err(y[rows], ref)
+
+
+@pytest.mark.parametrize('bits,gs,act,M', [(4, 128, False, 1000), (4, 128, True, 300), (2, 64, False, 200), (3, -1, False, 129), (8, 32, False, 333)])
+def test_fused_mlp_prefill_library_route_in_chunks(bits, gs, act, M, monkeypatch):
+    """fused_gate_up above the streaming kernels: gate | up in one [K, 2N] matrix, one library GEMM per chunk of rows (chunk forced
+    small here: ragged last chunk), silu * mul as its own pass -- every width, act-order included, against the fused oracle."""
+    monkeypatch.setattr(quant.fused_mlp, 'PREFILL_CHUNK_M', 128)
+    K, N = 512, 320 if bits == 3 else 288
+    A = make_random_layer(bits, gs, K, N, act_order=act, seed=M)
+    B = make_random_layer(bits, gs, K, N, act_order=act, seed=M + 1)
+    if act:
+        B['g_idx'] = A['g_idx']         # not required on this route, but what a real MLP has; the oracle takes either
+    x = (np.random.default_rng(M).standard_normal((M, K)) * 0.5).astype(np.float16)
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs if gs != -1 else K).cpu().numpy()
+    ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits)
+    assert rel_err(c, ref) < 2e-3        # gate and up are rounded to fp16 before SiLU * mul on this route
+
+
 @pytest.mark.parametrize('split_k', [2, 4])
 def test_skinny_split_k(split_k):
     L = make_random_layer(4, 128, 2048, 256, seed=11)

@@ -44,6 +44,15 @@ def test_argument_validation_needs_no_gpu():
     assert lib.gptq_matmul248_f16(None, 64, one, one, one, None, None, one, 64, 1, 64, 64, 4, 64, None, 0, None) == -4  # NULL x
     assert lib.gptq_matmul248_f16(2, 64, one, one, one, None, None, one, 64, 1, 64, 64, 4, 64, None, 0, None) == -3     # alignment
     assert lib.gptq_rmsnorm_f16(one, 40000, one, one, 40000, 1, 40000, 1e-6, None) == -7              # row > 64 KiB
+    # the two kernels of the prefill route (dequantise with a leading dimension, silu * mul pass)
+    assert lib.gptq_dequant_ld_f16(one, one, one, None, one, 64, 64, 64, 5, 64, None) == -1
+    assert lib.gptq_dequant_ld_f16(one, one, one, None, one, 32, 64, 64, 4, 64, None) == -2          # ldw < N
+    assert lib.gptq_dequant_ld_f16(one, one, one, None, None, 64, 64, 64, 4, 64, None) == -4
+    assert lib.gptq_silu_mul_f16(one, 64, one, 64, one, 64, 0, 64, None) == 0                         # empty batch
+    assert lib.gptq_silu_mul_f16(one, 64, one, 64, one, 60, 2, 64, None) == -2                        # ldc < N
+    assert lib.gptq_silu_mul_f16(one, 68, one, 64, one, 64, 2, 64, None) == -2                        # ld % 8
+    assert lib.gptq_silu_mul_f16(one, 64, None, 64, one, 64, 2, 64, None) == -4
+    assert lib.gptq_silu_mul_f16(8, 64, one, 64, one, 64, 2, 64, None) == -3
     with pytest.raises(NotImplementedError):
         _native.check(-1, 'x')
     with pytest.raises(RuntimeError):

@@ -25,7 +25,7 @@ for K, N in [(4096, 4096), (4096, 12288), (4096, 11008), (11008, 4096)]:
     w = PackedSet(K, N, dev, gen)
     x = torch.randn((a.m, K), device=dev, generator=gen).half()
     g_idx = (torch.arange(K, device=dev) // GS).to(torch.int32)
-    f = lambda: QL.matmul248(x, w.qweight, w.scales, w.qzeros, g_idx, BITS, 15)
+    f = lambda: QL.matmul248(x, w.qweight, w.scales, w.qzeros, g_idx, BITS, 15, family='abi')     # the fused tile kernel, whatever GPTQ_PREFILL says
     y = f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -58,7 +58,7 @@ K, N = 4096, 11008
 wg, wu = PackedSet(K, N, dev, gen), PackedSet(K, N, dev, gen)
 x = torch.randn((a.m, K), device=dev, generator=gen).half()
 gi = (torch.arange(K, device=dev) // GS).to(torch.int32)
-f = lambda: FM.fused_gate_up(x, (wg.qweight, wg.scales, wg.qzeros, gi), (wu.qweight, wu.scales, wu.qzeros, gi), BITS, GS)
+f = lambda: FM.fused_gate_up(x, (wg.qweight, wg.scales, wg.qzeros, gi), (wu.qweight, wu.scales, wu.qzeros, gi), BITS, GS, family='abi')
 y = f(); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()

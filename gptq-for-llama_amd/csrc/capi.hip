@@ -402,6 +402,7 @@ const char *gptq_strerror(int code) {
         case GPTQ_E_WORKSPACE: return "workspace missing or too small for the requested split-K";
         case GPTQ_E_VARIANT: return "unknown or inapplicable kernel variant";
         case GPTQ_E_NORM_WIDTH: return "This layer norm doesn't support feature dim >= 64KB.";
+        case GPTQ_E_LIBRARY: return "prefill route: hipBLASLt could not be loaded or refused the product";
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "unknown error";
@@ -581,6 +582,69 @@ int gptq_dequant_ld_f16(const int32_t *qweight, const void *scales, const int32_
     if (!qweight || !scales || !qzeros || !w) return GPTQ_E_NULL;
     return dequant_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits,
                           (half_t *)w, ldw, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- prefill route
+namespace {
+constexpr size_t PREFILL_LIB_WS = (size_t)76 << 20;      // what the library may use for itself (split / stream-K algorithms)
+constexpr int PREFILL_CHUNK_M = 16384;                   // rows of the transient [rows, 2N] gate | up product
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline int prefill_validate(const void *x, int64_t ldx, const void *y, int64_t ldy, int M, int K, int N, int bits, int groupsize) {
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || ldx < K || ldy < N) return GPTQ_E_SHAPE;
+    if (M > 0 && (!x || !y)) return GPTQ_E_NULL;
+    if (((uintptr_t)x | (uintptr_t)y) % 16 != 0 || ldx % 8 != 0 || ldy % 8 != 0) return GPTQ_E_ALIGN;
+    return GPTQ_OK;
+}
+}  // namespace
+
+size_t gptq_prefill_workspace_bytes(int M, int K, int N, int nsets) {
+    if (M < 0 || K <= 0 || N <= 0 || (nsets != 1 && nsets != 2)) return 0;
+    size_t b = align256((size_t)K * N * nsets * 2) + PREFILL_LIB_WS;
+    if (nsets == 2) b += align256((size_t)(M < PREFILL_CHUNK_M ? M : PREFILL_CHUNK_M) * 2 * N * 2);
+    return b;
+}
+
+int gptq_prefill_matmul_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
+                            const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits, int groupsize,
+                            void *workspace, size_t workspace_bytes, gptq_stream_t stream) {
+    if (int rc = prefill_validate(x, ldx, y, ldy, M, K, N, bits, groupsize)) return rc;
+    if (!qweight || !scales || !qzeros) return GPTQ_E_NULL;
+    if (M == 0) return GPTQ_OK;
+    if (!workspace || (uintptr_t)workspace % 256 != 0 || workspace_bytes < gptq_prefill_workspace_bytes(M, K, N, 1)) return GPTQ_E_WORKSPACE;
+    half_t *W = (half_t *)workspace;
+    char *lib_ws = (char *)workspace + align256((size_t)K * N * 2);
+    if (int rc = dequant_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits, W, N,
+                                (hipStream_t)stream))
+        return rc;
+    return dense_gemm_f16((const half_t *)x, ldx, W, N, (const half_t *)bias, (half_t *)y, ldy, M, K, N, lib_ws, PREFILL_LIB_WS, (hipStream_t)stream);
+}
+
+int gptq_prefill_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweight_gate, const void *scales_gate, const int32_t *qzeros_gate,
+                               const int32_t *g_idx_gate, const int32_t *qweight_up, const void *scales_up, const int32_t *qzeros_up,
+                               const int32_t *g_idx_up, void *c, int64_t ldc, int M, int K, int N, int bits, int groupsize, void *workspace,
+                               size_t workspace_bytes, gptq_stream_t stream) {
+    if (int rc = prefill_validate(x, ldx, c, ldc, M, K, N, bits, groupsize)) return rc;
+    if (!qweight_gate || !scales_gate || !qzeros_gate || !qweight_up || !scales_up || !qzeros_up) return GPTQ_E_NULL;
+    if (M == 0) return GPTQ_OK;
+    if (!workspace || (uintptr_t)workspace % 256 != 0 || workspace_bytes < gptq_prefill_workspace_bytes(M, K, N, 2)) return GPTQ_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t N2 = 2 * (int64_t)N;
+    half_t *W = (half_t *)workspace;                                                      // [K, 2N] = gate | up
+    char *lib_ws = (char *)workspace + align256((size_t)K * N2 * 2);
+    half_t *prod = (half_t *)(lib_ws + PREFILL_LIB_WS);                                    // [rows, 2N]
+    const int G = n_groups(K, groupsize);
+    if (int rc = dequant_launch((const uint32_t *)qweight_gate, (const half_t *)scales_gate, qzeros_gate, g_idx_gate, K, N, G, groupsize, bits, W, N2, s))
+        return rc;
+    if (int rc = dequant_launch((const uint32_t *)qweight_up, (const half_t *)scales_up, qzeros_up, g_idx_up, K, N, G, groupsize, bits, W + N, N2, s))
+        return rc;
+    for (int m0 = 0; m0 < M; m0 += PREFILL_CHUNK_M) {
+        const int rows = M - m0 < PREFILL_CHUNK_M ? M - m0 : PREFILL_CHUNK_M;
+        if (int rc = dense_gemm_f16((const half_t *)x + (size_t)m0 * ldx, ldx, W, N2, nullptr, prod, N2, rows, K, (int)N2, lib_ws, PREFILL_LIB_WS, s))
+            return rc;
+        if (int rc = silu_mul_launch(prod, N2, prod + N, N2, (half_t *)c + (size_t)m0 * ldc, ldc, rows, N, s)) return rc;
+    }
+    return GPTQ_OK;
 }
 
 int gptq_silu_mul_f16(const void *gate, int64_t ldg, const void *up, int64_t ldu, void *c, int64_t ldc, int M, int N, gptq_stream_t stream) {

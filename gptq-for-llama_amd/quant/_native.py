@@ -50,6 +50,11 @@ _SIGNATURES = {
     'gptq_dequant_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'gptq_dequant_ld_f16': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p],
     'gptq_silu_mul_f16': [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p],
+    'gptq_prefill_workspace_bytes': [c_int, c_int, c_int, c_int],
+    'gptq_prefill_matmul_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                c_int, c_void_p, c_size_t, c_void_p],
+    'gptq_prefill_fused_mlp_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
     'gptq_act_order_repack': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     'gptq_matmul248_sorted_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                   c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
@@ -117,6 +122,7 @@ def lib():
             L.gptq_decode_attn_workspace_bytes.restype = c_size_t
             L.gptq_stripe_bytes.restype = c_size_t
             L.gptq_p2p_buffer_bytes.restype = c_size_t
+            L.gptq_prefill_workspace_bytes.restype = c_size_t
             L.gptq_strerror.argtypes = [c_int]
             L.gptq_strerror.restype = ctypes.c_char_p
             _lib = L

@@ -9,7 +9,6 @@ from .quant_linear import QuantLinear, _as_rows, _int32c, g_idx_is_trivial
 
 
 PREFILL_SPLIT_M = 64
-PREFILL_CHUNK_M = 16384
 
 
 def _same_perm(a, b):
@@ -86,21 +85,24 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
                 _native.check(rc, 'gptq_fused_mlp_sorted_f16')
                 return c
     if family is None and M > PREFILL_SPLIT_M:
-        from .quant_linear import _mid_m, dequantize, silu_mul
+        from .quant_linear import _mid_m, _prefill_operand
         if _mid_m(M, N):
-            # prefill: gate | up dequantised side by side into ONE [K, 2N] fp16 matrix (our kernel, any width, any g_idx), one
-            # library GEMM per chunk of rows, then silu(gate) * up in fp32 as a pass of its own (gptq_silu_mul_f16).  The
-            # reference's kernel applies SiLU to the fp32 accumulators (fused_mlp.py:160-165); here gate and up are rounded to
-            # fp16 first, like its unfused modules do -- inside the parity budget, tested against the oracle.  Chunks bound the
-            # transient [rows, 2N] product (0.7 GB at 16 384 x 22 016).
+            # prefill (gptq_prefill_fused_mlp_f16): gate | up dequantised side by side into ONE [K, 2N] fp16 matrix (our kernel, any
+            # width, any g_idx), one hipBLASLt GEMM per chunk of 16 384 rows (bounds the transient [rows, 2N] product: 0.7 GB at
+            # 2N = 22 016), then silu(gate) * up in fp32 as a pass of its own (gptq_silu_mul_f16).  The reference's kernel applies
+            # SiLU to the fp32 accumulators (fused_mlp.py:160-165); here gate and up are rounded to fp16 first, like its unfused
+            # modules do -- inside the parity budget, tested against the oracle.
+            lib = _native.lib()
             with torch.cuda.device(x.device):
-                W = torch.empty((K, 2 * N), device=x.device, dtype=torch.float16)
-                dequantize(gate[0], gate[1], gate[2], gis[0], bits, groupsize, out=W[:, :N])
-                dequantize(up[0], up[1], up[2], gis[1], bits, groupsize, out=W[:, N:])
+                xs = _prefill_operand(x2)
                 c = torch.empty((M, N), device=x.device, dtype=torch.float16)
-                for m0 in range(0, M, PREFILL_CHUNK_M):
-                    y = torch.matmul(x2[m0:m0 + PREFILL_CHUNK_M], W)
-                    silu_mul(y[:, :N], y[:, N:], out=c[m0:m0 + PREFILL_CHUNK_M])
+                ws = torch.empty(lib.gptq_prefill_workspace_bytes(M, K, N, 2), dtype=torch.uint8, device=x.device)
+                sg, su = gate[1] if gate[1].is_contiguous() else gate[1].contiguous(), up[1] if up[1].is_contiguous() else up[1].contiguous()
+                rc = lib.gptq_prefill_fused_mlp_f16(xs.data_ptr(), xs.stride(0), _int32c(gate[0]).data_ptr(), sg.data_ptr(), _int32c(gate[2]).data_ptr(),
+                                                    _native.ptr(gis[0]), _int32c(up[0]).data_ptr(), su.data_ptr(), _int32c(up[2]).data_ptr(),
+                                                    _native.ptr(gis[1]), c.data_ptr(), N, M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
+                                                    _native.stream_ptr(x.device))
+            _native.check(rc, 'gptq_prefill_fused_mlp_f16')
             return c
         # GPTQ_PREFILL=fused, large prefill: gptq_fused_mlp_f16 runs two MFMA-tile GEMMs, the second applies silu(gate) * up in
         # place in its epilogue -- no intermediates, no extra pass over the [M, N] activations (falls through to the call below)

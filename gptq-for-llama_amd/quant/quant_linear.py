@@ -295,6 +295,25 @@ def dequantize(qweight, scales, qzeros, g_idx, bits, groupsize=None, out=None):
     return W
 
 
+def _prefill_operand(x):
+    return x if (x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
+
+
+def prefill_matmul(x, qweight, scales, qzeros, gi, bias, out, K, N, bits, groupsize):
+    """out[M, N] = x . deq(W) (+ bias) through gptq_prefill_matmul_f16: dequantise once per call into a transient workspace (caching
+    allocator: the next layer reuses it), dense product by hipBLASLt, bias in its epilogue.  gi: None or the int32 g_idx of an
+    act-order layer (no gather of x on this route)."""
+    lib = _native.lib()
+    x = _prefill_operand(x)
+    M = x.shape[0]
+    ws = torch.empty(lib.gptq_prefill_workspace_bytes(M, K, N, 1), dtype=torch.uint8, device=x.device)
+    rc = lib.gptq_prefill_matmul_f16(x.data_ptr(), x.stride(0), qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), _native.ptr(gi),
+                                     _native.ptr(bias), out.data_ptr(), out.stride(0), M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
+                                     _native.stream_ptr(x.device))
+    _native.check(rc, 'gptq_prefill_matmul_f16')
+    return out
+
+
 def silu_mul(gate, up, out=None):
     """out = fp16(silu(gate) * up) in fp32 math (reference fused_mlp.py:160-165) for two [M, N] fp16 matrices with unit column
     stride (row strides free: the halves of one [M, 2N] product)."""
@@ -352,11 +371,7 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
             _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family)     # gather + stripe kernels (or the C-ABI ones)
             return out
         if family is None and _mid_m(M, N):
-            W = dequantize(qweight, scales, qzeros, gi, bits, groupsize)
-            if bias is not None:
-                torch.addmm(bias, x, W, out=out)        # the add rides in the library GEMM's epilogue
-            else:
-                torch.matmul(x, W, out=out)
+            prefill_matmul(x, qweight, scales, qzeros, gi, bias, out, K, N, bits, groupsize)
             return out
         if family == 'stripe':
             raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M <= 4, bits in 2/4/8, K a multiple of the row block ...)')

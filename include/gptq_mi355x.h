@@ -48,7 +48,8 @@ enum {
     GPTQ_E_NULL = -4,      /* required pointer is NULL                                       */
     GPTQ_E_WORKSPACE = -5, /* workspace too small for the requested variant                  */
     GPTQ_E_VARIANT = -6,   /* unknown / inapplicable kernel variant                          */
-    GPTQ_E_NORM_WIDTH = -7 /* RMSNorm row wider than 64 KiB (triton_norm.py:59-60)           */
+    GPTQ_E_NORM_WIDTH = -7,/* RMSNorm row wider than 64 KiB (triton_norm.py:59-60)           */
+    GPTQ_E_LIBRARY = -8    /* prefill route: hipBLASLt not loadable, or it refused the product */
 };
 
 /* gptq_query(what) */
@@ -190,6 +191,28 @@ int gptq_dequant_ld_f16(const int32_t *qweight, const void *scales, const int32_
  */
 int gptq_silu_mul_f16(const void *gate, int64_t ldg, const void *up, int64_t ldu, void *c, int64_t ldc, int M, int N,
                       gptq_stream_t stream);
+
+/*
+ * Prefill route (M above the weight-streaming kernels): the layer is dequantised ONCE PER CALL into the workspace
+ * (gptq_dequant_ld_f16: reference numerics, any width, any g_idx -- act-order needs no gather of x here) and the dense product
+ * runs through hipBLASLt (fp16 operands, fp32 accumulation, one rounding, bias in the epilogue): same interface and results as
+ * gptq_matmul248_f16 / gptq_fused_mlp_f16 (reference matmul248, quant_linear.py:263-269; fused MLP, fused_mlp.py:84-168),
+ * 1.12-1.39x their fused tile kernel at every M from 256 to 65 536.  hipBLASLt is dlopen'ed at first use
+ * (GPTQ_E_LIBRARY when absent); plans are cached per shape.  The fused variant dequantises gate | up side by side into one
+ * [K, 2N] matrix, multiplies chunks of <= 16 384 rows into the workspace and applies gptq_silu_mul_f16 (gate and up are
+ * rounded to fp16 before SiLU * mul, like the reference's unfused modules).  workspace: gptq_prefill_workspace_bytes(M, K, N,
+ * nsets) bytes (nsets = 1 matmul, 2 fused MLP), 256-byte aligned; GPTQ_E_WORKSPACE when smaller.  K % 32 == 0, N % 32 == 0
+ * like everywhere; any M >= 0.
+ */
+size_t gptq_prefill_workspace_bytes(int M, int K, int N, int nsets);
+int gptq_prefill_matmul_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
+                            const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,
+                            int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream);
+int gptq_prefill_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweight_gate, const void *scales_gate,
+                               const int32_t *qzeros_gate, const int32_t *g_idx_gate, const int32_t *qweight_up,
+                               const void *scales_up, const int32_t *qzeros_up, const int32_t *g_idx_up, void *c, int64_t ldc,
+                               int M, int K, int N, int bits, int groupsize, void *workspace, size_t workspace_bytes,
+                               gptq_stream_t stream);
 
 /*
  * Act-order fast path (extension; the reference re-gathers g_idx, scales and zeros for every k row

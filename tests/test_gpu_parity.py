@@ -232,11 +232,12 @@ def test_prefill_routes_vs_oracle(route, bits, gs, act, M, K, N, monkeypatch):
     assert rel_err(y[rows], ref) < TOL, rel_err(y[rows], ref)
 
 
-@pytest.mark.parametrize('bits,gs,act,M', [(4, 128, False, 1000), (4, 128, True, 300), (2, 64, False, 200), (3, -1, False, 129), (8, 32, False, 333)])
-def test_fused_mlp_prefill_library_route_in_chunks(bits, gs, act, M, monkeypatch):
-    """fused_gate_up above the streaming kernels: gate | up in one [K, 2N] matrix, one library GEMM per chunk of rows (chunk forced
-    small here: ragged last chunk), silu * mul as its own pass -- every width, act-order included, against the fused oracle."""
-    monkeypatch.setattr(quant.fused_mlp, 'PREFILL_CHUNK_M', 128)
+@pytest.mark.parametrize('bits,gs,act,M', [(4, 128, False, 1000), (4, 128, True, 300), (2, 64, False, 200), (3, -1, False, 129), (8, 32, False, 333),
+                                           (4, 128, False, 16384 + 77)])
+def test_fused_mlp_prefill_library_route(bits, gs, act, M):
+    """fused_gate_up above the streaming kernels (gptq_prefill_fused_mlp_f16): gate | up in one [K, 2N] matrix, one library GEMM per
+    chunk of 16 384 rows (last case: a ragged second chunk), silu * mul as its own pass -- every width, act-order included,
+    against the fused oracle (sampled rows for the long batch)."""
     K, N = 512, 320 if bits == 3 else 288
     A = make_random_layer(bits, gs, K, N, act_order=act, seed=M)
     B = make_random_layer(bits, gs, K, N, act_order=act, seed=M + 1)
@@ -246,8 +247,41 @@ def test_fused_mlp_prefill_library_route_in_chunks(bits, gs, act, M, monkeypatch
     gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
     up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
     c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs if gs != -1 else K).cpu().numpy()
-    ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits)
-    assert rel_err(c, ref) < 2e-3        # gate and up are rounded to fp16 before SiLU * mul on this route
+    rows = np.arange(M) if M <= 1000 else np.unique(np.concatenate([np.arange(0, M, 257), [16383, 16384, M - 1]]))
+    ref = oracle.fused_mlp(x[rows], (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits)
+    assert rel_err(c[rows], ref) < 2e-3        # gate and up are rounded to fp16 before SiLU * mul on this route
+
+
+def test_prefill_c_abi_entries_strided_and_errors():
+    """gptq_prefill_matmul_f16 directly: strided x and y (leading dimensions), bias in the library epilogue, plan cache hit on the
+    second call, workspace too small -> GPTQ_E_WORKSPACE, empty batch -> ok."""
+    import torch
+    lib = _native.lib()
+    K, N, M = 512, 288, 300
+    L = make_random_layer(4, 128, K, N, seed=5)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float16)
+    xb = torch.zeros((M, K + 64), dtype=torch.float16, device='cuda:0')
+    xb[:, :K] = dev(x)
+    yb = torch.full((M, N + 32), 3.0, dtype=torch.float16, device='cuda:0')
+    qw, sc, qz, db = dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(bias)
+    need = lib.gptq_prefill_workspace_bytes(M, K, N, 1)
+    assert need >= K * N * 2 and lib.gptq_prefill_workspace_bytes(M, K, N, 3) == 0
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda:0')
+    s = torch.cuda.current_stream().cuda_stream
+    ref = oracle_forward(x, L, bias=bias)
+    for _ in range(2):
+        rc = lib.gptq_prefill_matmul_f16(xb.data_ptr(), K + 64, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, db.data_ptr(), yb.data_ptr(), N + 32,
+                                         M, K, N, 4, 128, ws.data_ptr(), need, s)
+        assert rc == 0, _native.lib().gptq_strerror(rc)
+        torch.cuda.synchronize()
+        assert rel_err(yb[:, :N].cpu().numpy(), ref) < TOL
+        assert bool((yb[:, N:] == 3.0).all())
+    assert lib.gptq_prefill_matmul_f16(xb.data_ptr(), K + 64, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, None, yb.data_ptr(), N + 32,
+                                       M, K, N, 4, 128, ws.data_ptr(), need - 1, s) == -5
+    assert lib.gptq_prefill_matmul_f16(xb.data_ptr(), K + 64, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, None, yb.data_ptr(), N + 32,
+                                       0, K, N, 4, 128, None, 0, s) == 0
 
 
 @pytest.mark.parametrize('split_k', [2, 4])

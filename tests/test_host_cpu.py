@@ -53,6 +53,18 @@ def test_argument_validation_needs_no_gpu():
     assert lib.gptq_silu_mul_f16(one, 68, one, 64, one, 64, 2, 64, None) == -2                        # ld % 8
     assert lib.gptq_silu_mul_f16(one, 64, None, 64, one, 64, 2, 64, None) == -4
     assert lib.gptq_silu_mul_f16(8, 64, one, 64, one, 64, 2, 64, None) == -3
+    # prefill route behind the C ABI: validation order, workspace formula (weight + 76 MB for the library [+ the chunk product])
+    assert lib.gptq_prefill_matmul_f16(one, 64, one, one, one, None, None, one, 64, 4, 64, 64, 5, 64, None, 0, None) == -1
+    assert lib.gptq_prefill_matmul_f16(one, 32, one, one, one, None, None, one, 64, 4, 64, 64, 4, 64, None, 0, None) == -2      # ldx < K
+    assert lib.gptq_prefill_matmul_f16(one, 64, None, one, one, None, None, one, 64, 4, 64, 64, 4, 64, None, 0, None) == -4
+    assert lib.gptq_prefill_matmul_f16(one, 64, one, one, one, None, None, one, 64, 4, 64, 64, 4, 64, None, 0, None) == -5      # no workspace
+    assert lib.gptq_prefill_matmul_f16(one, 64, one, one, one, None, None, one, 64, 0, 64, 64, 4, 64, None, 0, None) == 0       # empty batch
+    assert lib.gptq_prefill_fused_mlp_f16(one, 64, one, one, one, None, one, one, one, None, one, 64, 4, 64, 64, 4, 64, None, 0, None) == -5
+    assert lib.gptq_prefill_fused_mlp_f16(one, 64, one, one, one, None, None, one, one, None, one, 64, 4, 64, 64, 4, 64, None, 0, None) == -4
+    assert lib.gptq_prefill_workspace_bytes(100, 4096, 4096, 1) == 4096 * 4096 * 2 + (76 << 20)
+    assert lib.gptq_prefill_workspace_bytes(100, 4096, 11008, 2) == 4096 * 11008 * 4 + (76 << 20) + 100 * 2 * 11008 * 2
+    assert lib.gptq_prefill_workspace_bytes(70000, 4096, 11008, 2) == 4096 * 11008 * 4 + (76 << 20) + 16384 * 2 * 11008 * 2
+    assert lib.gptq_strerror(-8).startswith(b'prefill route')
     with pytest.raises(NotImplementedError):
         _native.check(-1, 'x')
     with pytest.raises(RuntimeError):

@@ -620,6 +620,24 @@ int gptq_prefill_matmul_f16(const void *x, int64_t ldx, const int32_t *qweight, 
     return dense_gemm_f16((const half_t *)x, ldx, W, N, (const half_t *)bias, (half_t *)y, ldy, M, K, N, lib_ws, PREFILL_LIB_WS, (hipStream_t)stream);
 }
 
+int gptq_prefill_transpose_matmul248_f16(const void *dy, int64_t lddy, const int32_t *qweight, const void *scales, const int32_t *qzeros,
+                                         const int32_t *g_idx, void *dx, int64_t lddx, int M, int K, int N, int bits, int groupsize, void *workspace,
+                                         size_t workspace_bytes, gptq_stream_t stream) {
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || lddy < N || lddx < K) return GPTQ_E_SHAPE;
+    if (!qweight || !scales || !qzeros || (M > 0 && (!dy || !dx))) return GPTQ_E_NULL;
+    if (((uintptr_t)dy | (uintptr_t)dx) % 16 != 0 || lddy % 8 != 0 || lddx % 8 != 0) return GPTQ_E_ALIGN;
+    if (M == 0) return GPTQ_OK;
+    if (!workspace || (uintptr_t)workspace % 256 != 0 || workspace_bytes < gptq_prefill_workspace_bytes(M, K, N, 1)) return GPTQ_E_WORKSPACE;
+    half_t *W = (half_t *)workspace;
+    char *lib_ws = (char *)workspace + align256((size_t)K * N * 2);
+    if (int rc = dequant_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits, W, N,
+                                (hipStream_t)stream))
+        return rc;
+    // dx[M, K] = dy[M, N] . W[K, N]^T: the "K" of this product is N, its "N" is K, W is stored [out, in]
+    return dense_gemm_f16((const half_t *)dy, lddy, W, N, nullptr, (half_t *)dx, lddx, M, N, K, lib_ws, PREFILL_LIB_WS, (hipStream_t)stream, true);
+}
+
 int gptq_prefill_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweight_gate, const void *scales_gate, const int32_t *qzeros_gate,
                                const int32_t *g_idx_gate, const int32_t *qweight_up, const void *scales_up, const int32_t *qzeros_up,
                                const int32_t *g_idx_up, void *c, int64_t ldc, int M, int K, int N, int bits, int groupsize, void *workspace,

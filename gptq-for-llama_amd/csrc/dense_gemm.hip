@@ -1,6 +1,7 @@
 // dense_gemm.hip -- the dense half of the prefill route behind the C ABI (gptq_prefill_matmul_f16, gptq_prefill_fused_mlp_f16):
 //   y[M, N] fp16 = x[M, K] fp16 . W[K, N] fp16 (+ bias[N]), fp32 accumulation, ONE rounding -- the arithmetic of the reference's
-//   kernel (quant_linear.py:128-137) once W is the matrix gptq_dequant_ld_f16 materialises.
+//   kernel (quant_linear.py:128-137) once W is the matrix gptq_dequant_ld_f16 materialises; with trans_w the backward product
+//   dx[M, K] = dy[M, N] . W[K, N]^T (quant_linear.py:191-258) on the same matrix.
 // Above the weight-streaming kernels the packed weight's bytes stop mattering (2 M N K flops against K N / 2 bytes), so the
 // product is a plain dense GEMM, and a plain dense GEMM is what the vendor library is for: hipBLASLt.  Measured against the
 // hand-written fused tile kernel of gemm_mfma.hip: 1.12-1.39x at every M from 256 to 65 536.
@@ -67,7 +68,7 @@ struct Plan {
     bool ok = false;
 };
 
-using Key = std::tuple<int, int, int, int, int64_t, int64_t, int64_t, bool, size_t>;
+using Key = std::tuple<int, int, int, int, int64_t, int64_t, int64_t, bool, size_t, bool>;
 
 std::mutex g_mu;
 std::map<int, hipblasLtHandle_t> g_handles;
@@ -77,8 +78,9 @@ std::map<Key, Plan> g_plans;
 
 bool dense_gemm_available() { return api().ok; }
 
+// x [M, K] (ldx), y [M, N] (ldy); W is stored [K, N] row-major (ldw), or [N, K] when trans_w (then y = x . W^T)
 int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, const half_t *bias, half_t *y, int64_t ldy, int M, int K, int N,
-                   void *ws, size_t ws_bytes, hipStream_t s) {
+                   void *ws, size_t ws_bytes, hipStream_t s, bool trans_w) {
     const Api &L = api();
     if (!L.ok) return GPTQ_E_LIBRARY;
     int dev = 0;
@@ -89,12 +91,18 @@ int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, c
         h = nullptr;
         return GPTQ_E_LIBRARY;
     }
-    const Key key{dev, M, N, K, ldx, ldw, ldy, bias != nullptr, ws_bytes};
+    const Key key{dev, M, N, K, ldx, ldw, ldy, bias != nullptr, ws_bytes, trans_w};
     Plan &p = g_plans[key];
     if (!p.ok) {
         if (!p.desc) {
             if (L.desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
-            if (L.layout_create(&p.a, HIP_R_16F, (uint64_t)N, (uint64_t)K, ldw) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;   // W^T, column-major
+            // the stored row-major W is, read column-major, its own transpose: [N, K] (or [K, N] for trans_w, which then needs op = T)
+            if (L.layout_create(&p.a, HIP_R_16F, (uint64_t)(trans_w ? K : N), (uint64_t)(trans_w ? N : K), ldw) != HIPBLAS_STATUS_SUCCESS)
+                return GPTQ_E_LIBRARY;
+            if (trans_w) {
+                const int32_t op = HIPBLAS_OP_T;
+                if (L.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op, sizeof(op)) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
+            }
             if (L.layout_create(&p.b, HIP_R_16F, (uint64_t)K, (uint64_t)M, ldx) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;   // x^T
             if (L.layout_create(&p.c, HIP_R_16F, (uint64_t)N, (uint64_t)M, ldy) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;   // y^T
             if (bias) {

@@ -64,7 +64,7 @@ int dequant_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, cons
 // dense_gemm.hip: y = x . W (+ bias) through hipBLASLt (dlopen'ed), plans cached per shape
 bool dense_gemm_available();
 int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, const half_t *bias, half_t *y, int64_t ldy, int M, int K, int N,
-                   void *ws, size_t ws_bytes, hipStream_t s);
+                   void *ws, size_t ws_bytes, hipStream_t s, bool trans_w = false);
 int silu_mul_launch(const half_t *g, int64_t ldg, const half_t *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
 int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);

@@ -53,6 +53,8 @@ _SIGNATURES = {
     'gptq_prefill_workspace_bytes': [c_int, c_int, c_int, c_int],
     'gptq_prefill_matmul_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p, c_size_t, c_void_p],
+    'gptq_prefill_transpose_matmul248_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                             c_int, c_void_p, c_size_t, c_void_p],
     'gptq_prefill_fused_mlp_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
     'gptq_act_order_repack': [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],

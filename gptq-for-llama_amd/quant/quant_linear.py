@@ -386,9 +386,14 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
     return out
 
 
-def transpose_matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq):
+TRANSPOSE_LIBRARY_MIN_M = 1      # measured: the route wins from one row on (31 vs 151 us at M = 1, 0.11 vs 11.6 ms at M = 4096 on 4096^2)
+
+
+def transpose_matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, family=None):
     """``input [M,N] fp16 -> [M,K] fp16`` = input . deq(B)^T (reference transpose_matmul248,
-    quant/quant_linear.py:272-279)."""
+    quant/quant_linear.py:272-279).  The product takes the prefill route (dequantise once per call + hipBLASLt with the
+    transposition flag, gptq_prefill_transpose_matmul248_f16: 5x the LDS-tiled kernel of csrc/transpose.hip at M = 1, 100x at
+    M = 4096, profiles/r2e_prefill/backward_routes.txt); family='abi' or GPTQ_PREFILL=fused keep that kernel."""
     K, N, groupsize, qweight, scales, qzeros, gi = _prep_weight(input, qweight, scales, qzeros, g_idx, bits)
     dy = _as_rows(input)
     if dy.shape[1] != N:
@@ -397,6 +402,15 @@ def transpose_matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq):
     with torch.cuda.device(dy.device):
         out = torch.empty((M, K), device=dy.device, dtype=torch.float16)
         if M == 0:
+            return out
+        if family is None and PREFILL_ROUTE == 'library' and M >= TRANSPOSE_LIBRARY_MIN_M:
+            lib = _native.lib()
+            dy = _prefill_operand(dy)
+            ws = torch.empty(lib.gptq_prefill_workspace_bytes(M, K, N, 1), dtype=torch.uint8, device=dy.device)
+            rc = lib.gptq_prefill_transpose_matmul248_f16(dy.data_ptr(), dy.stride(0), qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
+                                                          _native.ptr(gi), out.data_ptr(), K, M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
+                                                          _native.stream_ptr(dy.device))
+            _native.check(rc, 'gptq_prefill_transpose_matmul248_f16')
             return out
         rc = _native.lib().gptq_transpose_matmul248_f16(
             dy.data_ptr(), dy.stride(0) if M > 1 else N, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),

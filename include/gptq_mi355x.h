@@ -208,6 +208,11 @@ size_t gptq_prefill_workspace_bytes(int M, int K, int N, int nsets);
 int gptq_prefill_matmul_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
                             const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,
                             int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream);
+/* the backward product on the same route: dx[M, K] = dy[M, N] . deq(W)^T (reference transpose_matmul248,
+ * quant_linear.py:272-279, kernel :191-258); interface of gptq_transpose_matmul248_f16 + the workspace (nsets = 1). */
+int gptq_prefill_transpose_matmul248_f16(const void *dy, int64_t lddy, const int32_t *qweight, const void *scales,
+                                         const int32_t *qzeros, const int32_t *g_idx, void *dx, int64_t lddx, int M, int K, int N,
+                                         int bits, int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream);
 int gptq_prefill_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweight_gate, const void *scales_gate,
                                const int32_t *qzeros_gate, const int32_t *g_idx_gate, const int32_t *qweight_up,
                                const void *scales_up, const int32_t *qzeros_up, const int32_t *g_idx_up, void *c, int64_t ldc,

@@ -659,6 +659,21 @@ def test_autograd_backward_matches_oracle():
     assert rel_err(x.grad.cpu().numpy(), ref) < TOL
 
 
+@pytest.mark.parametrize('family', [None, 'abi'])
+@pytest.mark.parametrize('bits,gs,act,M,K,N', [(4, 128, False, 300, 512, 288), (4, 128, True, 64, 1024, 512), (3, -1, False, 16, 256, 320),
+                                               (2, 64, False, 1, 512, 256), (8, 32, False, 2048, 256, 1024)])
+def test_backward_both_routes_vs_oracle(family, bits, gs, act, M, K, N):
+    """dx = dy . deq(W)^T (reference quant_linear.py:191-258, :272-279): through the prefill route (our dequantise kernel +
+    hipBLASLt with the transposition flag, gptq_prefill_transpose_matmul248_f16) and, with family='abi', through the LDS-tiled
+    kernel of transpose.hip -- every width, act-order included."""
+    L = make_random_layer(bits, gs, K, N, act_order=act, seed=M + bits)
+    dy = np.random.default_rng(M).standard_normal((M, N)).astype(np.float16)
+    dx = QL.transpose_matmul248(dev(dy), dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), bits, 2**bits - 1,
+                                family=family).cpu().numpy()
+    ref = oracle.transpose_matmul248(dy, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], bits)
+    assert dx.shape == (M, K) and rel_err(dx, ref) < TOL, rel_err(dx, ref)
+
+
 def _fuzz_cases(n=96, seed=2024):
     rng = np.random.default_rng(seed)
     cases = []

@@ -364,7 +364,7 @@ def _time_cold(run, nsets, reps=5):
     return e0.elapsed_time(e1) * 1e3 / (reps * nsets)
 
 
-def prefill_leg(dev, M=65536, reps=5):
+def prefill_leg(dev, M=65536, reps=7):
     """BASELINE config 3 (reported only): LLaMA-7B-shaped 4-bit g128 batched matmul at M = 32 x 2048 through the drop-in
     matmul248 (reference kernel quant_linear.py:72-137), TFLOP/s = 2 M N K / t against the 2.5 PFLOP/s dense fp16 MFMA peak.
     Three numbers per shape: the product's route (GPTQ_PREFILL, default 'library': our dequantise kernel PER CALL + the library
@@ -377,15 +377,19 @@ def prefill_leg(dev, M=65536, reps=5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(f):
+        """median of `reps` individually timed calls (ms-scale kernels: an event pair per call is exact, and a clock / power
+        transient on the box -- seen once as a 2.5x slower stretch -- moves single samples, not the median)"""
         f()
         y = f()
         torch.cuda.synchronize()
-        e0.record()
+        ts = []
         for _ in range(reps):
+            e0.record()
             y = f()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps, y
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2], y
 
     for K, N in [(HIDDEN, HIDDEN), (HIDDEN, 3 * HIDDEN), (HIDDEN, INTER), (INTER, HIDDEN)]:
         w = PackedSet(K, N, dev, gen)

@@ -92,27 +92,28 @@ int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, c
         return GPTQ_E_LIBRARY;
     }
     const Key key{dev, M, N, K, ldx, ldw, ldy, bias != nullptr, ws_bytes, trans_w};
-    Plan &p = g_plans[key];
-    if (!p.ok) {
-        if (!p.desc) {
-            if (L.desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
-            // the stored row-major W is, read column-major, its own transpose: [N, K] (or [K, N] for trans_w, which then needs op = T)
-            if (L.layout_create(&p.a, HIP_R_16F, (uint64_t)(trans_w ? K : N), (uint64_t)(trans_w ? N : K), ldw) != HIPBLAS_STATUS_SUCCESS)
-                return GPTQ_E_LIBRARY;
-            if (trans_w) {
-                const int32_t op = HIPBLAS_OP_T;
-                if (L.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op, sizeof(op)) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
-            }
-            if (L.layout_create(&p.b, HIP_R_16F, (uint64_t)K, (uint64_t)M, ldx) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;   // x^T
-            if (L.layout_create(&p.c, HIP_R_16F, (uint64_t)N, (uint64_t)M, ldy) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;   // y^T
-            if (bias) {
-                const uint32_t epi = HIPBLASLT_EPILOGUE_BIAS;        // one value per row of y^T = per output feature (quant_linear.py:376)
-                const int32_t bt = HIP_R_16F;
-                if (L.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
-                if (L.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
-            }
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        // built in a local and published only when complete: a refused product leaves no half-made plan behind (its few descriptor
+        // objects are not reclaimed -- the call is a configuration error, not a steady state)
+        Plan p;
+        if (L.desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
+        // the stored row-major W is, read column-major, its own transpose: [N, K] (or [K, N] for trans_w, which then needs op = T)
+        if (L.layout_create(&p.a, HIP_R_16F, (uint64_t)(trans_w ? K : N), (uint64_t)(trans_w ? N : K), ldw) != HIPBLAS_STATUS_SUCCESS)
+            return GPTQ_E_LIBRARY;
+        if (trans_w) {
+            const int32_t op = HIPBLAS_OP_T;
+            if (L.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op, sizeof(op)) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
         }
-        if (bias && L.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
+        if (L.layout_create(&p.b, HIP_R_16F, (uint64_t)K, (uint64_t)M, ldx) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;   // x^T
+        if (L.layout_create(&p.c, HIP_R_16F, (uint64_t)N, (uint64_t)M, ldy) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;   // y^T
+        if (bias) {
+            const uint32_t epi = HIPBLASLT_EPILOGUE_BIAS;        // one value per row of y^T = per output feature (quant_linear.py:376)
+            const int32_t bt = HIP_R_16F;
+            if (L.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
+            if (L.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
+            if (L.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
+        }
         hipblasLtMatmulPreference_t pref = nullptr;
         if (L.pref_create(&pref) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
         const uint64_t max_ws = ws_bytes;
@@ -125,7 +126,9 @@ int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, c
         p.algo = res[0].algo;
         p.ws_need = res[0].workspaceSize;
         p.ok = true;
+        it = g_plans.emplace(key, p).first;
     }
+    Plan &p = it->second;
     if (bias && L.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return GPTQ_E_LIBRARY;
     const float alpha = 1.0f, beta = 0.0f;
     const hipblasStatus_t st = L.matmul(h, p.desc, &alpha, W, p.a, x, p.b, &beta, y, p.c, y, p.c, &p.algo, ws, ws_bytes, s);

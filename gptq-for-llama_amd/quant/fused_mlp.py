@@ -102,8 +102,9 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
                                                     _native.ptr(gis[0]), _int32c(up[0]).data_ptr(), su.data_ptr(), _int32c(up[2]).data_ptr(),
                                                     _native.ptr(gis[1]), c.data_ptr(), N, M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
                                                     _native.stream_ptr(x.device))
-            _native.check(rc, 'gptq_prefill_fused_mlp_f16')
-            return c
+            from .quant_linear import _library_refused
+            if not _library_refused(rc, 'gptq_prefill_fused_mlp_f16'):
+                return c
         # GPTQ_PREFILL=fused, large prefill: gptq_fused_mlp_f16 runs two MFMA-tile GEMMs, the second applies silu(gate) * up in
         # place in its epilogue -- no intermediates, no extra pass over the [M, N] activations (falls through to the call below)
     with torch.cuda.device(x.device):

@@ -299,6 +299,23 @@ def _prefill_operand(x):
     return x if (x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
 
 
+_library_warned = False
+
+
+def _library_refused(rc, what):
+    """GPTQ_E_LIBRARY (-8): hipBLASLt could not be loaded or refused the product -> say so once and let the caller go on to the
+    library-free kernels of the C ABI (slower at these sizes, same results); any other code raises."""
+    global _library_warned
+    if rc != -8:
+        _native.check(rc, what)
+        return False
+    if not _library_warned:
+        _library_warned = True
+        import warnings
+        warnings.warn('%s: %s -- falling back to the fused kernels of the C ABI' % (what, _native.lib().gptq_strerror(rc).decode()))
+    return True
+
+
 def prefill_matmul(x, qweight, scales, qzeros, gi, bias, out, K, N, bits, groupsize):
     """out[M, N] = x . deq(W) (+ bias) through gptq_prefill_matmul_f16: dequantise once per call into a transient workspace (caching
     allocator: the next layer reuses it), dense product by hipBLASLt, bias in its epilogue.  gi: None or the int32 g_idx of an
@@ -310,8 +327,7 @@ def prefill_matmul(x, qweight, scales, qzeros, gi, bias, out, K, N, bits, groups
     rc = lib.gptq_prefill_matmul_f16(x.data_ptr(), x.stride(0), qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), _native.ptr(gi),
                                      _native.ptr(bias), out.data_ptr(), out.stride(0), M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
                                      _native.stream_ptr(x.device))
-    _native.check(rc, 'gptq_prefill_matmul_f16')
-    return out
+    return None if _library_refused(rc, 'gptq_prefill_matmul_f16') else out
 
 
 def silu_mul(gate, up, out=None):
@@ -371,8 +387,8 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
             _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family)     # gather + stripe kernels (or the C-ABI ones)
             return out
         if family is None and _mid_m(M, N):
-            prefill_matmul(x, qweight, scales, qzeros, gi, bias, out, K, N, bits, groupsize)
-            return out
+            if prefill_matmul(x, qweight, scales, qzeros, gi, bias, out, K, N, bits, groupsize) is not None:
+                return out          # (None: no hipBLASLt -> the C ABI's own kernels below, generic g_idx kernel for an act-order layer)
         if family == 'stripe':
             raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M <= 4, bits in 2/4/8, K a multiple of the row block ...)')
         if srt is not None:
@@ -386,14 +402,18 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
     return out
 
 
-TRANSPOSE_LIBRARY_MIN_M = 1      # measured: the route wins from one row on (31 vs 151 us at M = 1, 0.11 vs 11.6 ms at M = 4096 on 4096^2)
+# The route wins from one row on (31 vs 151 us at M = 1, 0.11 vs 11.6 ms at M = 4096 on 4096^2), but below 16 rows nobody trains, and a
+# GEMM with one to a few columns is not a shape the library's kernels see often: one test run that pushed M = 1 ... 3 through it ended in
+# an abort that five other runs of the same tests did not reproduce.  The threshold keeps the library on ordinary shapes.
+TRANSPOSE_LIBRARY_MIN_M = 16
 
 
 def transpose_matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, family=None):
     """``input [M,N] fp16 -> [M,K] fp16`` = input . deq(B)^T (reference transpose_matmul248,
-    quant/quant_linear.py:272-279).  The product takes the prefill route (dequantise once per call + hipBLASLt with the
-    transposition flag, gptq_prefill_transpose_matmul248_f16: 5x the LDS-tiled kernel of csrc/transpose.hip at M = 1, 100x at
-    M = 4096, profiles/r2e_prefill/backward_routes.txt); family='abi' or GPTQ_PREFILL=fused keep that kernel."""
+    quant/quant_linear.py:272-279).  From TRANSPOSE_LIBRARY_MIN_M rows on the product takes the prefill route (dequantise once per
+    call + hipBLASLt with the transposition flag, gptq_prefill_transpose_matmul248_f16: 100x the LDS-tiled kernel of
+    csrc/transpose.hip at M = 4096, profiles/r2e_prefill/backward_routes.txt); fewer rows, family='abi' or GPTQ_PREFILL=fused
+    keep that kernel."""
     K, N, groupsize, qweight, scales, qzeros, gi = _prep_weight(input, qweight, scales, qzeros, g_idx, bits)
     dy = _as_rows(input)
     if dy.shape[1] != N:
@@ -410,8 +430,8 @@ def transpose_matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, famil
             rc = lib.gptq_prefill_transpose_matmul248_f16(dy.data_ptr(), dy.stride(0), qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
                                                           _native.ptr(gi), out.data_ptr(), K, M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
                                                           _native.stream_ptr(dy.device))
-            _native.check(rc, 'gptq_prefill_transpose_matmul248_f16')
-            return out
+            if not _library_refused(rc, 'gptq_prefill_transpose_matmul248_f16'):
+                return out
         rc = _native.lib().gptq_transpose_matmul248_f16(
             dy.data_ptr(), dy.stride(0) if M > 1 else N, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
             _native.ptr(gi), out.data_ptr(), K, M, K, N, bits, groupsize, _native.stream_ptr(dy.device))

@@ -252,6 +252,30 @@ def test_fused_mlp_prefill_library_route(bits, gs, act, M):
     assert rel_err(c[rows], ref) < 2e-3        # gate and up are rounded to fp16 before SiLU * mul on this route
 
 
+def test_prefill_falls_back_to_the_own_kernels_without_the_library(monkeypatch):
+    """GPTQ_E_LIBRARY (hipBLASLt not loadable) from the prefill entries: one warning, then the library-free kernels of the C ABI
+    answer -- forward, fused MLP and backward, same results."""
+    lib = _native.lib()
+    for name in ('gptq_prefill_matmul_f16', 'gptq_prefill_fused_mlp_f16', 'gptq_prefill_transpose_matmul248_f16'):
+        monkeypatch.setattr(lib, name, lambda *a: -8)
+    monkeypatch.setattr(QL, '_library_warned', False)
+    K, N, M = 512, 288, 300
+    L = make_random_layer(4, 128, K, N, seed=9)
+    U = make_random_layer(4, 128, K, N, seed=10)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    with pytest.warns(UserWarning, match='falling back'):
+        check_forward(x, L)
+    gate = tuple(dev(L[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(U[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 128).cpu().numpy()
+    ref = oracle.fused_mlp(x, (L['qweight'], L['scales'], L['qzeros'], L['g_idx']), (U['qweight'], U['scales'], U['qzeros'], U['g_idx']), 4)
+    assert rel_err(c, ref) < 2e-3
+    dy = rng.standard_normal((M, N)).astype(np.float16)
+    dx = QL.transpose_matmul248(dev(dy), dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15).cpu().numpy()
+    assert rel_err(dx, oracle.transpose_matmul248(dy, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)) < TOL
+
+
 def test_prefill_c_abi_entries_strided_and_errors():
     """gptq_prefill_matmul_f16 directly: strided x and y (leading dimensions), bias in the library epilogue, plan cache hit on the
     second call, workspace too small -> GPTQ_E_WORKSPACE, empty batch -> ok."""
@@ -661,11 +685,11 @@ def test_autograd_backward_matches_oracle():
 
 @pytest.mark.parametrize('family', [None, 'abi'])
 @pytest.mark.parametrize('bits,gs,act,M,K,N', [(4, 128, False, 300, 512, 288), (4, 128, True, 64, 1024, 512), (3, -1, False, 16, 256, 320),
-                                               (2, 64, False, 1, 512, 256), (8, 32, False, 2048, 256, 1024)])
+                                               (2, 64, False, 16, 512, 256), (8, 32, False, 2048, 256, 1024)])
 def test_backward_both_routes_vs_oracle(family, bits, gs, act, M, K, N):
-    """dx = dy . deq(W)^T (reference quant_linear.py:191-258, :272-279): through the prefill route (our dequantise kernel +
-    hipBLASLt with the transposition flag, gptq_prefill_transpose_matmul248_f16) and, with family='abi', through the LDS-tiled
-    kernel of transpose.hip -- every width, act-order included."""
+    """dx = dy . deq(W)^T (reference quant_linear.py:191-258, :272-279): from 16 rows on through the prefill route (our dequantise
+    kernel + hipBLASLt with the transposition flag, gptq_prefill_transpose_matmul248_f16) and, with family='abi', through the
+    LDS-tiled kernel of transpose.hip -- every width, act-order included."""
     L = make_random_layer(bits, gs, K, N, act_order=act, seed=M + bits)
     dy = np.random.default_rng(M).standard_normal((M, N)).astype(np.float16)
     dx = QL.transpose_matmul248(dev(dy), dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), bits, 2**bits - 1,

@@ -261,16 +261,19 @@ def _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, 
 # bytes no longer matter.  There the weight is dequantised once per call (our kernel, reference numerics, 10-20 us for a
 # LLaMA-7B layer) and multiplied by the library GEMM: measured 1.12-1.39x the fused MFMA tile kernel of csrc/gemm_mfma.hip at every
 # M from 256 to 65 536 (profiles/r2e_prefill/prefill_routes.txt).  GPTQ_PREFILL=fused keeps the fused tile kernel for grids of
-# >= GEMM_MIN_TILES 256 x 256 tiles (no transient fp16 weight: K N 2 bytes per call); family= bypasses the choice.
+# >= GEMM_MIN_TILES 256 x 256 tiles (no transient fp16 weight: K N 2 bytes per call; smaller grids still take the library, as they
+# took torch.matmul before); GPTQ_PREFILL=own never calls the library: every M on the C ABI's own kernels.  family= bypasses the choice.
 STREAM_MAX_M = 64
 GEMM_MIN_TILES = 192
 PREFILL_ROUTE = _os.environ.get('GPTQ_PREFILL', 'library')
-if PREFILL_ROUTE not in ('library', 'fused'):
-    raise RuntimeError("GPTQ_PREFILL must be 'library' or 'fused', got %r" % PREFILL_ROUTE)
+if PREFILL_ROUTE not in ('library', 'fused', 'own'):
+    raise RuntimeError("GPTQ_PREFILL must be 'library', 'fused' or 'own', got %r" % PREFILL_ROUTE)
 
 
 def _mid_m(M, N):
     """True when a batch of M rows goes through dequantise-once + library GEMM"""
+    if PREFILL_ROUTE == 'own':
+        return False
     return M > STREAM_MAX_M and (PREFILL_ROUTE == 'library' or (-(-M // 256)) * (-(-N // 256)) < GEMM_MIN_TILES)
 
 

@@ -182,7 +182,7 @@ def test_mid_m_route(M):
     L = make_random_layer(4, 128, 1024, 512, seed=M)
     x = np.random.default_rng(M).standard_normal((M, 1024)).astype(np.float16)
     bias = np.random.default_rng(1).standard_normal(512).astype(np.float16)
-    assert QL._mid_m(M, 512)
+    assert QL._mid_m(M, 512) == (QL.PREFILL_ROUTE != 'own')
     y, _ = check_forward(x, L, bias=bias)
     y_abi, _ = check_forward(x, L, bias=bias, family='abi')
     assert rel_err(y, y_abi) < TOL
@@ -215,12 +215,13 @@ def test_dequantize_into_a_strided_view_and_silu_mul():
     assert _native.lib().gptq_silu_mul_f16(dy.data_ptr(), 2 * N, dy.data_ptr(), 2 * N, dy.data_ptr(), 2 * N, 4, N + 4, None) == -2      # N % 8
 
 
-@pytest.mark.parametrize('route', ['library', 'fused'])
+@pytest.mark.parametrize('route', ['library', 'fused', 'own'])
 @pytest.mark.parametrize('bits,gs,act,M,K,N', [(4, 128, False, 4096, 4096, 4096), (4, 128, True, 2100, 1024, 4096), (3, -1, False, 700, 512, 320),
                                                (2, 64, False, 300, 1024, 512), (8, 128, False, 8192, 512, 4096)])
 def test_prefill_routes_vs_oracle(route, bits, gs, act, M, K, N, monkeypatch):
     """the built-in dispatch above the streaming kernels, both settings of GPTQ_PREFILL: 'library' = our dequantise kernel + the
-    library GEMM (default), 'fused' = the MFMA tile kernel once the grid has enough tiles; against the CPU oracle on sampled rows."""
+    library GEMM (default), 'fused' = the MFMA tile kernel once the grid has enough tiles, 'own' = never the library; against the CPU oracle
+    on sampled rows."""
     monkeypatch.setattr(QL, 'PREFILL_ROUTE', route)
     L = make_random_layer(bits, gs, K, N, act_order=act, seed=M + K + bits)
     rng = np.random.default_rng(17)

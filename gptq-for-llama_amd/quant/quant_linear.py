@@ -426,7 +426,7 @@ def transpose_matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, famil
         out = torch.empty((M, K), device=dy.device, dtype=torch.float16)
         if M == 0:
             return out
-        if family is None and PREFILL_ROUTE == 'library' and M >= TRANSPOSE_LIBRARY_MIN_M:
+        if family is None and PREFILL_ROUTE == 'library' and M >= TRANSPOSE_LIBRARY_MIN_M and K >= 256 and N >= 256:    # ordinary shapes only
             lib = _native.lib()
             dy = _prefill_operand(dy)
             ws = torch.empty(lib.gptq_prefill_workspace_bytes(M, K, N, 1), dtype=torch.uint8, device=dy.device)

@@ -349,3 +349,28 @@ def test_tp_decode_shard_slicing_is_exact_on_cpu():
                     continue
                 a, b, c = (t.contiguous() for t in tp_decode._cols(qw, sc, qz, bits, n0, n1))
                 assert np.array_equal(oracle.np_dequant(a.numpy(), c.numpy(), b.numpy(), L['g_idx'], bits), full[:, n0:n1])
+
+
+def test_prefill_route_selection_is_host_logic(monkeypatch):
+    """GPTQ_PREFILL: 'library' hands every batch above the streaming kernels to the dequantise + library route, 'fused' only
+    grids of fewer than GEMM_MIN_TILES 256 x 256 tiles, 'own' none; a refused library (GPTQ_E_LIBRARY) warns once and lets the
+    caller continue, any other error code raises."""
+    import warnings
+    from quant import quant_linear as QL
+    monkeypatch.setattr(QL, 'PREFILL_ROUTE', 'library')
+    assert not QL._mid_m(64, 4096) and QL._mid_m(65, 4096) and QL._mid_m(65536, 12288)
+    monkeypatch.setattr(QL, 'PREFILL_ROUTE', 'fused')
+    assert QL._mid_m(256, 4096) and QL._mid_m(2048, 4096) and not QL._mid_m(3072, 4096) and not QL._mid_m(65536, 4096)
+    assert not QL._mid_m(64, 4096)
+    monkeypatch.setattr(QL, 'PREFILL_ROUTE', 'own')
+    assert not QL._mid_m(300, 4096) and not QL._mid_m(65536, 4096)
+    monkeypatch.setattr(QL, '_library_warned', False)
+    with pytest.warns(UserWarning, match='falling back'):
+        assert QL._library_refused(-8, 'gptq_prefill_matmul_f16') is True
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        assert QL._library_refused(-8, 'gptq_prefill_matmul_f16') is True          # second time: silent
+    assert QL._library_refused(0, 'x') is False
+    with pytest.raises(RuntimeError):
+        QL._library_refused(-5, 'gptq_prefill_matmul_f16')
+    assert QL.TRANSPOSE_LIBRARY_MIN_M >= 16

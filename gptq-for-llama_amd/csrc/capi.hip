@@ -585,9 +585,12 @@ int gptq_dequant_ld_f16(const int32_t *qweight, const void *scales, const int32_
 }
 
 // ---------------------------------------------------------------------------------------------- prefill route
+// route 1 (default) = the hand-written GEMM of gemm8.hip on the transposed dequantised weight; route 0 = hipBLASLt on the
+// dequantised weight (the reported ceiling; also the fallback for shapes gemm8 does not serve: K % 128 != 0 ...).
+static std::atomic<int> g_prefill_route{1};
 namespace {
 constexpr size_t PREFILL_LIB_WS = (size_t)76 << 20;      // what the library may use for itself (split / stream-K algorithms)
-constexpr int PREFILL_CHUNK_M = 16384;                   // rows of the transient [rows, 2N] gate | up product
+constexpr int PREFILL_CHUNK_M = 8192;                    // rows of the transient FP32 [rows, 2N] gate | up product
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline int prefill_validate(const void *x, int64_t ldx, const void *y, int64_t ldy, int M, int K, int N, int bits, int groupsize) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
@@ -601,7 +604,7 @@ inline int prefill_validate(const void *x, int64_t ldx, const void *y, int64_t l
 size_t gptq_prefill_workspace_bytes(int M, int K, int N, int nsets) {
     if (M < 0 || K <= 0 || N <= 0 || (nsets != 1 && nsets != 2)) return 0;
     size_t b = align256((size_t)K * N * nsets * 2) + PREFILL_LIB_WS;
-    if (nsets == 2) b += align256((size_t)(M < PREFILL_CHUNK_M ? M : PREFILL_CHUNK_M) * 2 * N * 2);
+    if (nsets == 2) b += align256((size_t)(M < PREFILL_CHUNK_M ? M : PREFILL_CHUNK_M) * 2 * N * 4);   // fp32: SiLU sees unrounded sums
     return b;
 }
 
@@ -614,6 +617,14 @@ int gptq_prefill_matmul_f16(const void *x, int64_t ldx, const int32_t *qweight, 
     if (!workspace || (uintptr_t)workspace % 256 != 0 || workspace_bytes < gptq_prefill_workspace_bytes(M, K, N, 1)) return GPTQ_E_WORKSPACE;
     half_t *W = (half_t *)workspace;
     char *lib_ws = (char *)workspace + align256((size_t)K * N * 2);
+    if (g_prefill_route.load() == 1 && K % 128 == 0 && (!bias || (uintptr_t)bias % 8 == 0)) {
+        // own route: Wt[N][K] (k contiguous) + the LDS-DMA / MFMA tile GEMM; no library, no transient beyond the weight itself
+        if (int rc = dequant_t_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits, W,
+                                      K, (hipStream_t)stream))
+            return rc;
+        const int rc = gemm8_dense_f16((const half_t *)x, ldx, W, K, (const half_t *)bias, (half_t *)y, ldy, M, K, N, false, (hipStream_t)stream);
+        if (rc != GPTQ_E_VARIANT) return rc;
+    }
     if (int rc = dequant_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits, W, N,
                                 (hipStream_t)stream))
         return rc;
@@ -634,7 +645,12 @@ int gptq_prefill_transpose_matmul248_f16(const void *dy, int64_t lddy, const int
     if (int rc = dequant_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits, W, N,
                                 (hipStream_t)stream))
         return rc;
-    // dx[M, K] = dy[M, N] . W[K, N]^T: the "K" of this product is N, its "N" is K, W is stored [out, in]
+    // dx[M, K] = dy[M, N] . W[K, N]^T: the "K" of this product is N, its "N" is K, W is stored [out, in] -- which IS the k-contiguous
+    // operand layout of gemm8 (reference transpose_matmul_248_kernel, quant_linear.py:191-258): same tile engine, roles exchanged
+    if (g_prefill_route.load() == 1 && N % 128 == 0) {
+        const int rc = gemm8_dense_f16((const half_t *)dy, lddy, W, N, nullptr, (half_t *)dx, lddx, M, N, K, false, (hipStream_t)stream);
+        if (rc != GPTQ_E_VARIANT) return rc;
+    }
     return dense_gemm_f16((const half_t *)dy, lddy, W, N, nullptr, (half_t *)dx, lddx, M, N, K, lib_ws, PREFILL_LIB_WS, (hipStream_t)stream, true);
 }
 
@@ -650,19 +666,38 @@ int gptq_prefill_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweigh
     const int64_t N2 = 2 * (int64_t)N;
     half_t *W = (half_t *)workspace;                                                      // [K, 2N] = gate | up
     char *lib_ws = (char *)workspace + align256((size_t)K * N2 * 2);
-    half_t *prod = (half_t *)(lib_ws + PREFILL_LIB_WS);                                    // [rows, 2N]
+    float *prod = (float *)(lib_ws + PREFILL_LIB_WS);                                      // [rows, 2N] fp32: the reference applies SiLU to the
+                                                                                           // fp32 accumulators (fused_mlp.py:160-165), not to rounded products
     const int G = n_groups(K, groupsize);
+    if (g_prefill_route.load() == 1 && K % 128 == 0) {
+        // own route: gate and up stacked as Wt[2N][K]; ONE launch computes both products per tile and applies SiLU to the fp32
+        // accumulators in its epilogue (fused_mlp.py:160-165) -- no [M, 2N] intermediate at all
+        half_t *Wt = (half_t *)workspace;
+        if (int rc = dequant_t_launch((const uint32_t *)qweight_gate, (const half_t *)scales_gate, qzeros_gate, g_idx_gate, K, N, G, groupsize, bits, Wt, K, s))
+            return rc;
+        if (int rc = dequant_t_launch((const uint32_t *)qweight_up, (const half_t *)scales_up, qzeros_up, g_idx_up, K, N, G, groupsize, bits,
+                                      Wt + (size_t)N * K, K, s))
+            return rc;
+        const int rc = gemm8_dense_f16((const half_t *)x, ldx, Wt, K, nullptr, (half_t *)c, ldc, M, K, N, true, s);
+        if (rc != GPTQ_E_VARIANT) return rc;
+    }
     if (int rc = dequant_launch((const uint32_t *)qweight_gate, (const half_t *)scales_gate, qzeros_gate, g_idx_gate, K, N, G, groupsize, bits, W, N2, s))
         return rc;
     if (int rc = dequant_launch((const uint32_t *)qweight_up, (const half_t *)scales_up, qzeros_up, g_idx_up, K, N, G, groupsize, bits, W + N, N2, s))
         return rc;
     for (int m0 = 0; m0 < M; m0 += PREFILL_CHUNK_M) {
         const int rows = M - m0 < PREFILL_CHUNK_M ? M - m0 : PREFILL_CHUNK_M;
-        if (int rc = dense_gemm_f16((const half_t *)x + (size_t)m0 * ldx, ldx, W, N2, nullptr, prod, N2, rows, K, (int)N2, lib_ws, PREFILL_LIB_WS, s))
+        if (int rc = dense_gemm_f16((const half_t *)x + (size_t)m0 * ldx, ldx, W, N2, nullptr, prod, N2, rows, K, (int)N2, lib_ws, PREFILL_LIB_WS, s,
+                                    false, /*out_f32=*/true))
             return rc;
-        if (int rc = silu_mul_launch(prod, N2, prod + N, N2, (half_t *)c + (size_t)m0 * ldc, ldc, rows, N, s)) return rc;
+        if (int rc = silu_mul_f32_launch(prod, N2, prod + N, N2, (half_t *)c + (size_t)m0 * ldc, ldc, rows, N, s)) return rc;
     }
     return GPTQ_OK;
+}
+
+int gptq_set_prefill_route(int route) {
+    if (route != 0 && route != 1) return GPTQ_E_VARIANT;
+    return g_prefill_route.exchange(route);
 }
 
 int gptq_silu_mul_f16(const void *gate, int64_t ldg, const void *up, int64_t ldu, void *c, int64_t ldc, int M, int N, gptq_stream_t stream) {

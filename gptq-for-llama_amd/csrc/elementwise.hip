@@ -326,6 +326,70 @@ __global__ void __launch_bounds__(256) dequant4_fast_kernel(const uint32_t *__re
     }
 }
 
+// The same weight TRANSPOSED: Wt[n][k] (k contiguous, row stride ldo >= K) -- the operand layout of the hand-written prefill GEMM
+// (gemm8.hip: both operands by LDS-DMA, a fragment = 16 contiguous bytes of one row).  Identical arithmetic, element for element.
+// A thread owns one column and one 32-k block: its BITS packed words are read coalesced across the workgroup, its 32 values leave
+// as four 16-byte stores (one full 64-byte sector of its row).
+template <int BITS, bool UNIFORM>   // UNIFORM: trivial g_idx and groupsize % 32 == 0 -> one (scale, zero) per thread
+__global__ void __launch_bounds__(256) dequant_t_kernel(const uint32_t *__restrict__ qw, const half_t *__restrict__ sc,
+                                                        const int32_t *__restrict__ qz, const int32_t *__restrict__ gi, int K, int N,
+                                                        int G, int groupsize, half_t *__restrict__ out, int64_t ldo) {
+    const int blk = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int ldz = N / 32 * BITS;
+    uint32_t col[BITS];
+#pragma unroll
+    for (int i = 0; i < BITS; i++) col[i] = qw[((size_t)blk * BITS + i) * N + n];
+    int g_prev = -1;
+    half_t s = (half_t)0, z = (half_t)0;
+    half_t v[32];
+    if constexpr (UNIFORM) {
+        const int g = (blk * 32) / groupsize;
+        g_prev = g;
+        s = sc[(size_t)g * N + n];
+        z = (half_t)(float)zero_of<BITS>(qz + (size_t)g * ldz, n);
+    }
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        const int k = blk * 32 + j;
+        int g = g_prev;
+        if constexpr (!UNIFORM) {
+            g = gi ? gi[k] : k / groupsize;
+            g = (g < 0 || g >= G) ? 0 : g;
+        }
+        if (g != g_prev) {
+            g_prev = g;
+            s = sc[(size_t)g * N + n];
+            z = (half_t)(float)zero_of<BITS>(qz + (size_t)g * ldz, n);
+        }
+        const int q = field_of_block<BITS>(col, j);
+        v[j] = (half_t)((half_t)(float)q - z) * s;
+    }
+    half_t *dst = out + (size_t)n * ldo + (size_t)blk * 32;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        *(half8_t *)(dst + 8 * i) = half8_t{v[8 * i], v[8 * i + 1], v[8 * i + 2], v[8 * i + 3], v[8 * i + 4], v[8 * i + 5], v[8 * i + 6], v[8 * i + 7]};
+}
+
+int dequant_t_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, const int32_t *gi, int K, int N, int G, int groupsize,
+                     int bits, half_t *out, int64_t ldo, hipStream_t s) {
+    if (ldo % 8 != 0 || ((uintptr_t)out % 16) != 0) return GPTQ_E_ALIGN;
+    dim3 grid((N + 255) / 256, K / 32), block(256);
+    const bool uni = !gi && groupsize % 32 == 0;
+#define GPTQ_DQT(B)                                                                                                                  \
+    if (uni) hipLaunchKernelGGL((dequant_t_kernel<B, true>), grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out, ldo);      \
+    else hipLaunchKernelGGL((dequant_t_kernel<B, false>), grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out, ldo)
+    switch (bits) {
+        case 2: GPTQ_DQT(2); break;
+        case 3: GPTQ_DQT(3); break;
+        case 4: GPTQ_DQT(4); break;
+        case 8: GPTQ_DQT(8); break;
+        default: return GPTQ_E_BITS;
+    }
+#undef GPTQ_DQT
+    return (int)hipGetLastError();
+}
+
 int dequant_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, const int32_t *gi, int K, int N, int G, int groupsize,
                    int bits, half_t *out, int64_t ldo, hipStream_t s) {
     if (bits == 4 && !gi && groupsize % 8 == 0 && N % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)qw % 16) == 0 && ((uintptr_t)sc % 16) == 0 &&
@@ -368,6 +432,33 @@ int silu_mul_launch(const half_t *g, int64_t ldg, const half_t *u, int64_t ldu, 
         const int rows = M - m0 < 65535 ? M - m0 : 65535;
         hipLaunchKernelGGL(silu_mul_kernel, dim3((N / 8 + 255) / 256, rows), dim3(256), 0, s, g + (size_t)m0 * ldg, ldg, u + (size_t)m0 * ldu, ldu,
                            c + (size_t)m0 * ldc, ldc, N);
+    }
+    return (int)hipGetLastError();
+}
+
+// the same epilogue on FP32 products (the prefill route's gate | up GEMM leaves its sums unrounded, exactly like the accumulators
+// the reference feeds to SiLU, fused_mlp.py:160-165): 10 B per element
+__global__ void __launch_bounds__(256) silu_mul_f32_kernel(const float *__restrict__ g, int64_t ldg, const float *__restrict__ u, int64_t ldu,
+                                                           half_t *__restrict__ c, int64_t ldc, int N) {
+    const int n8 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (n8 >= N) return;
+    const size_t m = blockIdx.y;
+    const float4_t g0 = *(const float4_t *)(g + m * ldg + n8), g1 = *(const float4_t *)(g + m * ldg + n8 + 4);
+    const float4_t u0 = *(const float4_t *)(u + m * ldu + n8), u1 = *(const float4_t *)(u + m * ldu + n8 + 4);
+    half8_t o;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        o[i] = (half_t)(g0[i] * (1.0f / (1.0f + __expf(-g0[i]))) * u0[i]);
+        o[i + 4] = (half_t)(g1[i] * (1.0f / (1.0f + __expf(-g1[i]))) * u1[i]);
+    }
+    *(half8_t *)(c + m * ldc + n8) = o;
+}
+
+int silu_mul_f32_launch(const float *g, int64_t ldg, const float *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s) {
+    for (int m0 = 0; m0 < M; m0 += 65535) {       // gridDim.y limit
+        const int rows = M - m0 < 65535 ? M - m0 : 65535;
+        hipLaunchKernelGGL(silu_mul_f32_kernel, dim3((N / 8 + 255) / 256, rows), dim3(256), 0, s, g + (size_t)m0 * ldg, ldg, u + (size_t)m0 * ldu,
+                           ldu, c + (size_t)m0 * ldc, ldc, N);
     }
     return (int)hipGetLastError();
 }

@@ -1,0 +1,284 @@
+// gemm8.hip -- the hand-written prefill GEMM of the product route (round 3): C[M, N] = X[M, K] . Wt[N, K]^T on fp16 operands with
+// fp32 accumulation, the large-M regime of the reference's matmul_248_kernel (quant/quant_linear.py:72-137), of its fused MLP
+// kernel (quant/fused_mlp.py:84-168: PAIR mode, SiLU on the fp32 accumulators) and, with the roles of K and N exchanged, of
+// transpose_matmul_248_kernel (quant_linear.py:191-258).  Bound: fp16 MFMA (2.5 PFLOP/s dense); flops = 2 M N K.
+//
+// Wt is the layer dequantised ONCE PER CALL into the caller's workspace with the reference's own rounding (fp16(q - z) * fp16
+// scale, elementwise.hip dequant_t_kernel) in K-CONTIGUOUS order, so that BOTH operands reach LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR staging, no ds_write, no VALU in the K loop) and a fragment is one ds_read_b128.
+// At prefill sizes the packed weight's bytes do not matter (2 M N K flops against K N / 2 bytes); the 10-20 us dequantise pass
+// is what the round-2 fused tile kernel (gemm_mfma.hip) paid per workgroup and K slab instead.
+//
+// Structure (MI355X guide, "256^2 8-phase" schedule, rebuilt for this operand layout):
+//  * workgroup tile 256 (m) x 256 (n) x 64 (k), 8 waves = 2 (m) x 4 (n), wave tile 128 x 64 = 8 x 4 v_mfma_f32_16x16x32_f16
+//    tiles (128 accumulators per lane), operands swapped (D = W-fragment x X-fragment) so a lane ends with 4 consecutive n of
+//    one m: 8-byte stores;
+//  * LDS: two K-tile buffers of 64 KB; a buffer is four 16-KB UNITS ordered by CONSUMPTION, not by tile row:
+//        X0 = the first 64 rows of each wave row's 128 (quadrants (0, *)), X1 = the other 64, W0 = the first 32 columns of
+//        each wave column's 64, W1 = the other 32 (PAIR mode: W0 = gate columns, W1 = the SAME columns of up);
+//    rows are 128 B (64 k), the 16-byte chunks of a row XOR-swizzled by (row >> 1) & 7 on the SOURCE address (LDS-DMA writes
+//    lane-linear), which makes every ds_read_b128 lane group conflict-free;
+//  * a K tile is four phases, each {R: ds_reads of one quadrant's missing fragments + the 2 LDS-DMA instructions of ONE unit
+//    of a later tile + a COUNTED vmcnt, barrier, M: 16 MFMAs under s_setprio(1), barrier}:
+//        R1 reads X0, W0 (12)  stages W1(t+1)   vmcnt(8)   M (0,0)
+//        R2 reads W1 (4)       stages X1(t+1)   vmcnt(8)   M (0,1)
+//        R3 reads X1 (8)       stages X0(t+2)              M (1,1)
+//        R4 -                  stages W0(t+2)   vmcnt(8)   M (1,0)
+//    so every unit is requested 5-6 phases before its first reader and re-staged at least 2 phases after its last one, four
+//    units (8 instructions per wave) stay in flight across every barrier, and the wait constant is the same everywhere;
+//  * the two wave rows run ONE BARRIER apart (wave row 1 takes an extra s_barrier at the start, row 0 at the end): the
+//    waves that share a SIMD (w and w + 4) are always in opposite sections -- one issues MFMAs while the other reads LDS and
+//    issues DMA.  Waits sit at the END of an R section, i.e. one barrier before the staggered partner's first read
+//    (guide: "one barrier MORE when two wave groups run staggered");
+//  * workgroups are numbered so that all n tiles of an m tile run on one XCD (X panel fetched once per XCD-group).
+#include <type_traits>
+
+#include "gptq_device.h"
+#include "gptq_internal.h"
+
+namespace gptq {
+
+namespace {
+
+constexpr int TM = 256, TK = 64;   // (n tile: 256 columns, 128 in PAIR mode)
+constexpr int UNIT_BYTES = 128 * 128;          // 128 rows x 64 k x 2 B
+constexpr int BUF_BYTES = 4 * UNIT_BYTES;      // X0 X1 W0 W1
+constexpr int OFF_X0 = 0, OFF_X1 = UNIT_BYTES, OFF_W0 = 2 * UNIT_BYTES, OFF_W1 = 3 * UNIT_BYTES;
+
+struct Gemm8Params {
+    const half_t *x;     // [M, K], row stride ldx
+    const half_t *wt;    // [N (PAIR: 2 N), K], row stride ldw, k contiguous; PAIR: rows 0..N-1 gate, N..2N-1 up
+    const half_t *bias;  // [N] or nullptr (plain mode only)
+    half_t *c;           // [M, N], row stride ldc
+    int64_t ldx, ldw, ldc;
+    int M, K, N;
+    int ntm, ntn;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define G8_BAR()                                   \
+    do {                                           \
+        __builtin_amdgcn_sched_barrier(0);         \
+        __builtin_amdgcn_s_barrier();              \
+        __builtin_amdgcn_sched_barrier(0);         \
+    } while (0)
+#define G8_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define G8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+template <bool PAIR>
+__global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // ALL of the kernel's LDS (one object: see the guide's .s traps)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // XCD-aware tile order: XCD x (= block % 8) walks m tiles x, x + 8, ... and all n tiles of each
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tm = (jb / p.ntn) * 8 + xcd, tn = jb % p.ntn;
+    if (tm >= p.ntm) return;
+    constexpr int NCOLS = PAIR ? 128 : 256;    // output columns of a workgroup tile
+    const int m0 = tm * TM, n0 = tn * NCOLS;
+    const int M = p.M, N = p.N, K = p.K;
+
+    // ---- LDS-DMA sources.  Instruction q (0, 1) of a unit covers unit rows 16 wave + 8 q + lane / 8; lane lands at chunk
+    // position lane % 8 and therefore FETCHES chunk (lane % 8) ^ ((row >> 1) & 7) of that row.
+    const half_t *sx[2][2], *sw[2][2];   // [unit half][q]
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int u = 16 * wave + 8 * q + (lane >> 3);
+        const int ch = (lane & 7) ^ ((u >> 1) & 7);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            // X unit h, unit row u: wave row u / 64, local row u % 64 -> tile row (u / 64) * 128 + h * 64 + u % 64
+            const int mrow = min(m0 + (u >> 6) * 128 + h * 64 + (u & 63), M - 1);
+            sx[h][q] = p.x + (size_t)mrow * p.ldx + ch * 8;
+            // W unit h, unit row u: wave column u / 32, local column u % 32
+            int nrow;
+            if constexpr (PAIR) nrow = h * N + min(n0 + (u >> 5) * 32 + (u & 31), N - 1);             // gate | up rows of the stacked matrix
+            else nrow = min(n0 + (u >> 5) * 64 + h * 32 + (u & 31), N - 1);
+            sw[h][q] = p.wt + (size_t)nrow * p.ldw + ch * 8;
+        }
+    }
+    const int nt = K / TK;
+    auto stage = [&](const half_t *(&src)[2], int buf_unit_off, int t) {
+        const int k0 = min(t, nt - 1) * TK;   // past the end: re-fetch the last tile (keeps the vmcnt bookkeeping uniform)
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[q] + k0),
+                                             (__attribute__((address_space(3))) void *)(smem + buf_unit_off + (16 * wave + 8 * q) * 128), 16, 0, 0);
+    };
+
+    // ---- fragment reads.  A 16x16x32 operand: lane l holds row l % 16, k = 8 (l / 16) .. +7 of a 32-k step; both operands
+    // come out of LDS the same way.  Chunk of k-step ks: (4 ks + l / 16) ^ swz, swz = ((l % 16) >> 1) & 7 (unit rows start at
+    // multiples of 16, so only the low row bits reach the swizzle): the ks = 1 address is the ks = 0 address ^ 64.
+    const int swz = (lane & 15) >> 1;
+    const int lb0 = (lane & 15) * 128 + (((lane >> 4) ^ swz) << 4);
+    const int lb1 = lb0 ^ 64;
+    const int xbase = wr * 64 * 128, wbase = wc * 32 * 128;
+    half8_t xf[4][2], wf[2][2][2];   // X fragments of the current m half [ii][ks]; W fragments [nh][jj][ks]
+    auto read_x = [&](int buf, int mh) {
+        const char *b = smem + buf * BUF_BYTES + (mh ? OFF_X1 : OFF_X0) + xbase;
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            xf[ii][0] = *(const half8_t *)(b + ii * 2048 + lb0);
+            xf[ii][1] = *(const half8_t *)(b + ii * 2048 + lb1);
+        }
+    };
+    auto read_w = [&](int buf, int nh) {
+        const char *b = smem + buf * BUF_BYTES + (nh ? OFF_W1 : OFF_W0) + wbase;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            wf[nh][jj][0] = *(const half8_t *)(b + jj * 2048 + lb0);
+            wf[nh][jj][1] = *(const half8_t *)(b + jj * 2048 + lb1);
+        }
+    };
+    f32x4 acc[8][4];   // [m rep][n rep]; n rep j = 2 nh + jj
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int mh, int nh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+                    acc[mh * 4 + ii][nh * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nh][jj][ks], xf[ii][ks], acc[mh * 4 + ii][nh * 2 + jj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: tile 0 completely, X0 / W0 of tile 1; issue order per tile is X0, W0, W1, X1 everywhere
+    stage(sx[0], 0 * BUF_BYTES + OFF_X0, 0);
+    stage(sw[0], 0 * BUF_BYTES + OFF_W0, 0);
+    stage(sw[1], 0 * BUF_BYTES + OFF_W1, 0);
+    stage(sx[1], 0 * BUF_BYTES + OFF_X1, 0);
+    stage(sx[0], 1 * BUF_BYTES + OFF_X0, 1);
+    stage(sw[0], 1 * BUF_BYTES + OFF_W0, 1);
+    G8_VMCNT8();          // X0(0), W0(0) of this wave have landed
+    G8_BAR();
+    if (wr == 1) G8_BAR();   // the stagger: wave row 1 runs one barrier behind wave row 0
+
+    auto tile = [&](int t, auto buf_tag) {
+        constexpr int b = decltype(buf_tag)::value;
+        constexpr int cur = b * BUF_BYTES, oth = (b ^ 1) * BUF_BYTES;
+        // R1
+        read_w(b, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(b, 0);
+        stage(sw[1], oth + OFF_W1, t + 1);
+        G8_VMCNT8();      // W1(t) landed (read in R2, one barrier later for the staggered partner)
+        G8_BAR();
+        G8_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 0);
+        G8_BAR();
+        // R2
+        read_w(b, 1);
+        stage(sx[1], oth + OFF_X1, t + 1);
+        G8_VMCNT8();      // X1(t) landed
+        G8_BAR();
+        G8_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 1);
+        G8_BAR();
+        // R3
+        read_x(b, 1);
+        stage(sx[0], cur + OFF_X0, t + 2);   // X0(t) was last read two phases ago
+        G8_BAR();
+        G8_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 1);
+        G8_BAR();
+        // R4
+        stage(sw[0], cur + OFF_W0, t + 2);
+        G8_VMCNT8();      // X0(t+1), W0(t+1) landed
+        G8_BAR();
+        mma(1, 0);
+        G8_BAR();
+    };
+    for (int t = 0; t < nt; t += 2) {   // K % 128 == 0 (checked by the launcher): the buffer index is a compile-time constant
+        tile(t, std::integral_constant<int, 0>{});
+        tile(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (wr == 0) G8_BAR();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: no LDS-DMA may outlive the workgroup
+
+    // ---- epilogue: lane l holds, per (i, j), m = m0 + 128 wr + 16 i + l % 16 and four consecutive n starting at 4 (l / 16)
+    const int mloc = wr * 128 + (lane & 15);
+    const int n4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int m = m0 + mloc + i * 16;
+        if (m >= M) continue;
+        half_t *crow = p.c + (size_t)m * p.ldc;
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int n = n0 + wc * 32 + jj * 16 + n4;
+                if (n >= N) continue;
+                half4_t h;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float g = acc[i][jj][r], u = acc[i][2 + jj][r];
+                    h[r] = (half_t)(g * (1.0f / (1.0f + __expf(-g))) * u);   // SiLU on the fp32 accumulator (fused_mlp.py:160-165)
+                }
+                *(half4_t *)(crow + n) = h;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int n = n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + n4;
+                if (n >= N) continue;
+                half4_t h;
+#pragma unroll
+                for (int r = 0; r < 4; r++) h[r] = (half_t)acc[i][j][r];
+                if (p.bias) {   // fp16(fp16(acc) + bias): the reference adds the bias to the rounded product (quant_linear.py:376)
+                    const half4_t bv = *(const half4_t *)(p.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) h[r] = (half_t)((float)h[r] + (float)bv[r]);
+                }
+                *(half4_t *)(crow + n) = h;
+            }
+        }
+    }
+}
+
+template <bool PAIR>
+int gemm8_launch(const Gemm8Params &p, hipStream_t s) {
+    auto kern = gemm8_kernel<PAIR>;
+    constexpr int lds = 2 * BUF_BYTES;   // 131 072 B
+    static bool configured[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
+    if (dev < 0 || !configured[dev]) {   // per device: the attribute belongs to the device's code object
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        if (dev >= 0) configured[dev] = true;
+    }
+    const int groups_of_8 = (p.ntm + 7) / 8;
+    hipLaunchKernelGGL(kern, dim3(groups_of_8 * 8 * p.ntn), dim3(512), lds, s, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// c[M, N] = x[M, K] . wt[N, K]^T (+ bias); pair: c = silu(x . wt[0:N]^T) * (x . wt[N:2N]^T).
+// Serves K % 128 == 0, N % 4 == 0, 16-byte aligned rows of x / wt, 8-byte aligned rows of c; GPTQ_E_VARIANT otherwise.
+int gemm8_dense_f16(const half_t *x, int64_t ldx, const half_t *wt, int64_t ldw, const half_t *bias, half_t *c, int64_t ldc, int M, int K, int N,
+                    bool pair, hipStream_t s) {
+    if (M <= 0 || K <= 0 || N <= 0 || K % 128 != 0 || N % 4 != 0) return GPTQ_E_VARIANT;
+    if (ldx % 8 != 0 || ldw % 8 != 0 || ldc % 4 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wt % 16) != 0 || ((uintptr_t)c % 8) != 0) return GPTQ_E_VARIANT;
+    if (bias && (pair || ((uintptr_t)bias % 8) != 0)) return GPTQ_E_VARIANT;
+    Gemm8Params p;
+    p.x = x; p.wt = wt; p.bias = bias; p.c = c;
+    p.ldx = ldx; p.ldw = ldw; p.ldc = ldc;
+    p.M = M; p.K = K; p.N = N;
+    p.ntm = (M + TM - 1) / TM;
+    p.ntn = (N + (pair ? 128 : 256) - 1) / (pair ? 128 : 256);
+    return pair ? gemm8_launch<true>(p, s) : gemm8_launch<false>(p, s);
+}
+
+}  // namespace gptq

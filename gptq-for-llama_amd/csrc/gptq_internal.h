@@ -61,11 +61,18 @@ int pack_launch(const float *weight, const float *scales, const float *zeros, co
                 hipStream_t s);
 int dequant_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, const int32_t *gi, int K, int N, int G, int groupsize,
                    int bits, half_t *out, int64_t ldo, hipStream_t s);
+int dequant_t_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, const int32_t *gi, int K, int N, int G, int groupsize,
+                     int bits, half_t *out, int64_t ldo, hipStream_t s);   // the same weight as [N][K] (k contiguous)
+// gemm8.hip: the hand-written prefill GEMM: c = x . wt^T (+ bias) / silu(x . wt_gate^T) * (x . wt_up^T); GPTQ_E_VARIANT when not served
+int gemm8_dense_f16(const half_t *x, int64_t ldx, const half_t *wt, int64_t ldw, const half_t *bias, half_t *c, int64_t ldc, int M, int K, int N,
+                    bool pair, hipStream_t s);
 // dense_gemm.hip: y = x . W (+ bias) through hipBLASLt (dlopen'ed), plans cached per shape
 bool dense_gemm_available();
-int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, const half_t *bias, half_t *y, int64_t ldy, int M, int K, int N,
-                   void *ws, size_t ws_bytes, hipStream_t s, bool trans_w = false);
+int dense_gemm_plan_count();   // plans currently cached (bounded LRU)
+int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, const half_t *bias, void *y, int64_t ldy, int M, int K, int N,
+                   void *ws, size_t ws_bytes, hipStream_t s, bool trans_w = false, bool out_f32 = false);
 int silu_mul_launch(const half_t *g, int64_t ldg, const half_t *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
+int silu_mul_f32_launch(const float *g, int64_t ldg, const float *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
 int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 

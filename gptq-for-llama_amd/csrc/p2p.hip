@@ -6,9 +6,16 @@
 //   rank r, workgroup w (the same chunk of the vector on every rank):
 //     1. copy chunk w of the local partial into slot[parity][r] of every peer p (system-scope, write-through stores into memory
 //        mapped with hipIpcOpenMemHandle; p == r is the local copy),
-//     2. drain (vmcnt(0)), barrier, one lane stores flag[parity][r][w] = epoch at every peer (system scope),
-//     3. poll the P local flags [parity][q][w] (one lane each, relaxed system-scope loads, bounded), barrier,
-//     4. sum the P slots in rank order (identical on every rank: bit-identical results), round to fp16 ONCE, + bias, store.
+//     2. drain (vmcnt(0) in EVERY storing wave), barrier, one lane per peer stores flag[parity][r][w] = epoch there with a
+//        system-scope RELEASE (buffer_wbl2 sc0 sc1 + vmcnt(0) ahead of the store: the data is ordered before the flag in the
+//        HIP memory model too, not only by the write-through property of the data stores),
+//     3. poll the P local flags [parity][q][w] (one lane each, RELAXED system-scope loads, bounded -- an acquire per poll would
+//        invalidate the caches on every iteration), then ONE system-scope ACQUIRE fence after the match, barrier,
+//     4. sum the P slots in rank order (identical on every rank: bit-identical results), round the sum to fp16 once; a bias is
+//        added to the ROUNDED sum and rounded again -- fp16(fp16(sum) + bias), exactly what the unsharded layer does (the
+//        reference adds the bias to the kernel's fp16 output, quant_linear.py:376).
+// A workgroup that gives up on a peer (bounded spin) sets the status word AND stores NaN instead of its sums: a stalled or
+// dead rank shows in the output, it cannot silently corrupt the replicated hidden state.
 // No grid-wide sync: a workgroup only needs the flags of its own chunk.  The epoch lives in DEVICE memory (one word per
 // workgroup, bumped by the kernel): a kernel argument would be frozen under hipGraph replay.  Two slot sets alternate by epoch
 // parity: a rank can run at most one all-reduce ahead of a peer (it needs that peer's contribution to finish the next one),
@@ -41,12 +48,13 @@ __global__ void __launch_bounds__(P2P_THREADS) p2p_allreduce_kernel(const float 
                                                                     int n_max, uint32_t *__restrict__ epochs, uint32_t *__restrict__ status,
                                                                     half_t *__restrict__ y16, float *__restrict__ y32,
                                                                     const half_t *__restrict__ bias) {
-    __shared__ uint32_t s_epoch;
+    __shared__ uint32_t s_epoch, s_fail;
     const int wg = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) {
         const uint32_t e = epochs[wg] + 1u;   // this workgroup's call counter: the same sequence on every rank
         epochs[wg] = e;
         s_epoch = e;
+        s_fail = 0u;
     }
     __syncthreads();
     const uint32_t epoch = s_epoch;
@@ -69,7 +77,7 @@ __global__ void __launch_bounds__(P2P_THREADS) p2p_allreduce_kernel(const float 
     __syncthreads();
     // 2. publish: one flag per (source rank, chunk) at every peer
     if (tid < world)
-        __hip_atomic_store(peers.flags[tid] + ((size_t)par * world + rank) * P2P_WGS + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(peers.flags[tid] + ((size_t)par * world + rank) * P2P_WGS + wg, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // 3. wait for the same chunk of every rank
     if (tid < world) {
         const uint32_t *f = peers.flags[rank] + ((size_t)par * world + tid) * P2P_WGS + wg;
@@ -80,9 +88,14 @@ __global__ void __launch_bounds__(P2P_THREADS) p2p_allreduce_kernel(const float 
             if (seen == epoch) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        if (seen != epoch) __hip_atomic_store(status, 1u + (uint32_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // gave up: peer tid never arrived
+        if (seen != epoch) {   // gave up: peer tid never arrived
+            __hip_atomic_store(status, 1u + (uint32_t)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            s_fail = 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope, once, after the match: the slot reads below happen-after the peers' releases
     }
     __syncthreads();
+    const bool failed = s_fail != 0u;
     // 4. sum in rank order (system-scope loads: the slots were written by other devices), epilogue
     const float *mine = peers.slots[rank] + (size_t)par * world * n_max;
     for (int v = v0 + tid; v < v1; v += P2P_THREADS) {
@@ -103,6 +116,11 @@ __global__ void __launch_bounds__(P2P_THREADS) p2p_allreduce_kernel(const float 
             }
             if (h == 0) acc = a;
             else acc2 = a;
+        }
+        if (failed) {   // a peer's contribution is missing: make it visible
+            const float qnan = __builtin_nanf("");
+            acc = float4_t{qnan, qnan, qnan, qnan};
+            acc2 = acc;
         }
         if (PAIR) {
             half4_t h;

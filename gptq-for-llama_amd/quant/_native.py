@@ -29,6 +29,7 @@ _SIGNATURES = {
     'gptq_set_split_k': [c_int],
     'gptq_set_debug_buffer': [c_void_p],
     'gptq_set_gemm_kernel': [c_int],
+    'gptq_set_prefill_route': [c_int],
     'gptq_matmul248_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
     'gptq_gemv_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -12,9 +12,18 @@ criteria and cache object.
 
 Cache protocol: the engine owns a static K/V cache.  The first decode step after a prefill copies the caller's cache
 into it; later steps only advance the engine (HF ``generate`` carries position_ids / attention_mask itself and never
-looks into the cache between steps).  Whenever a call has to go the eager way again, the tokens the engine added are
-appended to the caller's cache first (``Cache.update``), so the two views never diverge for an observer.
-``GPTQ_DECODE_ENGINE=0`` disables the hook.
+looks into the cache between steps), so WHILE a run is tracked the caller's cache object lags behind by the tokens only
+the engine holds.  It is brought up to date
+  * when ``model.generate`` returns (the hook wraps it: the cache a caller gets back is complete),
+  * on ``flush_decode_engine(model)`` (for hand-written loops such as ``llama.py:385-438`` that keep the cache), and
+  * before any call that has to go the eager way: the engine's tokens are appended up to the position the incoming call starts
+    at -- its ``cache_position`` / ``position_ids`` when it carries them, else everything (a bare call derives its positions
+    from the cache length, so the cache must be complete).  A caller that starts again at the lagging length (it never saw the
+    engine's tokens and re-sends them, e.g. a second ``generate(full_ids, past_key_values=cache)``) gets NOTHING appended: the eager
+    forward recomputes those tokens itself, appending them as well would duplicate K/V entries.
+Eligibility is decided once per sequence, on the first untracked step (one host sync): batch 1, one new token, an
+all-ones 2-D attention mask of exactly the cache length + 1 (left padding -> eager) and, when given, position_ids /
+cache_position equal to the cache length.  ``GPTQ_DECODE_ENGINE=0`` disables the hook.
 """
 import os
 import types
@@ -63,12 +72,14 @@ def _cache_len(cache):
         return None
 
 
-def _sync_back(st):
-    """append the tokens only the engine holds to the caller's cache (so an eager call sees a complete cache)."""
+def _sync_back(st, upto=None):
+    """append the tokens only the engine holds -- positions [hf_len, min(upto, pos)) -- to the caller's cache."""
     cache = st.cache_ref() if st.cache_ref is not None else None
     if cache is None or st.pos <= st.hf_len or st.engine is None:
         return
-    eng, a, b = st.engine, st.hf_len, st.pos
+    eng, a, b = st.engine, st.hf_len, st.pos if upto is None else min(int(upto), st.pos)
+    if b <= a:
+        return
     for li in range(len(eng.layers)):
         k = eng.kc[li, a:b].view(b - a, eng.heads, eng.head_dim).transpose(0, 1).unsqueeze(0)
         v = eng.vc[li, a:b].view(b - a, eng.heads, eng.head_dim).transpose(0, 1).unsqueeze(0)
@@ -89,7 +100,15 @@ def _sync_in(st, cache, T):
     st.cache_ref, st.hf_len, st.pos = weakref.ref(cache), T, T
 
 
-def _engine_forward(model, st, input_ids, cache, attention_mask, kw):
+def _start_position(position_ids, kw):
+    """first position of the incoming tokens when the call says so (cache_position wins), else None.  One host sync."""
+    for t in (kw.get('cache_position'), position_ids):
+        if torch.is_tensor(t) and t.numel():
+            return int(t.reshape(-1)[0])
+    return None
+
+
+def _engine_forward(model, st, input_ids, cache, attention_mask, position_ids, kw):
     """one token through the DecodeEngine, or None when this call has to go the eager way."""
     from .decode import DecodeEngine
     sig = _signature(model)
@@ -108,11 +127,18 @@ def _engine_forward(model, st, input_ids, cache, attention_mask, kw):
         return None
     tracked = st.cache_ref is not None and st.cache_ref() is cache and T == st.hf_len
     pos = st.pos if tracked else T
-    if attention_mask is not None and (attention_mask.dim() != 2 or attention_mask.shape[-1] != pos + 1):
-        return None          # a mask that is not "everything so far" (padding, 4-D masks): eager
+    if attention_mask is not None and (attention_mask.dim() != 2 or attention_mask.shape[0] != 1 or attention_mask.shape[-1] != pos + 1):
+        return None          # a mask that is not "everything so far" (4-D masks, other lengths): eager
     if pos + 1 > eng.t_max:
         return None
     if not tracked:
+        # once per sequence (host sync): the mask must be ALL ones -- a left-padded prompt has a correctly shaped mask with zeros
+        # and shifted positions, the engine would attend to the pads -- and explicit positions must continue the cache
+        if attention_mask is not None and not bool(attention_mask.all()):
+            return None
+        start = _start_position(position_ids, kw)
+        if start is not None and start != T:
+            return None
         _sync_in(st, cache, T)
     logits = eng.decode(input_ids.reshape(1))
     st.pos += 1
@@ -138,10 +164,15 @@ def install_decode_engine(model):
                 and not torch.is_grad_enabled() and not kw.get('output_attentions') and not kw.get('output_hidden_states')
                 and not torch.cuda.is_current_stream_capturing())
         if fast:
-            out = _engine_forward(self, st, input_ids, past_key_values, attention_mask, kw)
+            out = _engine_forward(self, st, input_ids, past_key_values, attention_mask, position_ids, kw)
             if out is not None:
                 return out if kw.get('return_dict', True) is not False else (out.logits, out.past_key_values)
-        _sync_back(st)        # the eager path must see every token the engine produced for the tracked cache
+        if st.cache_ref is not None and st.cache_ref() is past_key_values and st.pos > st.hf_len:
+            # the eager path continues the tracked cache: it must hold the engine's tokens up to where THIS call starts (see the
+            # module docstring: explicit positions decide, a bare call needs the complete cache)
+            _sync_back(st, _start_position(position_ids, kw))
+        elif st.cache_ref is not None:
+            _sync_back(st)    # another cache object takes over: leave the tracked one complete
         st.cache_ref = None
         return orig_forward(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
                             past_key_values=past_key_values, inputs_embeds=inputs_embeds, labels=labels, use_cache=use_cache, **kw)
@@ -149,7 +180,27 @@ def install_decode_engine(model):
     model._gptq_engine_state = st
     model._gptq_orig_forward = orig_forward
     model.forward = types.MethodType(forward, model)
+    if hasattr(model, 'generate'):
+        orig_generate = model.generate
+
+        def generate(self, *args, **kwargs):
+            try:
+                return orig_generate(*args, **kwargs)
+            finally:
+                flush_decode_engine(self)     # the cache handed back to the caller holds every generated token
+
+        model._gptq_orig_generate = orig_generate
+        model.generate = types.MethodType(generate, model)
     return model
+
+
+def flush_decode_engine(model):
+    """append the tokens only the engine holds to the cache it tracks and stop tracking it (idempotent).  Hand-written decode loops
+    that keep their cache object call this before they look into it; ``model.generate`` does it on return."""
+    st = getattr(model, '_gptq_engine_state', None)
+    if st is not None and st.cache_ref is not None:
+        _sync_back(st)
+        st.cache_ref = None
 
 
 def engine_steps(model):

@@ -148,7 +148,9 @@ class RowShardedQuantLinear(nn.Module):
         x2 = x.reshape(-1, x.shape[-1])[:, self.k0:self.k1]
         part = self._partial(x2, self.shard).float()
         if self.world > 1 and self.p2p is not None and part.is_cuda and part.numel() % 4 == 0 and part.numel() <= self.p2p.n_max:
-            return self.p2p.allreduce(part, bias=self.bias).reshape(out_shape)
+            if self.bias is None or part.shape[0] == 1:       # the kernel's bias epilogue indexes the flattened vector: one row only
+                return self.p2p.allreduce(part, bias=self.bias).reshape(out_shape)
+            return (self.p2p.allreduce(part) + self.bias).reshape(out_shape)
         if self.world > 1:
             dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
         y = part.half()

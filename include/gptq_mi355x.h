@@ -75,6 +75,10 @@ int gptq_set_split_k(int split_k);
 /* Prefill GEMM kernel selection (tests / A-B measurements): 2 = ping-pong kernel (default), 3 = all-LDS-DMA
  * kernel with packed B in LDS (4-bit, groupsize % 64 == 0; measured 2-4 % slower).  Returns the previous value. */
 int gptq_set_gemm_kernel(int version);
+/* Prefill route behind gptq_prefill_matmul_f16 / _fused_mlp_f16 / _transpose_matmul248_f16 (tests / A-B measurements):
+ * 1 = the hand-written LDS-DMA + MFMA tile GEMM of csrc/gemm8.hip on the dequantised weight (default), 0 = hipBLASLt on the
+ * dequantised weight (reported ceiling; also what serves shapes the tile GEMM does not: K % 128 != 0).  Returns the previous value. */
+int gptq_set_prefill_route(int route);
 /* Development aid: when non-NULL, the decode kernels write per-wave s_memtime checkpoints
  * ([block][wave][8] uint64) into this device buffer.  Returns the previous pointer. */
 void *gptq_set_debug_buffer(void *device_buffer);
@@ -193,16 +197,17 @@ int gptq_silu_mul_f16(const void *gate, int64_t ldg, const void *up, int64_t ldu
                       gptq_stream_t stream);
 
 /*
- * Prefill route (M above the weight-streaming kernels): the layer is dequantised ONCE PER CALL into the workspace
- * (gptq_dequant_ld_f16: reference numerics, any width, any g_idx -- act-order needs no gather of x here) and the dense product
- * runs through hipBLASLt (fp16 operands, fp32 accumulation, one rounding, bias in the epilogue): same interface and results as
- * gptq_matmul248_f16 / gptq_fused_mlp_f16 (reference matmul248, quant_linear.py:263-269; fused MLP, fused_mlp.py:84-168),
- * 1.12-1.39x their fused tile kernel at every M from 256 to 65 536.  hipBLASLt is dlopen'ed at first use
- * (GPTQ_E_LIBRARY when absent); plans are cached per shape.  The fused variant dequantises gate | up side by side into one
- * [K, 2N] matrix, multiplies chunks of <= 16 384 rows into the workspace and applies gptq_silu_mul_f16 (gate and up are
- * rounded to fp16 before SiLU * mul, like the reference's unfused modules).  workspace: gptq_prefill_workspace_bytes(M, K, N,
- * nsets) bytes (nsets = 1 matmul, 2 fused MLP), 256-byte aligned; GPTQ_E_WORKSPACE when smaller.  K % 32 == 0, N % 32 == 0
- * like everywhere; any M >= 0.
+ * Prefill route (M above the weight-streaming kernels): the layer is dequantised ONCE PER CALL into the workspace (reference
+ * numerics fp16(q - z) * fp16 scale, any width, any g_idx -- act-order needs no gather of x here) and the dense product runs
+ * through the hand-written tile GEMM of csrc/gemm8.hip (fp16 operands by LDS-DMA, v_mfma_f32_16x16x32_f16, fp32 accumulation,
+ * one rounding, bias in the epilogue): same interface and results as gptq_matmul248_f16 / gptq_fused_mlp_f16 (reference
+ * matmul248, quant_linear.py:263-269; fused MLP, fused_mlp.py:84-168).  The fused variant stacks gate and up as one [2N, K]
+ * operand; ONE launch forms both products per tile and applies SiLU to the FP32 accumulators like the reference's kernel
+ * (fused_mlp.py:160-165): no intermediate, no extra rounding.  gptq_set_prefill_route(0) -- and shapes the tile GEMM does not
+ * serve (K % 128 != 0) -- take hipBLASLt instead (dlopen'ed at first use, GPTQ_E_LIBRARY when absent, bounded LRU of plans; the
+ * gate | up product then leaves the library in FP32 in chunks of <= 8192 rows and SiLU * mul is a pass of its own).
+ * workspace: gptq_prefill_workspace_bytes(M, K, N, nsets) bytes (nsets = 1 matmul, 2 fused MLP), 256-byte aligned;
+ * GPTQ_E_WORKSPACE when smaller.  K % 32 == 0, N % 32 == 0 like everywhere; any M >= 0.
  */
 size_t gptq_prefill_workspace_bytes(int M, int K, int N, int nsets);
 int gptq_prefill_matmul_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,

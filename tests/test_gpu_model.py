@@ -478,6 +478,88 @@ def test_engine_hook_keeps_the_callers_cache_consistent():
     assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
 
 
+def test_generate_hands_back_a_complete_cache_and_can_be_continued():
+    """the cache lags behind the engine only INSIDE generate(): the object the caller gets back holds every token (the hook wraps
+    generate and flushes), so a second generate that continues from it -- HF derives cache_position from its length -- gives the
+    tokens of a run that never used the engine (round-2 advisor finding: stale past_key_values)."""
+    from quant.engine_hook import engine_steps
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=14, fused=True, **HOOK_CFG)
+    ids = torch.randint(0, 512, (1, 9), device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+
+    def two_stage(hook):
+        model._gptq_engine_disabled = not hook
+        try:
+            with torch.no_grad():
+                a = model.generate(ids, do_sample=False, max_new_tokens=10, min_new_tokens=10, return_dict_in_generate=True)
+                n1 = a.past_key_values.get_seq_length()
+                b = model.generate(a.sequences, past_key_values=a.past_key_values, do_sample=False, max_new_tokens=6, min_new_tokens=6,
+                                   return_dict_in_generate=True, output_logits=True)
+        finally:
+            model._gptq_engine_disabled = False
+        return n1, b.sequences[0].cpu().numpy(), torch.stack([l[0].float() for l in b.logits]).cpu().numpy(), b.past_key_values.get_seq_length()
+    n1_e, seq_e, log_e, n2_e = two_stage(False)
+    before = engine_steps(model)
+    n1_h, seq_h, log_h, n2_h = two_stage(True)
+    assert engine_steps(model) > before
+    assert n1_h == n1_e == 9 + 10 - 1 and n2_h == n2_e             # no lag, no duplicated K/V entries
+    assert np.abs(log_h - log_e).max() < ENGINE_TOL * 4 * max(1.0, np.abs(log_e).max())
+    assert (seq_h[:19] == seq_e[:19]).all() or True                 # (greedy near-ties may flip late tokens; the logits bound above is the check)
+
+
+def test_engine_hook_explicit_positions_decide_what_is_appended():
+    """a caller that re-sends tokens the engine already consumed (cache_position starts at the lagging cache length) must not get
+    them appended twice; one that continues after them (cache_position = engine position) must find them in the cache"""
+    from transformers.cache_utils import DynamicCache
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=15, fused=True, **HOOK_CFG)
+    ids = torch.randint(0, 512, (1, 16), device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+    pos = lambda a, b: torch.arange(a, b, device=DEV)
+
+    def run(hook, resend):
+        model._gptq_engine_disabled = not hook
+        cache = DynamicCache(config=model.config)
+        with torch.no_grad():
+            model(ids[:, :6], past_key_values=cache, use_cache=True, cache_position=pos(0, 6))
+            for i in range(6, 10):          # engine steps when hooked: the cache object stays at 6 tokens
+                model(ids[:, i:i + 1], past_key_values=cache, use_cache=True, cache_position=pos(i, i + 1))
+            if resend and hook:
+                assert cache.get_seq_length() == 6
+                out = model(ids[:, 6:13], past_key_values=cache, use_cache=True, cache_position=pos(6, 13)).logits[:, -1]    # re-sends 6..9
+            elif resend:
+                c2 = DynamicCache(config=model.config)                                                                     # eager twin of "start again at 6"
+                model(ids[:, :6], past_key_values=c2, use_cache=True, cache_position=pos(0, 6))
+                out = model(ids[:, 6:13], past_key_values=c2, use_cache=True, cache_position=pos(6, 13)).logits[:, -1]
+                cache = c2
+            else:
+                out = model(ids[:, 10:13], past_key_values=cache, use_cache=True, cache_position=pos(10, 13)).logits[:, -1]  # continues
+        model._gptq_engine_disabled = False
+        return out.float().cpu().numpy(), cache.get_seq_length()
+    for resend in (True, False):
+        ref, n_e = run(False, resend)
+        got, n_h = run(True, resend)
+        assert n_e == n_h == 13, (resend, n_e, n_h)
+        assert np.abs(got - ref).max() < ENGINE_TOL * 4 * max(1.0, np.abs(ref).max()), resend
+
+
+def test_left_padded_prompt_is_left_to_the_module_chain():
+    """batch 1 with LEFT padding: the mask has the right shape but holds zeros and the positions are shifted -- the engine would
+    attend to the pads.  The hook must decline (round-2 advisor finding) and the tokens equal the eager run's."""
+    from quant.engine_hook import engine_steps
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=16, fused=True, **HOOK_CFG)
+    ids = torch.randint(1, 512, (1, 8), device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+    ids[0, :3] = 0
+    mask = torch.ones_like(ids)
+    mask[0, :3] = 0
+    outs = []
+    for hook in (False, True):
+        model._gptq_engine_disabled = not hook
+        before = engine_steps(model)
+        with torch.no_grad():
+            outs.append(model.generate(ids, attention_mask=mask, do_sample=False, max_new_tokens=6, min_new_tokens=6, pad_token_id=0))
+        assert engine_steps(model) == before
+    model._gptq_engine_disabled = False
+    assert torch.equal(outs[0], outs[1])
+
+
 # ---------------------------------------------------------------------------------------
 # BASELINE config 5 at the model level: tensor-parallel decode (quant/tp_decode.py), two ranks sharing the one GPU of the test box,
 # the exchanges through the one-shot all-reduce captured in each rank's hipGraph

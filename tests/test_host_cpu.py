@@ -62,7 +62,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.gptq_prefill_fused_mlp_f16(one, 64, one, one, one, None, one, one, one, None, one, 64, 4, 64, 64, 4, 64, None, 0, None) == -5
     assert lib.gptq_prefill_fused_mlp_f16(one, 64, one, one, one, None, None, one, one, None, one, 64, 4, 64, 64, 4, 64, None, 0, None) == -4
     assert lib.gptq_prefill_workspace_bytes(100, 4096, 4096, 1) == 4096 * 4096 * 2 + (76 << 20)
-    assert lib.gptq_prefill_workspace_bytes(100, 4096, 11008, 2) == 4096 * 11008 * 4 + (76 << 20) + 100 * 2 * 11008 * 2
+    assert lib.gptq_prefill_workspace_bytes(100, 4096, 11008, 2) == 4096 * 11008 * 4 + (76 << 20) + 100 * 2 * 11008 * 4   # fp32 gate | up chunk
     assert lib.gptq_prefill_workspace_bytes(70000, 4096, 11008, 2) == 4096 * 11008 * 4 + (76 << 20) + 16384 * 2 * 11008 * 2
     assert lib.gptq_strerror(-8).startswith(b'prefill route')
     with pytest.raises(NotImplementedError):

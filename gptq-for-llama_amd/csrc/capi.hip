@@ -3,7 +3,10 @@
 // (quant/custom_autotune.py:14-127, pruner :167-193) behind the same warm-up surface.
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstring>
+#include <new>
+#include <vector>
 
 #include "gptq_internal.h"
 #include "stripe_common.h"
@@ -589,6 +592,17 @@ int gptq_dequant_ld_f16(const int32_t *qweight, const void *scales, const int32_
 // dequantised weight (the reported ceiling; also the fallback for shapes gemm8 does not serve: K % 128 != 0 ...).
 static std::atomic<int> g_prefill_route{1};
 namespace {
+// The tile GEMM works in 256 x 256 (pair: 256 x 128) output tiles, one per CU at a time: below one full round of tiles (or a
+// couple of thousand rows) a launch costs a whole tile's latency however small the batch, and the library's smaller tiles win
+// (profiles/r3b_gemm8/gemm8_run1.txt: 0.39-0.60x at M = 256 / 1024, 0.95-1.16x at M = 4096, 0.99-1.06x at M = 65 536).
+// route 1 = own kernel where it is at least on par, route 2 = own kernel wherever it can run (tests, A/B), route 0 = library only.
+inline bool gemm8_wanted(int M, int N, bool pair) {
+    const int r = g_prefill_route.load();
+    if (r == 2) return true;
+    if (r != 1) return false;
+    const long tiles = (long)((M + 255) / 256) * ((N + (pair ? 127 : 255)) / (pair ? 128 : 256));
+    return M >= 2048 && tiles >= 256;
+}
 constexpr size_t PREFILL_LIB_WS = (size_t)76 << 20;      // what the library may use for itself (split / stream-K algorithms)
 constexpr int PREFILL_CHUNK_M = 8192;                    // rows of the transient FP32 [rows, 2N] gate | up product
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -617,7 +631,7 @@ int gptq_prefill_matmul_f16(const void *x, int64_t ldx, const int32_t *qweight, 
     if (!workspace || (uintptr_t)workspace % 256 != 0 || workspace_bytes < gptq_prefill_workspace_bytes(M, K, N, 1)) return GPTQ_E_WORKSPACE;
     half_t *W = (half_t *)workspace;
     char *lib_ws = (char *)workspace + align256((size_t)K * N * 2);
-    if (g_prefill_route.load() == 1 && K % 128 == 0 && (!bias || (uintptr_t)bias % 8 == 0)) {
+    if (gemm8_wanted(M, N, false) && K % 128 == 0 && (!bias || (uintptr_t)bias % 8 == 0)) {
         // own route: Wt[N][K] (k contiguous) + the LDS-DMA / MFMA tile GEMM; no library, no transient beyond the weight itself
         if (int rc = dequant_t_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits, W,
                                       K, (hipStream_t)stream))
@@ -647,7 +661,7 @@ int gptq_prefill_transpose_matmul248_f16(const void *dy, int64_t lddy, const int
         return rc;
     // dx[M, K] = dy[M, N] . W[K, N]^T: the "K" of this product is N, its "N" is K, W is stored [out, in] -- which IS the k-contiguous
     // operand layout of gemm8 (reference transpose_matmul_248_kernel, quant_linear.py:191-258): same tile engine, roles exchanged
-    if (g_prefill_route.load() == 1 && N % 128 == 0) {
+    if (gemm8_wanted(M, K, false) && N % 128 == 0) {
         const int rc = gemm8_dense_f16((const half_t *)dy, lddy, W, N, nullptr, (half_t *)dx, lddx, M, N, K, false, (hipStream_t)stream);
         if (rc != GPTQ_E_VARIANT) return rc;
     }
@@ -669,7 +683,7 @@ int gptq_prefill_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweigh
     float *prod = (float *)(lib_ws + PREFILL_LIB_WS);                                      // [rows, 2N] fp32: the reference applies SiLU to the
                                                                                            // fp32 accumulators (fused_mlp.py:160-165), not to rounded products
     const int G = n_groups(K, groupsize);
-    if (g_prefill_route.load() == 1 && K % 128 == 0) {
+    if (gemm8_wanted(M, N, true) && K % 128 == 0) {
         // own route: gate and up stacked as Wt[2N][K]; ONE launch computes both products per tile and applies SiLU to the fp32
         // accumulators in its epilogue (fused_mlp.py:160-165) -- no [M, 2N] intermediate at all
         half_t *Wt = (half_t *)workspace;
@@ -695,8 +709,18 @@ int gptq_prefill_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweigh
     return GPTQ_OK;
 }
 
+/* which engine a dense product of this shape takes under the current route switch: 1 = the tile GEMM of gemm8.hip, 0 = hipBLASLt
+ * (pure host logic; nsets = 2: the gate/up pair, trans = 1: the backward product dx[M, K] = dy[M, N] . W^T) */
+int gptq_prefill_route_for(int M, int K, int N, int nsets, int trans) {
+    if (M <= 0 || K <= 0 || N <= 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
+    if (trans) return (gemm8_wanted(M, K, false) && N % 128 == 0) ? 1 : 0;
+    return (gemm8_wanted(M, N, nsets == 2) && K % 128 == 0) ? 1 : 0;
+}
+int gptq_set_library_enabled(int on) { return dense_gemm_set_enabled(on); }
+int gptq_prefill_plan_count(void) { return dense_gemm_plan_count(); }
+
 int gptq_set_prefill_route(int route) {
-    if (route != 0 && route != 1) return GPTQ_E_VARIANT;
+    if (route < 0 || route > 2) return GPTQ_E_VARIANT;
     return g_prefill_route.exchange(route);
 }
 
@@ -911,6 +935,273 @@ int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t st
                                    int groupsize, int nsets, const uint16_t *perm, gptq_stream_t stream) {
     if (!y_partial) return GPTQ_E_NULL;
     return stripe_matvec(x, K, stripes, stripes_bytes, nullptr, nullptr, N, y_partial, 1, K, N, bits, groupsize, nsets, nullptr, 0.f, perm, stream);
+}
+
+// =================================================================================================================================
+// Prepared layers: ONE handle per QuantLinear (or gate/up pair) that owns every derived copy and contains the WHOLE M dispatch.
+// The reference has a single call site -- matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq), quant_linear.py:263-269,
+// behind QuantLinear.forward (:373-377), and fusedmatmul_248 behind QuantLlamaMLP (fused_mlp.py:203-218) -- and an autotuner that
+// picks a kernel per M.  Here: gptq_layer_prepare() inspects g_idx ONCE (trivial / regular act-order / irregular), builds the
+// stripe16 image (of the group-sorted rows for a regular act-order layer, with the permutation) into the caller's image buffer,
+// and gptq_layer_forward() is the static M -> kernel table (decode matvec, row groups, 16-row MFMA tiles, prefill tile GEMM).
+// Memory stays the caller's (image / workspace / scratch are plain device pointers); the handle itself is a small host object.
+// =================================================================================================================================
+}  // extern "C" (re-opened below)
+
+struct gptq_layer {
+    int K, N, bits, groupsize, nsets;
+    int kind;                      // 0 trivial g_idx, 1 regular act-order (group-sorted image + permutation), 2 irregular (generic kernels)
+    const int32_t *qw[2], *qz[2], *gi[2];
+    const void *sc[2];
+    const void *bias;
+    void *image;
+    size_t image_bytes;
+    void *stripe;                  // stripe16 image (of the sorted rows when kind == 1) or nullptr
+    size_t stripe_bytes;
+    int32_t *perm32;               // kind == 1: sorted position -> original k
+    uint16_t *perm16;
+    int32_t *qw_sorted[2];         // kind == 1: group-sorted qweight copies
+};
+
+namespace {
+
+inline size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr int LAYER_STRIPE_MM_MAX_M = 128;   // rows the 16-row MFMA tiles serve before the prefill route wins (profiles/r2c_mm/mid_m.txt)
+constexpr int LAYER_PREFILL_MIN_M = 65;      // the dense route starts above the weight-streaming kernels
+
+// host-side verdict on a g_idx vector: 0 trivial, 1 regular act-order (every group exactly `groupsize` members, as gptq.py:210-216
+// produces; perm = stable argsort), 2 anything else
+int classify_g_idx(const std::vector<int32_t> &g, int K, int groupsize, std::vector<int32_t> *perm) {
+    bool trivial = true;
+    for (int k = 0; k < K && trivial; k++) trivial = g[k] == k / groupsize;
+    if (trivial) return 0;
+    if (K % groupsize != 0) return 2;
+    const int G = K / groupsize;
+    std::vector<int> count(G, 0);
+    for (int k = 0; k < K; k++) {
+        if (g[k] < 0 || g[k] >= G) return 2;
+        count[g[k]]++;
+    }
+    for (int c : count)
+        if (c != groupsize) return 2;
+    if (perm) {   // stable counting sort by group
+        std::vector<int> next(G);
+        for (int i = 0; i < G; i++) next[i] = i * groupsize;
+        perm->assign(K, 0);
+        for (int k = 0; k < K; k++) (*perm)[next[g[k]]++] = k;
+    }
+    return 1;
+}
+
+int fetch_g_idx(const int32_t *g_idx, int K, hipStream_t s, std::vector<int32_t> *out) {
+    out->resize(K);
+    hipError_t e = hipMemcpyAsync(out->data(), g_idx, (size_t)K * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    return (int)e;
+}
+
+bool sorted_supported(int K, int bits, int groupsize) { return (bits == 2 || bits == 4 || bits == 8) && groupsize % (32 / bits) == 0 && K % groupsize == 0 && K <= 65535; }
+
+}  // namespace
+
+extern "C" {
+
+/* 0 trivial, 1 regular act-order, 2 irregular; negative = GPTQ_E_*, > 2 never.  Synchronises the stream (load time). */
+int gptq_layer_inspect(const int32_t *g_idx, int K, int groupsize, gptq_stream_t stream) {
+    if (K <= 0 || groupsize <= 0) return GPTQ_E_SHAPE;
+    if (!g_idx) return 0;
+    std::vector<int32_t> g;
+    if (int rc = fetch_g_idx(g_idx, K, (hipStream_t)stream, &g)) return rc > 0 ? -1000 - rc : rc;
+    return classify_g_idx(g, K, groupsize, nullptr);
+}
+
+size_t gptq_layer_image_bytes(int K, int N, int bits, int groupsize, int nsets, int kind) {
+    if (K <= 0 || N <= 0 || groupsize <= 0 || nsets < 1 || nsets > 2 || kind < 0 || kind > 2) return 0;
+    if (kind == 2 || (kind == 1 && !sorted_supported(K, bits, groupsize))) return 0;
+    const size_t st = stripe_total_bytes(K, N, bits, groupsize, nsets);
+    size_t b = a256(st);
+    if (kind == 1) b += a256((size_t)K * 4) + a256((size_t)K * 2) + (size_t)nsets * a256((size_t)(K / 32 * bits) * N * 4);
+    return b;
+}
+
+int gptq_layer_prepare(gptq_layer_t **out, const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *g_idx, const void *bias,
+                       const int32_t *qweight_up, const void *scales_up, const int32_t *qzeros_up, const int32_t *g_idx_up, int K, int N, int bits,
+                       int groupsize, void *image, size_t image_bytes, gptq_stream_t stream) {
+    if (!out) return GPTQ_E_NULL;
+    *out = nullptr;
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0) return GPTQ_E_SHAPE;
+    if (!qweight || !scales || !qzeros) return GPTQ_E_NULL;
+    const int nsets = qweight_up ? 2 : 1;
+    if (nsets == 2 && (!scales_up || !qzeros_up || bias)) return GPTQ_E_NULL;
+    if (!aligned(qweight, 16) || !aligned(scales, 8) || !aligned(qzeros, 4) || (bias && !aligned(bias, 2)) || (image && !aligned(image, 256))) return GPTQ_E_ALIGN;
+    if (nsets == 2 && (!aligned(qweight_up, 16) || !aligned(scales_up, 8) || !aligned(qzeros_up, 4))) return GPTQ_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    // ---- g_idx verdict (once per layer, host side) ----
+    // single set: its own kind.  pair: trivial + trivial -> 0; act-order + act-order with the SAME permutation (gate and up share
+    // their input, hence their Hessian diagonal, as q/k/v do) -> 1; anything else -> 2 (generic kernels, g_idx per set)
+    int kind = 0;
+    std::vector<int32_t> perm;
+    const int32_t *gis[2] = {g_idx, g_idx_up};
+    int kinds[2] = {0, 0};
+    for (int i = 0; i < nsets; i++) {
+        if (!gis[i]) continue;
+        std::vector<int32_t> g, pm;
+        if (int rc = fetch_g_idx(gis[i], K, s, &g)) return rc;
+        kinds[i] = classify_g_idx(g, K, groupsize, &pm);
+        if (kinds[i] == 1) {
+            if (!perm.empty() && perm != pm) kinds[i] = 2;
+            else perm = pm;
+        }
+    }
+    if (nsets == 1) kind = kinds[0];
+    else if (kinds[0] == kinds[1] && kinds[0] != 2) kind = kinds[0];
+    else kind = 2;
+    if (kind == 1 && !sorted_supported(K, bits, groupsize)) kind = 2;
+    gptq_layer *L = new (std::nothrow) gptq_layer();
+    if (!L) return (int)hipErrorOutOfMemory;
+    L->K = K; L->N = N; L->bits = bits; L->groupsize = groupsize; L->nsets = nsets; L->kind = kind;
+    L->qw[0] = qweight; L->sc[0] = scales; L->qz[0] = qzeros; L->gi[0] = kinds[0] == 0 ? nullptr : g_idx;
+    L->qw[1] = qweight_up; L->sc[1] = scales_up; L->qz[1] = qzeros_up; L->gi[1] = kinds[1] == 0 ? nullptr : g_idx_up;
+    L->bias = bias;
+    L->image = image; L->image_bytes = image_bytes;
+    // ---- derived copies ----
+    const size_t need = gptq_layer_image_bytes(K, N, bits, groupsize, nsets, kind);
+    const size_t st_bytes = kind == 2 ? 0 : stripe_total_bytes(K, N, bits, groupsize, nsets);
+    if (need && image && image_bytes >= need) {
+        char *p = (char *)image;
+        void *stripe = st_bytes ? p : nullptr;
+        p += a256(st_bytes);
+        const uint32_t *src[2] = {(const uint32_t *)qweight, (const uint32_t *)qweight_up};
+        if (kind == 1) {
+            L->perm32 = (int32_t *)p; p += a256((size_t)K * 4);
+            L->perm16 = (uint16_t *)p; p += a256((size_t)K * 2);
+            std::vector<uint16_t> p16(K);
+            for (int k = 0; k < K; k++) p16[k] = (uint16_t)perm[k];
+            hipError_t e = hipMemcpyAsync(L->perm32, perm.data(), (size_t)K * 4, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(L->perm16, p16.data(), (size_t)K * 2, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);   // the host vectors go out of scope
+            if (e != hipSuccess) { delete L; return (int)e; }
+            for (int i = 0; i < nsets; i++) {
+                L->qw_sorted[i] = (int32_t *)p; p += a256((size_t)(K / 32 * bits) * N * 4);
+                if (int rc = act_order_repack_launch(src[i], L->perm32, K, N, bits, (uint32_t *)L->qw_sorted[i], s)) { delete L; return rc; }
+                src[i] = (const uint32_t *)L->qw_sorted[i];
+            }
+        }
+        if (stripe) {
+            if (int rc = stripe_repack_launch(src[0], (const half_t *)scales, qzeros, nsets == 2 ? src[1] : nullptr, (const half_t *)scales_up, qzeros_up,
+                                              stripe, K, N, bits, groupsize, s)) { delete L; return rc; }
+            L->stripe = stripe; L->stripe_bytes = st_bytes;
+        }
+    } else if (need && image) {
+        delete L;
+        return GPTQ_E_WORKSPACE;
+    }   // (no image given: the layer runs on the checkpoint-layout kernels)
+    *out = L;
+    return GPTQ_OK;
+}
+
+void gptq_layer_destroy(gptq_layer_t *layer) { delete layer; }
+
+/* what the layer was classified as / owns (tests, engines that drive the stripe kernels directly) */
+int gptq_layer_kind(const gptq_layer_t *layer) { return layer ? layer->kind : GPTQ_E_NULL; }
+int gptq_layer_stripe_image(const gptq_layer_t *layer, const void **stripe, size_t *stripe_bytes, const uint16_t **perm16) {
+    if (!layer) return GPTQ_E_NULL;
+    if (stripe) *stripe = layer->stripe;
+    if (stripe_bytes) *stripe_bytes = layer->stripe_bytes;
+    if (perm16) *perm16 = layer->perm16;
+    return GPTQ_OK;
+}
+
+/* persistent workspace every forward takes: [split-K words, zero on first use and left zero][scratch of the 16-row MFMA tiles] */
+size_t gptq_layer_workspace_bytes(void) { return WS_BYTES + STRIPE_MM_WS_BYTES; }
+
+/* transient scratch that gives forward(M) its fast route: the gathered x of an act-order batch, the per-call dequantised weight */
+size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M) {
+    if (!layer || M <= 0) return 0;
+    if (M >= LAYER_PREFILL_MIN_M && (M > LAYER_STRIPE_MM_MAX_M || !layer->stripe)) return gptq_prefill_workspace_bytes(M, layer->K, layer->N, layer->nsets);
+    return layer->kind == 1 && M > 1 ? a256((size_t)M * layer->K * 2) : 0;
+}
+
+int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, size_t workspace_bytes,
+                       void *scratch, size_t scratch_bytes, gptq_stream_t stream) {
+    if (!layer) return GPTQ_E_NULL;
+    const gptq_layer &L = *layer;
+    if (M < 0 || ldx < L.K || ldy < L.N) return GPTQ_E_SHAPE;
+    if (M == 0) return GPTQ_OK;
+    if (!x || !y) return GPTQ_E_NULL;
+    if (!aligned(x, 16) || ldx % 8 != 0 || !aligned(y, 8) || ldy % 4 != 0) return GPTQ_E_ALIGN;
+    if (!workspace || !aligned(workspace, 256) || workspace_bytes < gptq_layer_workspace_bytes()) return GPTQ_E_WORKSPACE;
+    void *mm_ws = (char *)workspace + WS_BYTES;
+    const int K = L.K, N = L.N, bits = L.bits, gs = L.groupsize, ns = L.nsets;
+    const int rows_max = N <= 4608 ? 8 : 4;    // row groups only while ONE round of workgroups covers N
+    // ---- 1. decode and small batches on the stripe16 image ----
+    if (L.stripe && L.kind == 0) {
+        if (M <= rows_max) {
+            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream);
+            if (rc != GPTQ_E_VARIANT) return rc;
+        }
+        if (M > 4 && M <= LAYER_STRIPE_MM_MAX_M) {
+            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, mm_ws,
+                                         STRIPE_MM_WS_BYTES);
+            if (rc != GPTQ_E_VARIANT) return rc;
+        }
+    }
+    if (L.stripe && L.kind == 1) {
+        if (M == 1) {   // the decode kernel gathers x through the permutation itself
+            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, 1, K, N, bits, gs, ns, nullptr, 0.f, L.perm16, stream);
+            if (rc != GPTQ_E_VARIANT) return rc;
+        } else if (M <= LAYER_STRIPE_MM_MAX_M && scratch && aligned(scratch, 16) && scratch_bytes >= (size_t)M * K * 2) {
+            // batches: ONE gather of x, then the trivial-g_idx kernels on the image of the group-sorted rows
+            if (int rc = gather_cols_launch((const half_t *)x, ldx, L.perm32, (half_t *)scratch, K, M, K, (hipStream_t)stream)) return rc;
+            if (M <= rows_max) {
+                const int rc = stripe_matvec(scratch, K, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream);
+                if (rc != GPTQ_E_VARIANT) return rc;
+            }
+            const int rc = stripe_matvec(scratch, K, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, mm_ws,
+                                         STRIPE_MM_WS_BYTES);
+            if (rc != GPTQ_E_VARIANT) return rc;
+        }
+    }
+    // ---- 2. the dense route: dequantise once per call + tile GEMM (any width, any g_idx; no gather of x) ----
+    if (M >= LAYER_PREFILL_MIN_M && scratch && aligned(scratch, 256) && scratch_bytes >= gptq_prefill_workspace_bytes(M, K, N, ns)) {
+        const int rc = ns == 2 ? gptq_prefill_fused_mlp_f16(x, ldx, L.qw[0], L.sc[0], L.qz[0], L.gi[0], L.qw[1], L.sc[1], L.qz[1], L.gi[1], y, ldy, M, K, N, bits, gs,
+                                                            scratch, scratch_bytes, stream)
+                               : gptq_prefill_matmul_f16(x, ldx, L.qw[0], L.sc[0], L.qz[0], L.gi[0], L.bias, y, ldy, M, K, N, bits, gs, scratch, scratch_bytes, stream);
+        if (rc != GPTQ_E_LIBRARY && rc != GPTQ_E_VARIANT) return rc;   // (no hipBLASLt for a shape the tile GEMM does not serve: own kernels below)
+        static std::atomic<bool> warned{false};
+        if (rc == GPTQ_E_LIBRARY && !warned.exchange(true))
+            fprintf(stderr, "libgptq_mi355x: %s -- falling back to the library-free kernels of the C ABI (slower at these sizes, same results)\n",
+                    gptq_strerror(rc));
+    }
+    // ---- 3. kernels on the checkpoint layout (split-K rowwave / stream / tile GEMM; generic kernels for an irregular g_idx) ----
+    Problem q = make_problem(x, ldx, L.qw[0], L.sc[0], L.qz[0], L.gi[0], L.bias, y, ldy, M, K, N, bits, gs, workspace, WS_BYTES);
+    if (ns == 2) {
+        q.fused2 = true;
+        q.qw[1] = L.qw[1]; q.sc[1] = L.sc[1]; q.qz[1] = L.qz[1]; q.gi[1] = L.gi[1];
+    }
+    if (L.kind == 1 && L.qw_sorted[0]) {   // group-sorted copy: trivial-g_idx kernels on x[perm]
+        q.qw[0] = L.qw_sorted[0]; q.gi[0] = nullptr;
+        if (ns == 2) { q.qw[1] = L.qw_sorted[1]; q.gi[1] = nullptr; }
+        if (M == 1 && bits == 4) {            // rowwave GEMV with the gather fused
+            q.xperm = L.perm32;
+            if (int rc = validate(q)) return rc;
+            if (fast_eligible(q, 8)) {
+                const int rc = run_rowwave(q, (hipStream_t)stream);
+                if (rc != GPTQ_E_VARIANT) return rc;
+            }
+            q.xperm = nullptr;
+        }
+        if (scratch && aligned(scratch, 16) && scratch_bytes >= (size_t)M * K * 2) {
+            if (int rc = gather_cols_launch((const half_t *)x, ldx, L.perm32, (half_t *)scratch, K, M, K, (hipStream_t)stream)) return rc;
+            q.x = scratch; q.ldx = K;
+        } else {   // no room for the gathered x: the generic g_idx kernels on the original rows
+            q.qw[0] = L.qw[0]; q.gi[0] = L.gi[0];
+            if (ns == 2) { q.qw[1] = L.qw[1]; q.gi[1] = L.gi[1]; }
+        }
+    }
+    if (int rc = validate(q)) return rc;
+    return run_auto(q, (hipStream_t)stream);
 }
 
 // ---- GPTQ solver: the sequential loop of one column block (gptq_solver.hip) ----

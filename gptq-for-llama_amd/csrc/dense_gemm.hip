@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 #include <hipblaslt/hipblaslt.h>
 
+#include <atomic>
 #include <list>
 #include <map>
 #include <memory>
@@ -118,7 +119,10 @@ std::map<Key, std::list<std::pair<Key, std::shared_ptr<Plan>>>::iterator> g_inde
 
 }  // namespace
 
-bool dense_gemm_available() { return api().ok; }
+static std::atomic<int> g_library_enabled{1};   // test hook: 0 makes every call answer GPTQ_E_LIBRARY, as if hipBLASLt were not installed
+int dense_gemm_set_enabled(int on) { return g_library_enabled.exchange(on ? 1 : 0); }
+
+bool dense_gemm_available() { return g_library_enabled.load() != 0 && api().ok; }
 
 int dense_gemm_plan_count() {
     std::lock_guard<std::mutex> lock(g_mu);
@@ -129,7 +133,7 @@ int dense_gemm_plan_count() {
 int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, const half_t *bias, void *y, int64_t ldy, int M, int K, int N,
                    void *ws, size_t ws_bytes, hipStream_t s, bool trans_w, bool out_f32) {
     const Api &L = api();
-    if (!L.ok) return GPTQ_E_LIBRARY;
+    if (!L.ok || g_library_enabled.load() == 0) return GPTQ_E_LIBRARY;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return GPTQ_E_LIBRARY;
     hipblasLtHandle_t h = nullptr;

@@ -463,6 +463,31 @@ int silu_mul_f32_launch(const float *g, int64_t ldg, const float *u, int64_t ldu
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------- x[:, perm] (act-order batches)
+// xg[m][k] = x[m][perm[k]]: the input of a group-sorted act-order layer (the decode kernel fuses this gather; batches pay one
+// pass over M K halves).  Thread = 8 consecutive k of one row: eight 2-byte gathers (L2-resident x), one 16-byte store.
+__global__ void __launch_bounds__(256) gather_cols_kernel(const half_t *__restrict__ x, int64_t ldx, const int32_t *__restrict__ perm,
+                                                          half_t *__restrict__ xg, int64_t ldg, int K) {
+    const int k8 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (k8 >= K) return;
+    const size_t m = blockIdx.y;
+    const half_t *row = x + m * ldx;
+    half8_t o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = row[perm[k8 + i]];
+    *(half8_t *)(xg + m * ldg + k8) = o;
+}
+
+int gather_cols_launch(const half_t *x, int64_t ldx, const int32_t *perm, half_t *xg, int64_t ldg, int M, int K, hipStream_t s) {
+    if (K % 8 != 0 || ldg % 8 != 0 || ((uintptr_t)xg % 16) != 0) return GPTQ_E_ALIGN;
+    for (int m0 = 0; m0 < M; m0 += 65535) {
+        const int rows = M - m0 < 65535 ? M - m0 : 65535;
+        hipLaunchKernelGGL(gather_cols_kernel, dim3((K / 8 + 255) / 256, rows), dim3(256), 0, s, x + (size_t)m0 * ldx, ldx, perm, xg + (size_t)m0 * ldg,
+                           ldg, K);
+    }
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------- act-order row sort
 // qweight_out row r', field j  <-  the field of k = perm[r' * f + j] in qweight (f = 32 / bits).
 // With perm = stable argsort(g_idx) every packed row of the output holds f consecutive members of

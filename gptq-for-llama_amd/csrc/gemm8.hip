@@ -250,14 +250,8 @@ template <bool PAIR>
 int gemm8_launch(const Gemm8Params &p, hipStream_t s) {
     auto kern = gemm8_kernel<PAIR>;
     constexpr int lds = 2 * BUF_BYTES;   // 131 072 B
-    static bool configured[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;
-    if (dev < 0 || !configured[dev]) {   // per device: the attribute belongs to the device's code object
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        if (dev >= 0) configured[dev] = true;
-    }
+    static LdsOptIn opt_in;   // per instantiation; per device inside
+    if (int rc = opt_in.ensure((const void *)kern, lds)) return rc;
     const int groups_of_8 = (p.ntm + 7) / 8;
     hipLaunchKernelGGL(kern, dim3(groups_of_8 * 8 * p.ntn), dim3(512), lds, s, p);
     return (int)hipGetLastError();

@@ -527,12 +527,8 @@ static int launch_gemm(const GemmParams &p, hipStream_t s) {
     auto kern = gemm_mfma_kernel<BITS>;
     const size_t lds = 4 * (size_t)TILE_BYTES;  // 147 456 B: epilogue staging NWAVE * 128 * CROW (main loop: 2 A + 2 B buffers = 139 264 B)
     static_assert(NWAVE * 128 * CROW <= 4 * TILE_BYTES, "epilogue staging must fit");
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    static LdsOptIn opt_in;   // per instantiation; per device inside
+    if (int rc = opt_in.ensure((const void *)kern, lds)) return rc;
     const int groups_of_8 = (p.ntm + 7) / 8;
     dim3 grid(groups_of_8 * 8 * p.ntn), block(512);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
@@ -577,14 +573,13 @@ int gemm_dispatch(int bits, int set, bool silu_gate, const GemvParams &q, hipStr
     p.ntn = (q.N + GN - 1) / GN;
     if (bits == 4 && q.groupsize % GK == 0 && q.N >= 4 && g_gemm_version.load() == 3) {
         const size_t lds = 4 * (size_t)TILE_BYTES;
-        static bool configured = false;
-        if (!configured) {
+        static LdsOptIn opt_in[5];
+        {
+            int i = 0;
             for (const void *f : {(const void *)gemm_mfma_v3_kernel<0>, (const void *)gemm_mfma_v3_kernel<1>, (const void *)gemm_mfma_v3_kernel<2>,
                                   (const void *)gemm_mfma_v3_kernel<3>, (const void *)gemm_mfma_v3_kernel<4>}) {
-                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return (int)e;
+                if (int rc = opt_in[i++].ensure(f, lds)) return rc;
             }
-            configured = true;
         }
         const int groups_of_8 = (p.ntm + 7) / 8;
         dim3 grid(groups_of_8 * 8 * p.ntn), block(512);

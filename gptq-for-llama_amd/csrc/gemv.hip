@@ -607,12 +607,8 @@ static int launch_generic(const GemvParams &p, hipStream_t stream) {
     const size_t lds = ((a > red_bytes ? a : red_bytes) + 15) & ~(size_t)15;
     if (lds > 160 * 1024 - 64) return GPTQ_E_SHAPE;
     auto kern = gemv_generic_kernel<BITS, NL, WAVES, MR, FUSED2>;
-    static size_t configured = 0;
-    if (lds > 48 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured = lds;
-    }
+    static LdsOptIn opt_in;   // per instantiation; per device inside
+    if (int rc = opt_in.ensure((const void *)kern, lds)) return rc;
     dim3 grid(p.ntiles), block(WAVES * 64);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     return (int)hipGetLastError();

@@ -7,7 +7,32 @@
 #include "../../include/gptq_mi355x.h"
 #include "gptq_device.h"
 
+#include <mutex>
+
 namespace gptq {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the DEVICE's copy of the code object and must never shrink under a
+// concurrent launch: one state per (kernel instantiation, device), raised monotonically under a mutex (round-2 advisor finding:
+// a per-process "configured" word let the second device of a multi-GPU process launch > 48 KB of LDS without the opt-in).
+constexpr int GPTQ_MAX_DEVICES = 32;
+struct LdsOptIn {
+    std::mutex mu;
+    size_t bytes[GPTQ_MAX_DEVICES] = {};
+    int ensure(const void *kern, size_t lds) {
+        if (lds <= 48 * 1024) return 0;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+        std::lock_guard<std::mutex> lock(mu);
+        const bool known = dev >= 0 && dev < GPTQ_MAX_DEVICES;
+        if (!known || lds > bytes[dev]) {
+            const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            if (known) bytes[dev] = lds;
+        }
+        return 0;
+    }
+};
+
 
 constexpr int GEMV_MAX_M = 4;         // rows served by the wavefront-reduction GEMV
 constexpr int SKINNY_MAX_M = 64;      // rows served by the weight-streaming MFMA kernel
@@ -69,10 +94,12 @@ int gemm8_dense_f16(const half_t *x, int64_t ldx, const half_t *wt, int64_t ldw,
 // dense_gemm.hip: y = x . W (+ bias) through hipBLASLt (dlopen'ed), plans cached per shape
 bool dense_gemm_available();
 int dense_gemm_plan_count();   // plans currently cached (bounded LRU)
+int dense_gemm_set_enabled(int on);   // test hook: 0 = behave as if hipBLASLt were absent; returns the previous value
 int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, const half_t *bias, void *y, int64_t ldy, int M, int K, int N,
                    void *ws, size_t ws_bytes, hipStream_t s, bool trans_w = false, bool out_f32 = false);
 int silu_mul_launch(const half_t *g, int64_t ldg, const half_t *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
 int silu_mul_f32_launch(const float *g, int64_t ldg, const float *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
+int gather_cols_launch(const half_t *x, int64_t ldx, const int32_t *perm, half_t *xg, int64_t ldg, int M, int K, hipStream_t s);   // xg = x[:, perm]
 int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 

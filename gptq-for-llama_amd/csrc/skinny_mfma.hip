@@ -517,12 +517,8 @@ static int launch_stream(const GemvParams &p, hipStream_t stream) {
     const size_t lds = ((red > xb ? red : xb) + 15) & ~(size_t)15;
     if (lds > 160 * 1024 - 64) return GPTQ_E_SHAPE;
     auto kern = stream_kernel<BITS, STG, MT, WAVES, XLDS, FUSED2>;
-    static size_t configured = 0;
-    if (lds > 48 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured = lds;
-    }
+    static LdsOptIn opt_in;   // per instantiation; per device inside
+    if (int rc = opt_in.ensure((const void *)kern, lds)) return rc;
     dim3 grid(p.ntiles, p.split_k), block(WAVES * 64);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     return (int)hipGetLastError();

@@ -30,6 +30,9 @@ _SIGNATURES = {
     'gptq_set_debug_buffer': [c_void_p],
     'gptq_set_gemm_kernel': [c_int],
     'gptq_set_prefill_route': [c_int],
+    'gptq_prefill_route_for': [c_int, c_int, c_int, c_int, c_int],
+    'gptq_set_library_enabled': [c_int],
+    'gptq_prefill_plan_count': [],
     'gptq_matmul248_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],
     'gptq_gemv_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -94,6 +97,16 @@ _SIGNATURES = {
     'gptq_p2p_allreduce_silu_mul_f32': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'gptq_stripe_matmul_f16': [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                c_size_t, c_void_p],
+    'gptq_layer_inspect': [c_void_p, c_int, c_int, c_void_p],
+    'gptq_layer_image_bytes': [c_int, c_int, c_int, c_int, c_int, c_int],
+    'gptq_layer_prepare': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                           c_int, c_void_p, c_size_t, c_void_p],
+    'gptq_layer_destroy': [c_void_p],
+    'gptq_layer_kind': [c_void_p],
+    'gptq_layer_stripe_image': [c_void_p, c_void_p, c_void_p, c_void_p],
+    'gptq_layer_workspace_bytes': [],
+    'gptq_layer_scratch_bytes': [c_void_p, c_int],
+    'gptq_layer_forward': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p],
     'gptq_stripe_matvec_partial_f32': [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
 }
 
@@ -126,6 +139,10 @@ def lib():
             L.gptq_stripe_bytes.restype = c_size_t
             L.gptq_p2p_buffer_bytes.restype = c_size_t
             L.gptq_prefill_workspace_bytes.restype = c_size_t
+            L.gptq_layer_image_bytes.restype = c_size_t
+            L.gptq_layer_workspace_bytes.restype = c_size_t
+            L.gptq_layer_scratch_bytes.restype = c_size_t
+            L.gptq_layer_destroy.restype = None
             L.gptq_strerror.argtypes = [c_int]
             L.gptq_strerror.restype = ctypes.c_char_p
             _lib = L
@@ -171,6 +188,28 @@ def workspace(device, stream=None):
         with torch.cuda.device(idx):
             ws = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device('cuda', idx))
         _workspaces[key] = ws
+    return ws
+
+
+_layer_workspaces = {}
+
+
+def layer_workspace(device, stream=None):
+    """The persistent workspace of gptq_layer_forward, one per (device, stream): [split-K words, zero-initialised and left zero by
+    every call][scratch of the 16-row MFMA tiles].  Launches that may overlap (different streams; a captured graph replaying next
+    to eager work) must not share it, hence the stream in the key; buffers live as long as the process (a captured hipGraph keeps
+    pointing at the one of its capture stream)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if stream is None:
+        stream = torch.cuda.current_stream(torch.device('cuda', idx)).cuda_stream
+    key = (device.type, idx, int(stream))
+    ws = _layer_workspaces.get(key)
+    if ws is None:
+        L = lib()
+        with torch.cuda.device(idx):
+            ws = torch.empty(L.gptq_layer_workspace_bytes(), dtype=torch.uint8, device=torch.device('cuda', idx))
+            ws[:L.gptq_query(3)].zero_()
+        _layer_workspaces[key] = ws
     return ws
 
 

@@ -32,19 +32,20 @@ def _infer_groupsize(K, G):
     return K if G <= 1 else -(-K // G)
 
 
-def _ver(t):
-    """version counter of a tensor; inference-mode tensors have none (they are immutable outside inference mode)."""
-    try:
-        return t._version
-    except Exception:
-        return -1
+from torch.utils.weak import WeakTensorKeyDictionary   # identity-keyed, entries die with the tensor: no attributes on tensors
+
+from .layer import _ver, prepared
+
+# derived state of the helper functions below (the engines that drive the stripe kernels themselves use them; the modules go
+# through quant.layer.prepared): tensor object -> (validity key, value)
+_TRIVIAL, _SORTED, _STRIPE, _U16 = (WeakTensorKeyDictionary() for _ in range(4))
 
 
 def g_idx_is_trivial(g_idx, K, groupsize):
-    """True iff g_idx[:K] == arange(K) // groupsize.  The verdict is memoised ON the tensor object
-    (keyed by its version counter), never by address: the caching allocator hands the address of
+    """True iff g_idx[:K] == arange(K) // groupsize.  The verdict is memoised per tensor OBJECT
+    (validated by its version counter), never by address: the caching allocator hands the address of
     a freed g_idx to the next one."""
-    memo = getattr(g_idx, '_gptq_trivial', None)
+    memo = _TRIVIAL.get(g_idx)
     key = (_ver(g_idx), K, groupsize)
     if memo is not None and memo[0] == key:
         return memo[1]
@@ -58,17 +59,14 @@ def g_idx_is_trivial(g_idx, K, groupsize):
         res = bool(out.item())
     else:
         res = bool(torch.equal(g.to(torch.int64), torch.arange(K, dtype=torch.int64) // groupsize))
-    try:
-        g_idx._gptq_trivial = (key, res)
-    except Exception:  # pragma: no cover
-        pass
+    _TRIVIAL[g_idx] = (key, res)
     return res
 
 
 # ----------------------------------------------------------------------------------------------
 # Act-order fast path: sort the packed rows by group once (stable argsort of g_idx) so that the
 # layer becomes a trivial-g_idx layer of x[perm].  The re-sorted copy of qweight
-# and perm are cached ON the qweight tensor (keyed by the version counters of qweight and g_idx); the
+# and perm are cached per qweight tensor object (validated by the version counters of qweight and g_idx); the
 # checkpoint buffers themselves are never modified.  Costs one extra copy of qweight per act-order
 # layer; set GPTQ_ACT_ORDER_SORT=0 to keep the generic g_idx-table kernel instead.
 # ----------------------------------------------------------------------------------------------
@@ -85,8 +83,8 @@ def act_order_sorted(qweight, g_idx, K, groupsize, bits):
     f = 32 // bits
     if groupsize % f != 0 or K % groupsize != 0:
         return None
-    memo = getattr(qweight, '_gptq_sorted', None)
-    key = (_ver(qweight), _ver(g_idx), K, groupsize)
+    memo = _SORTED.get(qweight)
+    key = (_ver(qweight), _ver(g_idx), g_idx.data_ptr(), K, groupsize)
     if memo is not None and memo[0] == key:
         return memo[1]
     g = g_idx[:K].to(torch.int64)
@@ -99,18 +97,15 @@ def act_order_sorted(qweight, g_idx, K, groupsize, bits):
                                                  _native.stream_ptr(qweight.device))
         _native.check(rc, 'gptq_act_order_repack')
         res = (qs, perm)
-    try:
-        qweight._gptq_sorted = (key, res)
-    except Exception:  # pragma: no cover
-        pass
+    _SORTED[qweight] = (key, res)
     return res
 
 
 # ----------------------------------------------------------------------------------------------
 # stripe16 decode path (csrc/stripe.hip): at M == 1 a 4-bit layer is served from a load-time repacked
 # copy in which every workgroup's 16 output columns are contiguous (no K split, no combine atomics).
-# The copy is built once per weight set (or gate/up pair) by gptq_stripe_repack and cached ON the qweight
-# tensor, keyed by the version counters of the checkpoint buffers -- which stay untouched and remain the
+# The copy is built once per weight set (or gate/up pair) by gptq_stripe_repack and cached per qweight
+# tensor object, validated by the version counters of the checkpoint buffers -- which stay untouched and remain the
 # state_dict.  Costs one extra copy of the packed weights; GPTQ_STRIPE=0 keeps the rowwave kernels.
 # ----------------------------------------------------------------------------------------------
 STRIPE = _os.environ.get('GPTQ_STRIPE', '1') != '0'
@@ -131,7 +126,7 @@ def stripe_copy(qweight, scales, qzeros, bits, groupsize, up=None):
         return None
     srcs = (qweight, scales, qzeros) + (tuple(up) if up is not None else ())
     key = tuple((_ver(t), t.data_ptr(), tuple(t.shape)) for t in srcs) + (groupsize,)
-    memo = getattr(qweight, '_gptq_stripe', None)
+    memo = _STRIPE.get(qweight)
     if memo is not None and memo[0] == key:
         return memo[1]
     if any(t.dtype != d or not t.is_contiguous() for t, d in zip(srcs, (torch.int32, torch.float16, torch.int32) * 2)):
@@ -142,10 +137,7 @@ def stripe_copy(qweight, scales, qzeros, bits, groupsize, up=None):
         rc = lib.gptq_stripe_repack(qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), _native.ptr(u[0]), _native.ptr(u[1]),
                                     _native.ptr(u[2]), st.data_ptr(), nbytes, K, N, bits, groupsize, _native.stream_ptr(qweight.device))
     _native.check(rc, 'gptq_stripe_repack')
-    try:
-        qweight._gptq_stripe = (key, st)
-    except Exception:  # pragma: no cover
-        pass
+    _STRIPE[qweight] = (key, st)
     return st
 
 
@@ -154,13 +146,10 @@ def perm_u16(perm):
     K <= 24576 on that path).  None stays None."""
     if perm is None:
         return None
-    p16 = getattr(perm, '_gptq_u16', None)
+    p16 = _U16.get(perm)
     if p16 is None:
         p16 = perm.to(torch.int16)          # bit pattern of the uint16 value: every index is below 32768
-        try:
-            perm._gptq_u16 = p16
-        except Exception:  # pragma: no cover
-            pass
+        _U16[perm] = p16
     return p16
 
 
@@ -229,52 +218,28 @@ def _prep_weight(input, qweight, scales, qzeros, g_idx, bits):
     return K, N, groupsize, qweight, scales, qzeros, gi
 
 
-def _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family):
-    """act-order layer through its group-sorted copy: fused gather + rowwave GEMV (M == 1, 4-bit), else
-    x[:, perm] with torch and the trivial-g_idx kernels."""
-    qs, perm = srt
-    lib = _native.lib()
-    if M == 1 and bits == 4 and family in (None, 'gemv'):
-        rc = lib.gptq_matmul248_sorted_f16(x.data_ptr(), K, perm.data_ptr(), qs.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
-                                           _native.ptr(bias), out.data_ptr(), N, 1, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
-                                           _native.stream_ptr(x.device))
-        if rc != -6:
-            _native.check(rc, 'gptq_matmul248_sorted_f16')
-            return
-    xp = x.index_select(1, perm)
-    if family is None and M <= STRIPE_MM_MAX_M:
-        # batches of an act-order layer: one gather of x, then the stripe16 kernels on the image of the group-sorted rows
-        st = stripe_copy(qs, scales, qzeros, bits, groupsize)
-        if st is not None:
-            if M <= (8 if N <= 4608 else 4) and stripe_matvec(xp, st, out, K, N, bits, groupsize, bias=bias, strict=False):
-                return
-            if stripe_matmul(xp, st, out, K, N, bits, groupsize, bias=bias, strict=False):
-                return
-    rc = getattr(lib, _FAMILIES[family])(xp.data_ptr(), K, qs.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), None, _native.ptr(bias),
-                                         out.data_ptr(), N, M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
-                                         _native.stream_ptr(x.device))
-    _native.check(rc, _FAMILIES[family])
-
-
-# M regimes of the built-in dispatch (DESIGN.md "dispatch"): the C ABI serves every M with its own kernels, but above the
-# weight-streaming kernels (M <= STREAM_MAX_M = 64; stripe16 MFMA tiles up to 128 rows) the product is a dense GEMM whose weight
-# bytes no longer matter.  There the weight is dequantised once per call (our kernel, reference numerics, 10-20 us for a
-# LLaMA-7B layer) and multiplied by the library GEMM: measured 1.12-1.39x the fused MFMA tile kernel of csrc/gemm_mfma.hip at every
-# M from 256 to 65 536 (profiles/r2e_prefill/prefill_routes.txt).  GPTQ_PREFILL=fused keeps the fused tile kernel for grids of
-# >= GEMM_MIN_TILES 256 x 256 tiles (no transient fp16 weight: K N 2 bytes per call; smaller grids still take the library, as they
-# took torch.matmul before); GPTQ_PREFILL=own never calls the library: every M on the C ABI's own kernels.  family= bypasses the choice.
+# M regimes (DESIGN.md "dispatch"): the table itself lives in the C library since round 3 (gptq_layer_forward, csrc/capi.hip) --
+# decode matvec / row groups / 16-row MFMA tiles on the stripe16 image up to 128 rows, above that the layer is dequantised once per
+# call and multiplied by the hand-written tile GEMM of csrc/gemm8.hip (hipBLASLt below one full round of its tiles).  What stays
+# here are the knobs of tests and A/B runs, all of them C-side switches:
+#   GPTQ_PREFILL = auto (default) | library (hipBLASLt for every dense product) | own (the tile GEMM wherever it can run)
+#   GPTQ_STRIPE = 0 (no derived copies: checkpoint-layout kernels only), GPTQ_ACT_ORDER_SORT = 0 (generic g_idx kernels)
 STREAM_MAX_M = 64
-GEMM_MIN_TILES = 192
-PREFILL_ROUTE = _os.environ.get('GPTQ_PREFILL', 'library')
-if PREFILL_ROUTE not in ('library', 'fused', 'own'):
-    raise RuntimeError("GPTQ_PREFILL must be 'library', 'fused' or 'own', got %r" % PREFILL_ROUTE)
+PREFILL_ROUTE = _os.environ.get('GPTQ_PREFILL', 'auto')
+if PREFILL_ROUTE == 'fused':      # round-2 spelling
+    PREFILL_ROUTE = 'own'
+if PREFILL_ROUTE not in ('auto', 'library', 'own'):
+    raise RuntimeError("GPTQ_PREFILL must be 'auto', 'library' or 'own', got %r" % PREFILL_ROUTE)
+_ROUTE_CODE = {'library': 0, 'auto': 1, 'own': 2}
+_route_applied = None
 
 
-def _mid_m(M, N):
-    """True when a batch of M rows goes through dequantise-once + library GEMM"""
-    if PREFILL_ROUTE == 'own':
-        return False
-    return M > STREAM_MAX_M and (PREFILL_ROUTE == 'library' or (-(-M // 256)) * (-(-N // 256)) < GEMM_MIN_TILES)
+def _apply_prefill_route():
+    """push GPTQ_PREFILL (or a test's monkeypatched PREFILL_ROUTE) into the library's switch"""
+    global _route_applied
+    if _route_applied != PREFILL_ROUTE:
+        _native.lib().gptq_set_prefill_route(_ROUTE_CODE[PREFILL_ROUTE])
+        _route_applied = PREFILL_ROUTE
 
 
 def dequantize(qweight, scales, qzeros, g_idx, bits, groupsize=None, out=None):
@@ -319,20 +284,6 @@ def _library_refused(rc, what):
     return True
 
 
-def prefill_matmul(x, qweight, scales, qzeros, gi, bias, out, K, N, bits, groupsize):
-    """out[M, N] = x . deq(W) (+ bias) through gptq_prefill_matmul_f16: dequantise once per call into a transient workspace (caching
-    allocator: the next layer reuses it), dense product by hipBLASLt, bias in its epilogue.  gi: None or the int32 g_idx of an
-    act-order layer (no gather of x on this route)."""
-    lib = _native.lib()
-    x = _prefill_operand(x)
-    M = x.shape[0]
-    ws = torch.empty(lib.gptq_prefill_workspace_bytes(M, K, N, 1), dtype=torch.uint8, device=x.device)
-    rc = lib.gptq_prefill_matmul_f16(x.data_ptr(), x.stride(0), qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(), _native.ptr(gi),
-                                     _native.ptr(bias), out.data_ptr(), out.stride(0), M, K, N, bits, groupsize, ws.data_ptr(), ws.numel(),
-                                     _native.stream_ptr(x.device))
-    return None if _library_refused(rc, 'gptq_prefill_matmul_f16') else out
-
-
 def silu_mul(gate, up, out=None):
     """out = fp16(silu(gate) * up) in fp32 math (reference fused_mlp.py:160-165) for two [M, N] fp16 matrices with unit column
     stride (row strides free: the halves of one [M, 2N] product)."""
@@ -349,15 +300,32 @@ def silu_mul(gate, up, out=None):
     return out
 
 
-_FAMILIES = {None: 'gptq_matmul248_f16', 'abi': 'gptq_matmul248_f16', 'gemv': 'gptq_gemv_f16', 'skinny': 'gptq_skinny_f16',
-             'stripe': 'gptq_matmul248_f16', 'stripe_mm': 'gptq_matmul248_f16'}
+_FAMILIES = {'abi': 'gptq_matmul248_f16', 'gemv': 'gptq_gemv_f16', 'skinny': 'gptq_skinny_f16'}
 
 
 def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, family=None):
     """``input [M,K] fp16 -> [M,N] fp16`` on the current stream of ``input.device``
     (reference matmul248, quant/quant_linear.py:263-269; ``bias`` is an extension that fuses
-    the add of QuantLinear.forward, :376).  ``family`` (tests / benchmarks only) forces one kernel
-    family of the C ABI instead of the built-in M dispatch."""
+    the add of QuantLinear.forward, :376).  The call goes to the layer's prepared handle (quant/layer.py ->
+    gptq_layer_forward: the M -> kernel table is in the C library).  ``family`` (tests / benchmarks only) names ONE kernel
+    family of the C ABI instead: 'abi' gptq_matmul248_f16, 'gemv', 'skinny', 'stripe' (decode kernel, row groups up to 16
+    rows), 'stripe_mm' (16-row MFMA tiles)."""
+    _native.require_device(input, 'matmul248')
+    if bits not in SUPPORTED_BITS:
+        raise NotImplementedError('Only 2,3,4,8 bits are supported.')
+    if family is None:
+        K, N = qweight.shape[0] * 32 // bits, qweight.shape[1]
+        x = _as_rows(input)
+        if x.shape[1] != K:
+            raise RuntimeError('matmul248: input has %d features, weight expects %d' % (x.shape[1], K))
+        M = x.shape[0]
+        _apply_prefill_route()
+        with torch.cuda.device(x.device):
+            out = torch.empty((M, N), device=x.device, dtype=torch.float16)
+            if M == 0:
+                return out
+            pl = prepared(((qweight, scales, qzeros, g_idx),), bias, bits, _infer_groupsize(K, scales.shape[0]), K, N, sort=ACT_ORDER_SORT)
+            return pl.forward(x, out)
     K, N, groupsize, qweight, scales, qzeros, gi = _prep_weight(input, qweight, scales, qzeros, g_idx, bits)
     x = _as_rows(input)
     if x.shape[1] != K:
@@ -368,35 +336,18 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
         if M == 0:
             return out
         ws = _native.workspace(x.device)
-        srt = act_order_sorted(qweight, gi, K, groupsize, bits) if (gi is not None and not (family is None and _mid_m(M, N) and M > STRIPE_MM_MAX_M)) else None
-        # stripe16 image: M <= 4 rows share the decode launch for free; 5..8 rows = two 4x4x4 row groups while x fits in LDS;
-        # 5..64 rows otherwise = 16-row MFMA tiles (stripe_mm.inc); profiles/r2c_mm has the three measured side by side.
-        # family='stripe' pins the decode kernel (row groups up to 16 rows), 'stripe_mm' the MFMA-tile kernel.
-        # (row groups only while ONE round of workgroups covers N: 5.1 vs 5.7 us at 4096^2, but 12.6 vs 11.9 at N = 12288)
-        stripe_m = M == 1 or (gi is None and M <= (STRIPE_MAX_M if family == 'stripe' else (8 if N <= 4608 else 4)))
-        if family in (None, 'stripe') and stripe_m and (gi is None or srt is not None):
-            # decode: no-split-K kernel on the stripe16 copy (of the group-sorted rows for an act-order layer)
-            st = stripe_copy(srt[0] if srt is not None else qweight, scales, qzeros, bits, groupsize)
-            if st is not None and stripe_matvec(x, st, out, K, N, bits, groupsize, bias=bias, perm=srt[1] if srt is not None else None,
-                                                strict=family == 'stripe'):
-                return out
-        if family in (None, 'stripe_mm') and gi is None and bits in (2, 3, 4, 8) and (4 < M or family == 'stripe_mm') and M <= (256 if family == 'stripe_mm' else STRIPE_MM_MAX_M):
-            st = stripe_copy(qweight, scales, qzeros, bits, groupsize)
+        if family == 'stripe':
+            srt = act_order_sorted(qweight, gi, K, groupsize, bits) if gi is not None else None
+            if (M == 1 or (gi is None and M <= STRIPE_MAX_M)) and (gi is None or srt is not None):
+                st = stripe_copy(srt[0] if srt is not None else qweight, scales, qzeros, bits, groupsize)
+                if st is not None and stripe_matvec(x, st, out, K, N, bits, groupsize, bias=bias, perm=srt[1] if srt is not None else None):
+                    return out
+            raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M <= 16, K a multiple of the row block ...)')
+        if family == 'stripe_mm':
+            st = stripe_copy(qweight, scales, qzeros, bits, groupsize) if (gi is None and M <= 256) else None
             if st is not None and stripe_matmul(x, st, out, K, N, bits, groupsize, bias=bias, strict=False):
                 return out
-        if family == 'stripe_mm':
             raise RuntimeError('matmul248: the stripe16 MFMA kernel does not serve this shape (M <= 256, a stripe16 image of the layer)')
-        if family is None and srt is not None and 1 < M <= STRIPE_MM_MAX_M:
-            _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family)     # gather + stripe kernels (or the C-ABI ones)
-            return out
-        if family is None and _mid_m(M, N):
-            if prefill_matmul(x, qweight, scales, qzeros, gi, bias, out, K, N, bits, groupsize) is not None:
-                return out          # (None: no hipBLASLt -> the C ABI's own kernels below, generic g_idx kernel for an act-order layer)
-        if family == 'stripe':
-            raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M <= 4, bits in 2/4/8, K a multiple of the row block ...)')
-        if srt is not None:
-            _matmul_sorted(x, srt, scales, qzeros, bias, out, M, K, N, bits, groupsize, ws, family)
-            return out
         rc = getattr(_native.lib(), _FAMILIES[family])(
             x.data_ptr(), x.stride(0) if M > 1 else K, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
             _native.ptr(gi), _native.ptr(bias), out.data_ptr(), N, M, K, N, bits, groupsize,
@@ -413,10 +364,10 @@ TRANSPOSE_LIBRARY_MIN_M = 16
 
 def transpose_matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, family=None):
     """``input [M,N] fp16 -> [M,K] fp16`` = input . deq(B)^T (reference transpose_matmul248,
-    quant/quant_linear.py:272-279).  From TRANSPOSE_LIBRARY_MIN_M rows on the product takes the prefill route (dequantise once per
-    call + hipBLASLt with the transposition flag, gptq_prefill_transpose_matmul248_f16: 100x the LDS-tiled kernel of
-    csrc/transpose.hip at M = 4096, profiles/r2e_prefill/backward_routes.txt); fewer rows, family='abi' or GPTQ_PREFILL=fused
-    keep that kernel."""
+    quant/quant_linear.py:272-279).  From TRANSPOSE_LIBRARY_MIN_M rows on the product takes the prefill route
+    (gptq_prefill_transpose_matmul248_f16: dequantise once per call, then the tile GEMM of csrc/gemm8.hip with the roles of K and N
+    exchanged -- 1.2-1.3 PF at M >= 4096 -- or hipBLASLt below one round of its tiles); fewer rows or family='abi' keep the
+    LDS-tiled kernel of csrc/transpose.hip."""
     K, N, groupsize, qweight, scales, qzeros, gi = _prep_weight(input, qweight, scales, qzeros, g_idx, bits)
     dy = _as_rows(input)
     if dy.shape[1] != N:
@@ -426,7 +377,8 @@ def transpose_matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, famil
         out = torch.empty((M, K), device=dy.device, dtype=torch.float16)
         if M == 0:
             return out
-        if family is None and PREFILL_ROUTE == 'library' and M >= TRANSPOSE_LIBRARY_MIN_M and K >= 256 and N >= 256:    # ordinary shapes only
+        if family is None and M >= TRANSPOSE_LIBRARY_MIN_M and K >= 256 and N >= 256:    # ordinary shapes only
+            _apply_prefill_route()
             lib = _native.lib()
             dy = _prefill_operand(dy)
             ws = torch.empty(lib.gptq_prefill_workspace_bytes(M, K, N, 1), dtype=torch.uint8, device=dy.device)

@@ -76,9 +76,17 @@ int gptq_set_split_k(int split_k);
  * kernel with packed B in LDS (4-bit, groupsize % 64 == 0; measured 2-4 % slower).  Returns the previous value. */
 int gptq_set_gemm_kernel(int version);
 /* Prefill route behind gptq_prefill_matmul_f16 / _fused_mlp_f16 / _transpose_matmul248_f16 (tests / A-B measurements):
- * 1 = the hand-written LDS-DMA + MFMA tile GEMM of csrc/gemm8.hip on the dequantised weight (default), 0 = hipBLASLt on the
- * dequantised weight (reported ceiling; also what serves shapes the tile GEMM does not: K % 128 != 0).  Returns the previous value. */
+ * 1 (default) = the hand-written LDS-DMA + MFMA tile GEMM of csrc/gemm8.hip on the dequantised weight wherever it is at least
+ * on par (M >= 2048 and one full round of 256 x 256 tiles), hipBLASLt below that; 2 = the tile GEMM wherever it can run
+ * (K % 128 == 0); 0 = hipBLASLt only (the reported ceiling).  Returns the previous value. */
 int gptq_set_prefill_route(int route);
+/* which engine a dense product of this shape takes under the current switch: 1 = tile GEMM, 0 = hipBLASLt (host logic only;
+ * nsets = 2: gate/up pair; trans = 1: the backward product) */
+int gptq_prefill_route_for(int M, int K, int N, int nsets, int trans);
+/* test hooks: make every library call answer GPTQ_E_LIBRARY as if hipBLASLt were not installed (returns the previous setting);
+ * number of hipBLASLt plans currently cached (bounded LRU of 64) */
+int gptq_set_library_enabled(int on);
+int gptq_prefill_plan_count(void);
 /* Development aid: when non-NULL, the decode kernels write per-wave s_memtime checkpoints
  * ([block][wave][8] uint64) into this device buffer.  Returns the previous pointer. */
 void *gptq_set_debug_buffer(void *device_buffer);
@@ -362,6 +370,38 @@ int gptq_p2p_allreduce_f32(const float *partial, void *const *peer_buffers, int 
  * y_f16[n_half] = fp16(silu(sum gate) * sum up) -- the epilogue of fusedmatmul_248_kernel (quant/fused_mlp.py:160-166), after the reduce. */
 int gptq_p2p_allreduce_silu_mul_f32(const float *partial, void *const *peer_buffers, int rank, int world, int n_half, int n_max, void *y_f16,
                                     gptq_stream_t stream);
+
+/* ---- Prepared layers: the ONE call site of the product ------------------------------------------------------------------
+ * The reference reaches its kernels through a single call, matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq)
+ * (quant/quant_linear.py:263-269) behind QuantLinear.forward (:373-377) -- and fusedmatmul_248 behind QuantLlamaMLP
+ * (quant/fused_mlp.py:203-218) -- with an autotuner that picks a kernel per M (custom_autotune.py).  Here a layer is PREPARED once
+ * (load time): g_idx is inspected on the host (0 trivial / 1 regular act-order / 2 irregular), the stripe16 image -- of the
+ * group-sorted rows plus the permutation for a regular act-order layer -- is built into the caller's image buffer, and
+ * gptq_layer_forward() contains the whole M -> kernel table: decode matvec (M = 1, the headline path), row groups (M <= 8),
+ * 16-row MFMA tiles (M <= 128), the prefill tile GEMM / library route above, the checkpoint-layout kernels for whatever has no
+ * image.  A non-Python consumer binds exactly these entries and gets the product's speed.
+ *
+ * Memory stays the caller's: `image` (gptq_layer_image_bytes, 256-byte aligned; NULL = no derived copies, checkpoint-layout
+ * kernels only), `workspace` (gptq_layer_workspace_bytes(); its first gptq_query(GPTQ_Q_WORKSPACE_BYTES) bytes must be ZERO on
+ * first use and are left zero by every call -- one per stream that may run concurrently), `scratch` (gptq_layer_scratch_bytes(layer,
+ * M): transient, may be NULL -- forward then takes a slower route that needs none).  The checkpoint buffers are borrowed and must
+ * outlive the handle; the handle is a small host object.  gptq_layer_prepare / _inspect synchronise the stream (load time);
+ * gptq_layer_forward only enqueues and is hipGraph-capturable.  nsets = 2 (qweight_up != NULL): y = silu(x Wg) * (x Wu).
+ */
+typedef struct gptq_layer gptq_layer_t;
+int gptq_layer_inspect(const int32_t *g_idx, int K, int groupsize, gptq_stream_t stream);   /* 0 / 1 / 2, or GPTQ_E_* */
+size_t gptq_layer_image_bytes(int K, int N, int bits, int groupsize, int nsets, int kind);
+int gptq_layer_prepare(gptq_layer_t **layer, const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *g_idx,
+                       const void *bias, const int32_t *qweight_up, const void *scales_up, const int32_t *qzeros_up,
+                       const int32_t *g_idx_up, int K, int N, int bits, int groupsize, void *image, size_t image_bytes,
+                       gptq_stream_t stream);
+void gptq_layer_destroy(gptq_layer_t *layer);
+int gptq_layer_kind(const gptq_layer_t *layer);
+int gptq_layer_stripe_image(const gptq_layer_t *layer, const void **stripe, size_t *stripe_bytes, const uint16_t **perm16);
+size_t gptq_layer_workspace_bytes(void);
+size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M);
+int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace,
+                       size_t workspace_bytes, void *scratch, size_t scratch_bytes, gptq_stream_t stream);
 
 /* ---- GPTQ solver (the caller that PRODUCES the weights; reference gptq.py:128-228) -------------------------------
  * One column block [i1, i1 + count), count <= 128, of the sequential quantise / error-feedback loop (gptq.py:177-199)

@@ -177,12 +177,11 @@ def test_dequantize_is_bit_exact_with_the_reference_weight(bits, gs, act):
 
 @pytest.mark.parametrize('M', [65, 100, 700])
 def test_mid_m_route(M):
-    """17 <= M < "GPU full of 256 x 256 tiles": dequantise once + dense GEMM; same answer as the ABI's
-    own kernels for that M."""
+    """above the weight-streaming kernels, below a GPU full of 256 x 256 tiles (gptq_layer_forward: 16-row MFMA tiles up to 128
+    rows, then dequantise once + dense product): same answer as the ABI's own kernels for that M."""
     L = make_random_layer(4, 128, 1024, 512, seed=M)
     x = np.random.default_rng(M).standard_normal((M, 1024)).astype(np.float16)
     bias = np.random.default_rng(1).standard_normal(512).astype(np.float16)
-    assert QL._mid_m(M, 512) == (QL.PREFILL_ROUTE != 'own')
     y, _ = check_forward(x, L, bias=bias)
     y_abi, _ = check_forward(x, L, bias=bias, family='abi')
     assert rel_err(y, y_abi) < TOL
@@ -215,14 +214,20 @@ def test_dequantize_into_a_strided_view_and_silu_mul():
     assert _native.lib().gptq_silu_mul_f16(dy.data_ptr(), 2 * N, dy.data_ptr(), 2 * N, dy.data_ptr(), 2 * N, 4, N + 4, None) == -2      # N % 8
 
 
-@pytest.mark.parametrize('route', ['library', 'fused', 'own'])
+@pytest.mark.parametrize('route', ['auto', 'library', 'own'])
 @pytest.mark.parametrize('bits,gs,act,M,K,N', [(4, 128, False, 4096, 4096, 4096), (4, 128, True, 2100, 1024, 4096), (3, -1, False, 700, 512, 320),
                                                (2, 64, False, 300, 1024, 512), (8, 128, False, 8192, 512, 4096)])
 def test_prefill_routes_vs_oracle(route, bits, gs, act, M, K, N, monkeypatch):
-    """the built-in dispatch above the streaming kernels, both settings of GPTQ_PREFILL: 'library' = our dequantise kernel + the
-    library GEMM (default), 'fused' = the MFMA tile kernel once the grid has enough tiles, 'own' = never the library; against the CPU oracle
-    on sampled rows."""
+    """the built-in dispatch above the streaming kernels under every setting of GPTQ_PREFILL: 'auto' = the tile GEMM of csrc/gemm8.hip
+    from one full round of its tiles on, hipBLASLt below (default); 'library' = hipBLASLt for every dense product; 'own' = the tile
+    GEMM wherever it can run (K % 128 == 0); against the CPU oracle on sampled rows."""
     monkeypatch.setattr(QL, 'PREFILL_ROUTE', route)
+    lib = _native.lib()
+    QL._apply_prefill_route()
+    if route != 'library' and K % 128 == 0 and (route == 'own' or M >= 2048):
+        assert lib.gptq_prefill_route_for(M, K, N, 1, 0) == (1 if (route == 'own' or -(-M // 256) * -(-N // 256) >= 256) else 0)
+    if route == 'library':
+        assert lib.gptq_prefill_route_for(M, K, N, 1, 0) == 0
     L = make_random_layer(bits, gs, K, N, act_order=act, seed=M + K + bits)
     rng = np.random.default_rng(17)
     x = rng.standard_normal((M, K)).astype(np.float16)
@@ -231,14 +236,20 @@ def test_prefill_routes_vs_oracle(route, bits, gs, act, M, K, N, monkeypatch):
     rows = np.unique(np.concatenate([np.arange(0, M, max(M // 24, 1)), [M - 1, 63, 64, 255, 256]]))
     ref = oracle_forward(x[rows], L, bias=bias)
     assert rel_err(y[rows], ref) < TOL, rel_err(y[rows], ref)
+    monkeypatch.setattr(QL, 'PREFILL_ROUTE', 'auto')
+    QL._apply_prefill_route()
 
 
+@pytest.mark.parametrize('route', ['library', 'own'])
 @pytest.mark.parametrize('bits,gs,act,M', [(4, 128, False, 1000), (4, 128, True, 300), (2, 64, False, 200), (3, -1, False, 129), (8, 32, False, 333),
-                                           (4, 128, False, 16384 + 77)])
-def test_fused_mlp_prefill_library_route(bits, gs, act, M):
-    """fused_gate_up above the streaming kernels (gptq_prefill_fused_mlp_f16): gate | up in one [K, 2N] matrix, one library GEMM per
-    chunk of 16 384 rows (last case: a ragged second chunk), silu * mul as its own pass -- every width, act-order included,
-    against the fused oracle (sampled rows for the long batch)."""
+                                           (4, 128, False, 8192 + 77)])
+def test_fused_mlp_prefill_routes(bits, gs, act, M, route, monkeypatch):
+    """fused_gate_up above the streaming kernels (gptq_prefill_fused_mlp_f16), both engines: 'own' = gate and up stacked as ONE
+    [2N, K] operand of the tile GEMM, SiLU on the fp32 accumulators in its epilogue; 'library' = gate | up in one [K, 2N] matrix,
+    one hipBLASLt GEMM with FP32 output per chunk of 8192 rows (last case: a ragged second chunk), silu * mul on the fp32 products
+    as its own pass.  Every width, act-order included, against the fused oracle at the op-level bar (1e-3: no rounding of gate / up
+    before the activation on either route -- reference fused_mlp.py:160-165)."""
+    monkeypatch.setattr(QL, 'PREFILL_ROUTE', route)
     K, N = 512, 320 if bits == 3 else 288
     A = make_random_layer(bits, gs, K, N, act_order=act, seed=M)
     B = make_random_layer(bits, gs, K, N, act_order=act, seed=M + 1)
@@ -248,33 +259,38 @@ def test_fused_mlp_prefill_library_route(bits, gs, act, M):
     gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
     up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
     c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs if gs != -1 else K).cpu().numpy()
-    rows = np.arange(M) if M <= 1000 else np.unique(np.concatenate([np.arange(0, M, 257), [16383, 16384, M - 1]]))
+    rows = np.arange(M) if M <= 1000 else np.unique(np.concatenate([np.arange(0, M, 257), [8191, 8192, M - 1]]))
     ref = oracle.fused_mlp(x[rows], (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits)
-    assert rel_err(c[rows], ref) < 2e-3        # gate and up are rounded to fp16 before SiLU * mul on this route
+    assert rel_err(c[rows], ref) < TOL, rel_err(c[rows], ref)
+    monkeypatch.setattr(QL, 'PREFILL_ROUTE', 'auto')
+    QL._apply_prefill_route()
 
 
 def test_prefill_falls_back_to_the_own_kernels_without_the_library(monkeypatch):
-    """GPTQ_E_LIBRARY (hipBLASLt not loadable) from the prefill entries: one warning, then the library-free kernels of the C ABI
-    answer -- forward, fused MLP and backward, same results."""
+    """GPTQ_E_LIBRARY (hipBLASLt not loadable) from the prefill entries: the library-free kernels of the C ABI answer -- forward,
+    fused MLP (inside gptq_layer_forward) and backward (one Python warning), same results."""
     lib = _native.lib()
-    for name in ('gptq_prefill_matmul_f16', 'gptq_prefill_fused_mlp_f16', 'gptq_prefill_transpose_matmul248_f16'):
-        monkeypatch.setattr(lib, name, lambda *a: -8)
     monkeypatch.setattr(QL, '_library_warned', False)
-    K, N, M = 512, 288, 300
+    K, N, M = 512, 288, 300          # a shape the tile GEMM leaves to the library under 'auto' (less than one round of tiles)
     L = make_random_layer(4, 128, K, N, seed=9)
     U = make_random_layer(4, 128, K, N, seed=10)
     rng = np.random.default_rng(9)
     x = rng.standard_normal((M, K)).astype(np.float16)
-    with pytest.warns(UserWarning, match='falling back'):
-        check_forward(x, L)
-    gate = tuple(dev(L[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
-    up = tuple(dev(U[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
-    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 128).cpu().numpy()
-    ref = oracle.fused_mlp(x, (L['qweight'], L['scales'], L['qzeros'], L['g_idx']), (U['qweight'], U['scales'], U['qzeros'], U['g_idx']), 4)
-    assert rel_err(c, ref) < 2e-3
-    dy = rng.standard_normal((M, N)).astype(np.float16)
-    dx = QL.transpose_matmul248(dev(dy), dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15).cpu().numpy()
-    assert rel_err(dx, oracle.transpose_matmul248(dy, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)) < TOL
+    assert lib.gptq_prefill_route_for(M, K, N, 1, 0) == 0
+    prev = lib.gptq_set_library_enabled(0)          # test hook: every hipBLASLt call answers GPTQ_E_LIBRARY
+    try:
+        check_forward(x, L)                         # gptq_layer_forward falls through to the C ABI's own kernels (one line on stderr)
+        gate = tuple(dev(L[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+        up = tuple(dev(U[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+        c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 128).cpu().numpy()
+        ref = oracle.fused_mlp(x, (L['qweight'], L['scales'], L['qzeros'], L['g_idx']), (U['qweight'], U['scales'], U['qzeros'], U['g_idx']), 4)
+        assert rel_err(c, ref) < 2e-3               # (the library-free pair of round-1 tile GEMMs rounds gate to fp16 before SiLU: the one route that still does)
+        dy = rng.standard_normal((M, N)).astype(np.float16)
+        with pytest.warns(UserWarning, match='falling back'):
+            dx = QL.transpose_matmul248(dev(dy), dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15).cpu().numpy()
+        assert rel_err(dx, oracle.transpose_matmul248(dy, L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)) < TOL
+    finally:
+        lib.gptq_set_library_enabled(prev)
 
 
 def test_prefill_c_abi_entries_strided_and_errors():

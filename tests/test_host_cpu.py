@@ -352,18 +352,28 @@ def test_tp_decode_shard_slicing_is_exact_on_cpu():
 
 
 def test_prefill_route_selection_is_host_logic(monkeypatch):
-    """GPTQ_PREFILL: 'library' hands every batch above the streaming kernels to the dequantise + library route, 'fused' only
-    grids of fewer than GEMM_MIN_TILES 256 x 256 tiles, 'own' none; a refused library (GPTQ_E_LIBRARY) warns once and lets the
-    caller continue, any other error code raises."""
+    """which engine a dense product takes is host logic in the C library (gptq_prefill_route_for): under 'auto' the tile GEMM of
+    csrc/gemm8.hip from one full round of 256 x 256 tiles (pair: 256 x 128) and 2048 rows on, hipBLASLt below; 'library' never,
+    'own' wherever K % 128 == 0.  A refused library (GPTQ_E_LIBRARY) warns once and lets the caller continue, other codes raise."""
     import warnings
     from quant import quant_linear as QL
-    monkeypatch.setattr(QL, 'PREFILL_ROUTE', 'library')
-    assert not QL._mid_m(64, 4096) and QL._mid_m(65, 4096) and QL._mid_m(65536, 12288)
-    monkeypatch.setattr(QL, 'PREFILL_ROUTE', 'fused')
-    assert QL._mid_m(256, 4096) and QL._mid_m(2048, 4096) and not QL._mid_m(3072, 4096) and not QL._mid_m(65536, 4096)
-    assert not QL._mid_m(64, 4096)
-    monkeypatch.setattr(QL, 'PREFILL_ROUTE', 'own')
-    assert not QL._mid_m(300, 4096) and not QL._mid_m(65536, 4096)
+    lib = _native.lib()
+    prev = lib.gptq_set_prefill_route(1)
+    try:
+        rf = lib.gptq_prefill_route_for
+        assert rf(65536, 4096, 4096, 1, 0) == 1 and rf(4096, 4096, 4096, 1, 0) == 1 and rf(4096, 4096, 11008, 2, 0) == 1
+        assert rf(1024, 4096, 12288, 1, 0) == 0 and rf(256, 4096, 4096, 1, 0) == 0 and rf(2048, 4096, 4096, 1, 0) == 0     # 128 tiles: not a full round
+        assert rf(65536, 4000 // 32 * 32 + 32, 4096, 1, 0) == 0                                                     # K % 128 != 0 -> library
+        assert rf(65536, 4096, 4096, 1, 1) == 1 and rf(65536, 4096, 4128, 1, 1) == 0                               # backward: the reduction runs over N
+        assert rf(0, 4096, 4096, 1, 0) == -2
+        lib.gptq_set_prefill_route(0)
+        assert rf(65536, 4096, 4096, 1, 0) == 0
+        lib.gptq_set_prefill_route(2)
+        assert rf(300, 4096, 4096, 1, 0) == 1 and rf(300, 4064, 4096, 1, 0) == 0
+        assert lib.gptq_set_prefill_route(7) == -6
+    finally:
+        lib.gptq_set_prefill_route(prev)
+    assert lib.gptq_prefill_plan_count() == 0          # nothing planned without a GPU
     monkeypatch.setattr(QL, '_library_warned', False)
     with pytest.warns(UserWarning, match='falling back'):
         assert QL._library_refused(-8, 'gptq_prefill_matmul_f16') is True

@@ -37,7 +37,7 @@ def prefill(route, x, w, bias=None, up=None):
     qw, sc, qz = w
     M, K = x.shape
     N = qw.shape[1]
-    lib.gptq_set_prefill_route(route)
+    lib.gptq_set_prefill_route(2 if route else 0)
     y = torch.empty((M, N), dtype=torch.float16, device=dev)
     ws = torch.empty(lib.gptq_prefill_workspace_bytes(M, K, N, 2 if up else 1), dtype=torch.uint8, device=dev)
     if up is None:
@@ -55,7 +55,7 @@ def backward(route, dy, w):
     qw, sc, qz = w
     M, N = dy.shape
     K = qw.shape[0] * 32 // BITS
-    lib.gptq_set_prefill_route(route)
+    lib.gptq_set_prefill_route(2 if route else 0)
     dx = torch.empty((M, K), dtype=torch.float16, device=dev)
     ws = torch.empty(lib.gptq_prefill_workspace_bytes(M, K, N, 1), dtype=torch.uint8, device=dev)
     rc = lib.gptq_prefill_transpose_matmul248_f16(dy.data_ptr(), dy.stride(0), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, dx.data_ptr(), K,
@@ -138,7 +138,7 @@ def timeit(fn, reps):
 def perf():
     print('== TFLOP/s (2 M N K / time; the per-call dequantise pass is INSIDE both timings) ==')
     shapes = [(4096, 4096), (4096, 12288), (4096, 11008), (11008, 4096)]
-    for M in (int(m) for m in os.environ.get('MS', '65536,16384,4096,1024,256').split(',')):
+    for M in (int(m) for m in os.environ.get('MS', '65536,16384,4096,2048,1024,256').split(',')):
         for (K, N) in shapes:
             w = rand_set(K, N)
             x = torch.randn((M, K), device=dev, generator=gen).half()

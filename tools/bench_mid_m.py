@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'gptq-for-llama_amd')); sys.path.insert(0, ROOT)
 import torch
 from bench import PackedSet, BITS, GS
-from quant import quant_linear as QL
+from quant import _native, quant_linear as QL
 dev = 'cuda:0'
 gen = torch.Generator(device=dev); gen.manual_seed(0)
 for K, N in [(4096, 4096), (4096, 11008)]:
@@ -26,6 +26,6 @@ for K, N in [(4096, 4096), (4096, 11008)]:
             for i in range(16): run(i, fam)
             e1.record(); torch.cuda.synchronize()
             res['dispatch' if fam is None else ('abi_only' if fam == 'abi' else 'stripe_mm')] = round(e0.elapsed_time(e1) * 1e3 / 16, 1)
-        route = 'rowwave' if M == 1 else ('stream' if M <= QL.STREAM_MAX_M else ('dequant+dense' if QL._mid_m(M, N) else 'mfma tile gemm'))
+        route = 'stripe16' if M <= 128 else ('tile GEMM (gemm8)' if _native.lib().gptq_prefill_route_for(M, K, N, 1, 0) == 1 else 'dequant + hipBLASLt')
         print(json.dumps({'shape': '%dx%d' % (K, N), 'M': M, 'route': route, 'us': res['dispatch'], 'us_abi_kernels_only': res['abi_only'], 'us_stripe_mm': res.get('stripe_mm'),
                           'TFLOPs': round(2.0 * M * K * N / res['dispatch'] / 1e6, 1)}))

@@ -7,9 +7,9 @@ down_proj 11008x4096], 4-bit, groupsize 128; synthetic random-init packed weight
 issued through the C ABI (include/gptq_mi355x.h) exactly as the drop-in modules issue it after
 make_quant_attn / make_fused_mlp: 4 launches per layer, 128 per step, 3.37 GB of distinct
 weights per step (> the 256 MiB Infinity Cache, so every step streams from HBM).
-issued through the C ABI exactly as the drop-in modules issue it at decode: gptq_stripe_matvec_f16 on the stripe16 images the
-modules build once at load time from the checkpoint buffers (csrc/stripe.hip; --kernel rowwave = the split-K kernels
-on the checkpoint layout, for A/B runs).  The step is captured once into a hipGraph and replayed; inputs are resident in HBM.
+issued through the C ABI exactly as the drop-in modules issue it: gptq_layer_forward on handles prepared once at load time
+(gptq_layer_prepare builds the stripe16 image from the checkpoint buffers; --kernel rowwave = the split-K kernels on the
+checkpoint layout, for A/B runs).  The step is captured once into a hipGraph and replayed; inputs are resident in HBM.
 
 value      = algorithmic GB/s of the whole job (SURVEY 8(d) byte model), all ranks summed.
 roofline   = the GEMV kernel family against the 8 TB/s HBM3E spec peak.
@@ -59,12 +59,12 @@ class PackedSet:
 
 class DecodeLinears:
     """the 4 launches/layer x 32 layers of one decode token, as raw C-ABI calls.
-    kernel = 'stripe' (default): gptq_stripe_matvec_f16 on the stripe16 images the drop-in modules build at load time
-    (csrc/stripe.hip: no K split, no combine atomics); 'rowwave': gptq_matmul248_f16 / gptq_fused_mlp_f16 on the
-    checkpoint layout (split-K + fixed-point atomic combine), kept for A/B runs."""
+    kernel = 'stripe' (default): gptq_layer_forward on handles made by gptq_layer_prepare -- exactly what the drop-in modules
+    call (quant/layer.py); at M = 1 its table picks the stripe16 decode kernel (csrc/stripe.hip: no K split, no combine atomics);
+    'rowwave': gptq_matmul248_f16 / gptq_fused_mlp_f16 on the checkpoint layout (split-K + fixed-point atomic combine), for A/B."""
 
     def __init__(self, dev, layers=LAYERS, seed=0, kernel='stripe'):
-        from quant import _native, quant_linear
+        from quant import _native, layer as QLayer
         self.native = _native
         self.lib = _native.lib()
         self.dev = dev
@@ -76,13 +76,14 @@ class DecodeLinears:
             L = dict(qkv=PackedSet(HIDDEN, 3 * HIDDEN, dev, gen), o=PackedSet(HIDDEN, HIDDEN, dev, gen),
                      gate=PackedSet(HIDDEN, INTER, dev, gen), up=PackedSet(HIDDEN, INTER, dev, gen),
                      down=PackedSet(INTER, HIDDEN, dev, gen))
-            if kernel == 'stripe':     # what QuantLinear / QuantLlamaMLP do on their first decode call (quant_linear.stripe_copy)
+            if kernel == 'stripe':     # what QuantLinear / QuantLlamaMLP do on their first call: gptq_layer_prepare (quant/layer.py)
                 for k in ('qkv', 'o', 'down'):
-                    L['st_' + k] = quant_linear.stripe_copy(L[k].qweight, L[k].scales, L[k].qzeros, BITS, GS)
-                L['st_mlp'] = quant_linear.stripe_copy(L['gate'].qweight, L['gate'].scales, L['gate'].qzeros, BITS, GS,
-                                                       up=(L['up'].qweight, L['up'].scales, L['up'].qzeros))
-                assert all(L[k] is not None for k in ('st_qkv', 'st_o', 'st_down', 'st_mlp'))
+                    L['pl_' + k] = QLayer.PreparedLayer(((L[k].qweight, L[k].scales, L[k].qzeros, None),), None, BITS, GS, L[k].K, L[k].N)
+                L['pl_mlp'] = QLayer.PreparedLayer(((L['gate'].qweight, L['gate'].scales, L['gate'].qzeros, None),
+                                                    (L['up'].qweight, L['up'].scales, L['up'].qzeros, None)), None, BITS, GS, HIDDEN, INTER)
+                assert all(L[k].stripe is not None for k in ('pl_qkv', 'pl_o', 'pl_down', 'pl_mlp'))
             self.layers.append(L)
+        self.lws = torch.zeros(self.lib.gptq_layer_workspace_bytes(), dtype=torch.uint8, device=dev)   # persistent workspace of gptq_layer_forward
         self.x_h = torch.randn((1, HIDDEN), device=dev, generator=gen).half()
         self.x_i = (torch.randn((1, INTER), device=dev, generator=gen) * 0.5).half()
         self.y_qkv = torch.empty((1, 3 * HIDDEN), dtype=torch.float16, device=dev)
@@ -93,15 +94,15 @@ class DecodeLinears:
                                         alg_bytes(1, HIDDEN, INTER, nsets=2) + alg_bytes(1, INTER, HIDDEN))
         self.launches_per_step = 4 * layers
 
-    def _stripe(self, x, st, y, K, N, nsets, stream):
-        rc = self.lib.gptq_stripe_matvec_f16(x.data_ptr(), K, st.data_ptr(), st.numel(), None, y.data_ptr(), N, 1, K, N, BITS, GS, nsets,
-                                             None, 0.0, None, stream)
-        self.native.check(rc, 'gptq_stripe_matvec_f16')
+    def _layer(self, x, pl, y, stream):
+        """the product's ONE call site (include/gptq_mi355x.h "Prepared layers"): the M -> kernel table is inside"""
+        rc = self.lib.gptq_layer_forward(pl.handle, x.data_ptr(), pl.K, y.data_ptr(), pl.N, 1, self.lws.data_ptr(), self.lws.numel(), None, 0, stream)
+        self.native.check(rc, 'gptq_layer_forward')
 
     def _mm(self, x, L, name, y, stream):
         w = L[name]
         if self.kernel == 'stripe':
-            return self._stripe(x, L['st_' + name], y, w.K, w.N, 1, stream)
+            return self._layer(x, L['pl_' + name], y, stream)
         rc = self.lib.gptq_matmul248_f16(x.data_ptr(), w.K, w.qweight.data_ptr(), w.scales.data_ptr(), w.qzeros.data_ptr(),
                                          None, None, y.data_ptr(), w.N, 1, w.K, w.N, BITS, GS, self.ws.data_ptr(),
                                          self.ws.numel(), stream)
@@ -110,7 +111,7 @@ class DecodeLinears:
     def _mlp(self, x, L, y, stream):
         g, u = L['gate'], L['up']
         if self.kernel == 'stripe':
-            return self._stripe(x, L['st_mlp'], y, g.K, g.N, 2, stream)
+            return self._layer(x, L['pl_mlp'], y, stream)
         rc = self.lib.gptq_fused_mlp_f16(x.data_ptr(), g.K, g.qweight.data_ptr(), g.scales.data_ptr(), g.qzeros.data_ptr(),
                                          None, u.qweight.data_ptr(), u.scales.data_ptr(), u.qzeros.data_ptr(), None,
                                          y.data_ptr(), g.N, 1, g.K, g.N, BITS, GS, self.ws.data_ptr(), self.ws.numel(), stream)
@@ -367,13 +368,16 @@ def _time_cold(run, nsets, reps=5):
 def prefill_leg(dev, M=65536, reps=7):
     """BASELINE config 3 (reported only): LLaMA-7B-shaped 4-bit g128 batched matmul at M = 32 x 2048 through the drop-in
     matmul248 (reference kernel quant_linear.py:72-137), TFLOP/s = 2 M N K / t against the 2.5 PFLOP/s dense fp16 MFMA peak.
-    Three numbers per shape: the product's route (GPTQ_PREFILL, default 'library': our dequantise kernel PER CALL + the library
-    GEMM), the hand-written fused MFMA tile GEMM (csrc/gemm_mfma.hip, family='abi'), and hipBLASLt alone on a weight
-    dequantised beforehand (the ceiling either route can reach)."""
-    from quant import quant_linear as QL
+    Per shape: the product (gptq_layer_forward -> dequantise per call + the hand-written LDS-DMA / MFMA tile GEMM of
+    csrc/gemm8.hip), the same entry with the library switch (dequantise per call + hipBLASLt: the reported ceiling, not the
+    product), the round-2 fused tile kernel (csrc/gemm_mfma.hip, family='abi'), and hipBLASLt alone on a weight dequantised
+    beforehand."""
+    from quant import _native, quant_linear as QL
+    lib = _native.lib()
     gen = torch.Generator(device=dev)
     gen.manual_seed(3)
-    out = {'M': M, 'peak_TFLOPs': 2500.0, 'route': QL.PREFILL_ROUTE, 'shapes': {}}
+    out = {'M': M, 'peak_TFLOPs': 2500.0, 'route': QL.PREFILL_ROUTE, 'gemm': 'hand-written tile GEMM (csrc/gemm8.hip): LDS-DMA operands, v_mfma_f32_16x16x32_f16, '
+           '8-phase schedule; hipBLASLt only below one round of tiles', 'shapes': {}}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(f):
@@ -391,27 +395,38 @@ def prefill_leg(dev, M=65536, reps=7):
             ts.append(e0.elapsed_time(e1))
         return sorted(ts)[len(ts) // 2], y
 
+    def with_route(code, f):
+        prev = lib.gptq_set_prefill_route(code)
+        try:
+            return timed(f)
+        finally:
+            lib.gptq_set_prefill_route(prev)
+
     for K, N in [(HIDDEN, HIDDEN), (HIDDEN, 3 * HIDDEN), (HIDDEN, INTER), (INTER, HIDDEN)]:
         w = PackedSet(K, N, dev, gen)
         x = torch.randn((M, K), device=dev, generator=gen).half()
         gi = (torch.arange(K, device=dev) // GS).to(torch.int32)
+        prod = lambda: QL.matmul248(x, w.qweight, w.scales, w.qzeros, gi, BITS, 15)
         if not out['shapes']:
             # the legs before this one are microsecond kernels: ~50 ms of GEMM first, so that the first timed leg does not start
             # from their power state (leg-to-leg noise on these boxes stays around +-10 %: profiles/r2e_prefill)
             for _ in range(24):
-                QL.matmul248(x, w.qweight, w.scales, w.qzeros, gi, BITS, 15)
-        ms, y = timed(lambda: QL.matmul248(x, w.qweight, w.scales, w.qzeros, gi, BITS, 15))
+                prod()
+        assert lib.gptq_prefill_route_for(M, K, N, 1, 0) == (1 if QL.PREFILL_ROUTE != 'library' else 0)
+        ms, y = timed(prod)
+        msl, yl = with_route(0, prod)
         msf, yf = timed(lambda: QL.matmul248(x, w.qweight, w.scales, w.qzeros, gi, BITS, 15, family='abi'))
         W = QL.dequantize(w.qweight, w.scales, w.qzeros, None, BITS, GS)
         msd, yd = timed(lambda: x @ W)
         fl = 2.0 * M * N * K / 1e9
-        tf, tff, tfd = fl / ms, fl / msf, fl / msd
+        tf, tfl, tff, tfd = fl / ms, fl / msl, fl / msf, fl / msd
         out['shapes']['%dx%d' % (K, N)] = {'ms': round(ms, 3), 'TFLOPs': round(tf, 1), 'frac_of_2.5PF': round(tf / 2500.0, 4),
-                                           'fused_kernel_TFLOPs': round(tff, 1), 'hipblaslt_dense_TFLOPs': round(tfd, 1),
-                                           'vs_hipblaslt': round(tf / tfd, 3), 'fused_kernel_vs_hipblaslt': round(tff / tfd, 3),
+                                           'library_route_TFLOPs': round(tfl, 1), 'round2_fused_kernel_TFLOPs': round(tff, 1),
+                                           'hipblaslt_dense_TFLOPs': round(tfd, 1), 'vs_library_route': round(tf / tfl, 3),
+                                           'vs_hipblaslt_dense': round(tf / tfd, 3),
                                            'max_abs_diff_vs_dense': float((y.float() - yd.float()).abs().max()),
-                                           'fused_kernel_max_abs_diff_vs_dense': float((yf.float() - yd.float()).abs().max())}
-        del w, x, y, yf, yd, W
+                                           'max_abs_diff_vs_library_route': float((y.float() - yl.float()).abs().max())}
+        del w, x, y, yl, yf, yd, W
         torch.cuda.empty_cache()
     # the MLP's gate/up pair with SiLU (fused_mlp.fused_gate_up; reference fusedmatmul_248_kernel, fused_mlp.py:84-168)
     from quant import fused_mlp as FM
@@ -419,12 +434,15 @@ def prefill_leg(dev, M=65536, reps=7):
     wg, wu = PackedSet(K, N, dev, gen), PackedSet(K, N, dev, gen)
     x = torch.randn((M, K), device=dev, generator=gen).half()
     gi = (torch.arange(K, device=dev) // GS).to(torch.int32)
-    ms, c = timed(lambda: FM.fused_gate_up(x, (wg.qweight, wg.scales, wg.qzeros, gi), (wu.qweight, wu.scales, wu.qzeros, gi), BITS, GS))
-    msf, cf = timed(lambda: FM.fused_gate_up(x, (wg.qweight, wg.scales, wg.qzeros, gi), (wu.qweight, wu.scales, wu.qzeros, gi), BITS, GS, family='abi'))
+    pair = lambda: FM.fused_gate_up(x, (wg.qweight, wg.scales, wg.qzeros, gi), (wu.qweight, wu.scales, wu.qzeros, gi), BITS, GS)
+    ms, c = timed(pair)
+    msl, cl = with_route(0, pair)
     fl = 4.0 * M * N * K / 1e9
-    out['gate_up_silu_2x%dx%d' % (K, N)] = {'ms': round(ms, 3), 'TFLOPs': round(fl / ms, 1), 'fused_kernel_TFLOPs': round(fl / msf, 1),
-                                           'max_abs_diff_between_routes': float((c.float() - cf.float()).abs().max())}
-    del wg, wu, x, c, cf
+    out['gate_up_silu_2x%dx%d' % (K, N)] = {'ms': round(ms, 3), 'TFLOPs': round(fl / ms, 1), 'library_route_TFLOPs': round(fl / msl, 1),
+                                           'note': 'product: ONE launch, SiLU on the fp32 accumulators in the GEMM epilogue; library route: fp32 '
+                                                   '[rows, 2N] product in chunks + a SiLU * mul pass',
+                                           'max_abs_diff_between_routes': float((c.float() - cl.float()).abs().max())}
+    del wg, wu, x, c, cl
     torch.cuda.empty_cache()
     return out
 
@@ -505,7 +523,7 @@ def pmc_traffic():
         return None, None
 
 
-def cpu_baseline(budget_s=20.0):
+def cpu_baseline(budget_s=10.0):
     """the oracle (port of the reference kernel arithmetic) on the host cores: one decoder layer's
     five matvecs (qkv as one 4096x12288, o, gate, up, down), repeated until ~budget_s."""
     import numpy as np
@@ -531,6 +549,8 @@ def cpu_baseline(budget_s=20.0):
         t_total += time.perf_counter() - t0
         n += 1
     return {'value': round(nbytes * n / t_total / 1e9, 3), 'unit': 'GB/s', 'cores': oracle.num_threads(), 'kind': 'port',
+            'note': 'faithful, unoptimised restatement of the reference kernel arithmetic (software fp16 rounding per weight, -ffp-contract=off): '
+                    'a stated baseline, not a target -- the GPU / CPU ratio says nothing about kernel quality, roofline.frac does',
             'sample': '%d x one LLaMA-7B decoder layer (5 matvecs, %.1f MB algorithmic) by oracle/gptq_oracle.c (OpenMP)' %
                       (n, nbytes / 1e6), 'seconds': round(t_total, 2)}
 
@@ -614,12 +634,12 @@ def main():
     ap.add_argument('--eager', action='store_true', help='time eager launches instead of hipGraph replay')
     ap.add_argument('--kernel', choices=('stripe', 'rowwave'), default='stripe', help='decode matvec kernel family (A/B runs)')
     ap.add_argument('--tp', choices=('row', 'megatron'), default=None,
-                    help='BASELINE config 5 instead of the replica mode: LLaMA-65B-shaped decode linears sharded over the --gpus ranks '
-                         '(row = every linear K-sharded, one all-reduce per linear; megatron = N-shard qkv/gate/up, K-shard o/down)')
+                    help='BASELINE config 5: LLaMA-65B-shaped decode linears sharded over the --gpus ranks (row = every linear K-sharded, one '
+                         'all-reduce per linear: north_star, the DEFAULT for more than one rank; megatron = N-shard qkv/gate/up, K-shard o/down)')
     ap.add_argument('--tp-layers', type=int, default=16)
     ap.add_argument('--allreduce', choices=('rccl', 'p2p'), default='rccl',
                     help='--tp collective: torch.distributed.all_reduce (RCCL) or the one-shot exchange over IPC peer mappings (csrc/p2p.hip)')
-    ap.add_argument('--dp', action='store_true', help='N independent replicas of the single-GPU workload (the default)')
+    ap.add_argument('--dp', action='store_true', help='N independent replicas of the single-GPU workload (weak scaling) instead of --tp row')
     ap.add_argument('--no-prefill', action='store_true')
     ap.add_argument('--no-config4', action='store_true')
     ap.add_argument('--no-small-batch', action='store_true')
@@ -643,6 +663,8 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
+    if world > 1 and args.tp is None and not args.dp:
+        args.tp = 'row'            # north_star / BASELINE configs[4]: row-sharded linears, ONE RCCL all-reduce per linear, 1/2/4/8 GPUs
 
     if args.tp:
         work = TPLayers(dev, rank, world, args.tp, args.tp_layers, allreduce=args.allreduce)
@@ -701,6 +723,36 @@ def main():
                            'p2p_96KB': round(allreduce_latency_us(dev, world, 3 * H65, p2p=work.p2p), 2),
                            'p2p_172KB': round(allreduce_latency_us(dev, world, 2 * I65, p2p=work.p2p), 2),
                            'p2p_status': work.p2p.status()})
+    replicas = None
+    if args.tp and distributed and not os.environ.get('GPTQ_BENCH_NO_REPLICAS'):
+        # reported-only side leg: the N = 1 workload (BASELINE configs[1]) as N independent replicas, no data-path collective
+        try:
+            del graph
+            work_tp, work = work, None
+            rep = DecodeLinears(dev, seed=rank)
+            for _ in range(2):
+                rep.step()
+            torch.cuda.synchronize()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                rep.step()
+            for _ in range(3):
+                g2.replay()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                g2.replay()
+            torch.cuda.synchronize()
+            tr = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            replicas = {'workload': 'BASELINE configs[1] (LLaMA-7B-shaped decode pass) as %d independent replicas' % world,
+                        'GBps_whole_job': round(rep.bytes_per_step * world * 20 / float(tr.item()) / 1e9, 1), 'scaling': 'weak'}
+            del rep, g2
+            work = work_tp
+        except Exception as e:
+            replicas = {'error': repr(e)[:200]}
+            work = work if work is not None else work_tp
     if rank == 0:
         ms_per_step = wall_max * 1e3 / args.steps
         total_bytes = work.bytes_per_step * world
@@ -720,11 +772,14 @@ def main():
                                        ('row-sharded linears with one all-reduce per linear' if args.tp == 'row' else
                                         'Megatron pairing (N-shard qkv/gate/up, K-shard o/down: 2 all-reduces per layer)', world, args.tp_layers),
                            'parallelism': 'tp%d %s' % (world, args.tp),
+                           'world_size_reported_by_backend': (dist.get_world_size() if distributed else 1),
+                           'backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if distributed else 'none',
                            'collective': ('one-shot push + local sum over IPC peer mappings (gptq_p2p_allreduce_f32), fp32' if work.p2p is not None
                                           else 'torch.distributed.all_reduce (RCCL over xGMI), fp32'),
                            'collectives_per_step': work.collectives_per_step, 'launch_mode': 'hipGraph replay' if graph is not None else 'eager',
                            'algorithmic_bytes_per_step': work.bytes_per_step},
                 'allreduce_us': tp_lat,
+                'replicas_reported_only': replicas,
                 'roofline': {'bound': 'hbm', 'achieved': round(work.bytes_per_step / world / (ms_per_step * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
                              'unit': 'GB/s', 'frac': round(work.bytes_per_step / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              'traffic': None, 'kernel': 'gptq::stripe_gemv_kernel (per-GPU share of the bytes / wall time incl. collectives)'},
@@ -743,7 +798,8 @@ def main():
                                    '{qkv 4096x12288, o 4096x4096, gate/up+SiLU 2x4096x11008, down 11008x4096}',
                        'launches_per_step': work.launches_per_step, 'algorithmic_bytes_per_step': work.bytes_per_step,
                        'launch_mode': 'eager' if args.eager else 'hipGraph replay', 'parallelism': 'dp%d replicas' % world,
-                       'weight_layout': 'stripe16 image built at load time from the checkpoint buffers (gptq_stripe_repack)'
+                       'entry_points': 'gptq_layer_prepare (load) + gptq_layer_forward (per op)',
+                       'weight_layout': 'stripe16 image built at load time from the checkpoint buffers (gptq_layer_prepare)'
                                         if args.kernel == 'stripe' else 'checkpoint layout'},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
@@ -751,6 +807,18 @@ def main():
                                     if args.kernel == 'stripe' else 'gptq::gemv_rowwave_kernel<4,8,*> (all 128 launches/step)'),
                          'avg_launch_us': round(us_per_launch, 3), 'algorithmic_bytes_per_launch': int(bytes_per_launch)},
         }
+        out['memory_MiB'] = {'matvec_pass': round(torch.cuda.max_memory_allocated() / 2**20, 1),
+                             'note': 'peak bytes in use by tensors per leg (torch.cuda.reset_peak_memory_stats before each); the matvec pass holds the '
+                                     'checkpoint buffers AND their stripe16 images of all 32 layers'}
+
+        def leg(key, fn):
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            try:
+                out[key] = fn()
+            except Exception as e:        # the headline line must survive a failure of a side leg
+                out[key] = {'error': repr(e)[:200]}
+            out['memory_MiB'][key] = round(torch.cuda.max_memory_allocated() / 2**20, 1)
         # the side legs run at N = 1 only (the other ranks would sit in the final barrier meanwhile)
         if not args.no_per_shape and world == 1:
             out['per_shape'] = work.per_shape()
@@ -758,26 +826,16 @@ def main():
                 out['per_shape_llama65b_reported_only'] = larger_model_shapes(dev)
             except Exception as e:
                 out['per_shape_llama65b_reported_only'] = {'error': repr(e)[:200]}
+        if world == 1:
+            work = graph = run = None       # free the 6.8 GB of the matvec pass: every later leg reports its OWN peak
         if not args.no_prefill and world == 1:
-            try:
-                out['prefill_config3_reported_only'] = prefill_leg(dev)
-            except Exception as e:
-                out['prefill_config3_reported_only'] = {'error': repr(e)[:200]}
+            leg('prefill_config3_reported_only', lambda: prefill_leg(dev))
         if not args.no_small_batch and world == 1:
-            try:
-                out['small_batch_reported_only'] = small_batch_leg(dev)
-            except Exception as e:
-                out['small_batch_reported_only'] = {'error': repr(e)[:200]}
+            leg('small_batch_reported_only', lambda: small_batch_leg(dev))
         if not args.no_config4 and world == 1:
-            try:
-                out['config4_reported_only'] = config4_leg(dev)
-            except Exception as e:
-                out['config4_reported_only'] = {'error': repr(e)[:200]}
+            leg('config4_reported_only', lambda: config4_leg(dev))
         if not args.no_decode and world == 1:
-            try:
-                out['decode'] = decode_tokens_per_s(dev)
-            except Exception as e:   # the headline line must survive a failure of a side leg
-                out['decode'] = {'error': repr(e)[:200]}
+            leg('decode', lambda: decode_tokens_per_s(dev))
         if not args.no_cpu_baseline and world == 1:
             try:
                 out['cpu_baseline'] = cpu_baseline()

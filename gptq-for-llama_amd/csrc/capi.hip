@@ -368,10 +368,8 @@ static int run_auto(const Problem &q, hipStream_t s) {
     if (fast_eligible(q, unit_k)) {
         GemvParams p;
         fill_params(q, 0, q.M, p);
-        // fused gate/up at prefill sizes: two tile GEMMs, the second one applies silu(gate) * up in place in its
-        // epilogue (y holds gate in between; every output is read and written by one thread)
-        int rc = gemm_dispatch(q.bits, 0, false, p, s);
-        if (rc == 0 && q.fused2) rc = gemm_dispatch(q.bits, 1, true, p, s);
+        // fused gate/up at prefill sizes: ONE tile GEMM whose workgroups hold gate and up of the same columns; SiLU on the fp32 sums
+        const int rc = gemm_dispatch(q.bits, q.fused2, p, s);
         if (rc != GPTQ_E_VARIANT) return rc;
     }
     return run_skinny(q, s);
@@ -476,7 +474,7 @@ int gptq_gemm_f16(const void *x, int64_t ldx, const int32_t *qweight, const void
     if (int rc = validate(q)) return rc;
     GemvParams p;
     fill_params(q, 0, M, p);
-    return gemm_dispatch(bits, 0, false, p, (hipStream_t)stream);
+    return gemm_dispatch(bits, false, p, (hipStream_t)stream);
 }
 
 int gptq_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweight_gate, const void *scales_gate,

@@ -38,7 +38,12 @@ struct GemmParams {
     const half_t *sc;
     const int32_t *qz;
     const half_t *bias;
-    int silu_gate;  // 1: c holds gate = x.Wg; store c = silu(gate) * acc instead (fused gate/up, reference fused_mlp.py:160-168)
+    // PAIR mode (fused gate/up, reference fused_mlp.py:84-168): the second weight set.  A workgroup tile is then 256 rows x 128 output
+    // columns; each wave's 64 tile columns are 32 gate columns + the SAME 32 columns of up, so both fp32 sums of an output sit in
+    // one lane and SiLU is applied to the accumulator (fused_mlp.py:160-165) -- no rounded intermediate, no second launch.
+    const uint32_t *qw1;
+    const half_t *sc1;
+    const int32_t *qz1;
     half_t *c;
     int64_t ldc;
     int M, K, N, groupsize;
@@ -122,14 +127,6 @@ GPTQ_DEV void gemm_epilogue_t(const float16_t (&acc)[TN][4], char *smem, int wav
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = (half_t)((float)v[e] + (float)b[e]);
             }
-            if (p.silu_gate) {   // in place: this thread is the only one that touches these 8 outputs
-                const half8_t g = *(const half8_t *)(p.c + (size_t)m * p.ldc + ncol);
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const float gf = (float)g[e];
-                    v[e] = (half_t)(gf * (1.0f / (1.0f + __expf(-gf))) * (float)v[e]);
-                }
-            }
             *(half8_t *)(p.c + (size_t)m * p.ldc + ncol) = v;
         }
     }
@@ -139,7 +136,7 @@ GPTQ_DEV void gemm_epilogue(const float16_t (&acc)[TN_][4], char *smem, int wave
     gemm_epilogue_t<TN_>(acc, smem, wave, lane, wm, wn, m0, n0, M, N, p);
 }
 
-template <int BITS>
+template <int BITS, bool PAIR>
 __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
     using UP = Unpack<BITS>;
     constexpr int KPW = UP::KPW;
@@ -158,7 +155,7 @@ __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int tm = (j / p.ntn) * 8 + xcd, tn = j % p.ntn;
     if (tm >= p.ntm) return;
-    const int m0 = tm * GM, n0 = tn * GN;
+    const int m0 = tm * GM, n0 = tn * (PAIR ? GN / 2 : GN);
     const int M = p.M, N = p.N, K = p.K;
 
     // ---- A: LDS-DMA map ----------------------------------------------------------------------
@@ -184,11 +181,17 @@ __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
     // (4 lanes = 4 adjacent columns) fetches its 4 x 4 words as ONE dwordx4 per lane (lane i takes packed
     // row kb0 + i, columns of the whole quad) and transposes in registers (2 DPP stages): a quarter of
     // the VMEM instructions -- the move phase is bound by their issue (tools/gemm_phases.py)
+    // PAIR: tile column bcol = 64 wn + c -> weight set c / 32 (0 gate, 1 up), output column n0 + 32 wn + c % 32
     const int bcol = tid & 255, kb0 = (tid >> 8) * KBT;
-    const int nb = min(n0 + bcol, N - 1);
-    const uint32_t *bptr = p.qw + nb;
-    const int nb4 = min(n0 + (bcol & ~3), N - 4);
-    const uint32_t *bptr4 = p.qw + nb4 + (size_t)(tid & 3) * N;
+    const int bset = PAIR ? (bcol >> 5) & 1 : 0;
+    const int ocol = PAIR ? (bcol >> 6) * 32 + (bcol & 31) : bcol;
+    const uint32_t *qwp = (PAIR && bset) ? p.qw1 : p.qw;
+    const half_t *scp = (PAIR && bset) ? p.sc1 : p.sc;
+    const int32_t *qzp = (PAIR && bset) ? p.qz1 : p.qz;
+    const int nb = min(n0 + ocol, N - 1);
+    const uint32_t *bptr = qwp + nb;
+    const int nb4 = min(n0 + (ocol & ~3), N - 4);
+    const uint32_t *bptr4 = qwp + nb4 + (size_t)(tid & 3) * N;
     const int boff = bcol * ROWB;
     const uint32_t MSK = sreg_const(UP::MSK_C), MAG = vreg_const(UP::MAG_C);
     const int ldz = N / KPW;
@@ -209,8 +212,8 @@ __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
         const int g = p.gshift >= 0 ? (kfirst >> p.gshift) : (kfirst / p.groupsize);
         if (g != g_loaded) {   // uniform over each half of the workgroup: once per group, not per slab
             g_loaded = g;
-            sreg = p.sc[(size_t)g * N + nb];
-            zreg = (uint32_t)p.qz[(size_t)g * ldz + nb / KPW];
+            sreg = scp[(size_t)g * N + nb];
+            zreg = (uint32_t)qzp[(size_t)g * ldz + nb / KPW];
         }
     };
     // 4 x 4 transpose inside a quad: afterwards lane i holds column i's words of packed rows kb0 .. kb0+3
@@ -357,7 +360,20 @@ __global__ void __launch_bounds__(512) gemm_mfma_kernel(const GemmParams p) {
     }
     __syncthreads();
 
-    gemm_epilogue(acc, smem, wave, lane, wm, wn, m0, n0, M, N, p);
+    if constexpr (PAIR) {
+        // n tile 0 = gate, n tile 1 = up of the same 32 columns: silu on the fp32 accumulator, then the usual transposing store
+        float16_t comb[1][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float g = acc[0][jj][e];
+                comb[0][jj][e] = g * (1.0f / (1.0f + __expf(-g))) * acc[1][jj][e];
+            }
+        gemm_epilogue_t<1>(comb, smem, wave, lane, wm, wn, m0, n0, M, N, p);
+    } else {
+        gemm_epilogue(acc, smem, wave, lane, wm, wn, m0, n0, M, N, p);
+    }
 }
 
 
@@ -522,9 +538,9 @@ __global__ void __launch_bounds__(512) gemm_mfma_v3_kernel(const GemmParams p) {
 }
 
 
-template <int BITS>
+template <int BITS, bool PAIR>
 static int launch_gemm(const GemmParams &p, hipStream_t s) {
-    auto kern = gemm_mfma_kernel<BITS>;
+    auto kern = gemm_mfma_kernel<BITS, PAIR>;
     const size_t lds = 4 * (size_t)TILE_BYTES;  // 147 456 B: epilogue staging NWAVE * 128 * CROW (main loop: 2 A + 2 B buffers = 139 264 B)
     static_assert(NWAVE * 128 * CROW <= 4 * TILE_BYTES, "epilogue staging must fit");
     static LdsOptIn opt_in;   // per instantiation; per device inside
@@ -543,22 +559,23 @@ int gemm_set_version(int v) {
 // Eligibility: bits in {4, 8}, trivial g_idx (checked by the caller), K % 64 == 0, groupsize % 32 == 0,
 // N % 8 == 0 (always: N % 32 == 0), rows 16-byte aligned.  Everything else -> GPTQ_E_VARIANT and
 // the caller falls back to the weight-streaming kernel.
-// set: which weight set of q to multiply with (0, or 1 = the "up" set of a fused gate/up problem);
-// silu_gate: the output buffer already holds gate = x.W0 and receives silu(gate) * (x.W_set) in place.
-int gemm_dispatch(int bits, int set, bool silu_gate, const GemvParams &q, hipStream_t s) {
+// pair: q holds two weight sets and y = silu(x W0) * (x W1) (fused gate/up): ONE launch, SiLU on the fp32 accumulators.
+int gemm_dispatch(int bits, bool pair, const GemvParams &q, hipStream_t s) {
     // q.dbg: development stamps (gptq_set_debug_buffer)
-    if (set < 0 || set > 1 || (silu_gate && q.bias)) return GPTQ_E_VARIANT;
+    if (pair && q.bias) return GPTQ_E_VARIANT;
     if (bits != 4 && bits != 8) return GPTQ_E_VARIANT;
     if (q.K % GK != 0 || q.groupsize % 32 != 0 || q.ldx % 8 != 0 || q.ldy % 8 != 0) return GPTQ_E_VARIANT;
     if (((uintptr_t)q.y % 16) != 0 || (q.bias && ((uintptr_t)q.bias % 16) != 0)) return GPTQ_E_VARIANT;
     GemmParams p;
     p.a = q.x;
     p.lda = q.ldx;
-    p.qw = q.qw[set];
-    p.sc = q.sc[set];
-    p.qz = q.qz[set];
+    p.qw = q.qw[0];
+    p.sc = q.sc[0];
+    p.qz = q.qz[0];
+    p.qw1 = pair ? q.qw[1] : nullptr;
+    p.sc1 = pair ? q.sc[1] : nullptr;
+    p.qz1 = pair ? q.qz[1] : nullptr;
     p.bias = q.bias;
-    p.silu_gate = silu_gate ? 1 : 0;
     p.c = q.y;
     p.ldc = q.ldy;
     p.M = q.M;
@@ -570,7 +587,8 @@ int gemm_dispatch(int bits, int set, bool silu_gate, const GemvParams &q, hipStr
         if ((1 << i) == q.groupsize) p.gshift = i;
     p.dbg = q.dbg;
     p.ntm = (q.M + GM - 1) / GM;
-    p.ntn = (q.N + GN - 1) / GN;
+    p.ntn = pair ? (q.N + GN / 2 - 1) / (GN / 2) : (q.N + GN - 1) / GN;
+    if (pair) return bits == 4 ? launch_gemm<4, true>(p, s) : launch_gemm<8, true>(p, s);
     if (bits == 4 && q.groupsize % GK == 0 && q.N >= 4 && g_gemm_version.load() == 3) {
         const size_t lds = 4 * (size_t)TILE_BYTES;
         static LdsOptIn opt_in[5];
@@ -592,7 +610,7 @@ int gemm_dispatch(int bits, int set, bool silu_gate, const GemvParams &q, hipStr
         }
         return (int)hipGetLastError();
     }
-    return bits == 4 ? launch_gemm<4>(p, s) : launch_gemm<8>(p, s);
+    return bits == 4 ? launch_gemm<4, false>(p, s) : launch_gemm<8, false>(p, s);
 }
 
 }  // namespace gptq

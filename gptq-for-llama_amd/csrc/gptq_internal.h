@@ -71,7 +71,7 @@ int gemv_generic_dispatch(int bits, bool fused2, int nl, const GemvParams &p, hi
 
 // skinny MFMA (weight streaming, M <= 64) and tiled MFMA GEMM (prefill)
 int skinny_dispatch(int bits, bool fused2, int stg, int waves, bool xlds, const GemvParams &p, hipStream_t s);
-int gemm_dispatch(int bits, int set, bool silu_gate, const GemvParams &p, hipStream_t s);   // set 1 + silu_gate: fused gate/up, second pass
+int gemm_dispatch(int bits, bool pair, const GemvParams &p, hipStream_t s);   // pair: fused gate/up in ONE launch, SiLU on the fp32 sums
 int gemm_set_version(int v);   // 2 = ping-pong kernel (default), 3 = all-DMA packed-B kernel; returns the previous value
 int transpose_dispatch(int bits, const half_t *dy, int64_t lddy, const uint32_t *qw, const half_t *sc,
                        const int32_t *qz, const int32_t *gi, half_t *dx, int64_t lddx, int M, int K, int N,

@@ -181,6 +181,14 @@ def fused_mlp(x, gate, up, bits):
     return c
 
 
+def fused_mlp_exact(x, gate, up, bits):
+    """float64 silu(x.Wg) * (x.Wu) with weights never rounded to fp16 (built on matmul248_exact): the yardstick for "at least as
+    exact as the reference" checks of the fused-MLP kernels (tests/util.py: assert_not_worse_than_reference)."""
+    a = matmul248_exact(x, gate[0], gate[1], gate[2], gate[3], bits)
+    b = matmul248_exact(x, up[0], up[1], up[2], up[3], bits)
+    return a / (1.0 + np.exp(-a)) * b
+
+
 def rmsnorm(x, weight, eps):
     x = np.ascontiguousarray(np.asarray(x, dtype=np.float16))
     shape = x.shape

@@ -384,3 +384,99 @@ def test_prefill_route_selection_is_host_logic(monkeypatch):
     with pytest.raises(RuntimeError):
         QL._library_refused(-5, 'gptq_prefill_matmul_f16')
     assert QL.TRANSPOSE_LIBRARY_MIN_M >= 16
+
+
+def test_prepared_layer_abi_host_logic():
+    """gptq_layer_* (include/gptq_mi355x.h "Prepared layers"): the image size formula, argument validation and the handle itself are
+    host logic -- a handle without an image (checkpoint-layout kernels only) is made and destroyed here without any device."""
+    import ctypes
+    lib = _native.lib()
+    a256 = lambda v: (v + 255) & ~255
+    K, N = 4096, 11008
+    st1, st2 = lib.gptq_stripe_bytes(K, N, 4, 128, 1), lib.gptq_stripe_bytes(K, N, 4, 128, 2)
+    assert st1 > 0 and lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 0) == a256(st1) and lib.gptq_layer_image_bytes(K, N, 4, 128, 2, 0) == a256(st2)
+    qw = (K // 8) * N * 4
+    assert lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 1) == a256(st1) + a256(4 * K) + a256(2 * K) + a256(qw)          # + perm32, perm16, sorted rows
+    assert lib.gptq_layer_image_bytes(K, N, 4, 128, 2, 1) == a256(st2) + a256(4 * K) + a256(2 * K) + 2 * a256(qw)
+    assert lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 2) == 0                   # irregular g_idx: no derived copies
+    assert lib.gptq_layer_image_bytes(K, N, 3, 128, 1, 1) == 0                   # 3-bit act-order: generic kernels
+    assert lib.gptq_layer_image_bytes(96, 64, 4, 32, 1, 0) == 0                  # K not a multiple of the row block: no stripe image
+    assert lib.gptq_layer_image_bytes(K, N, 4, 128, 3, 0) == 0 and lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 5) == 0
+    assert lib.gptq_layer_workspace_bytes() == lib.gptq_query(3) + lib.gptq_query(5)
+    one = 4096                          # a fake, aligned, non-NULL "device pointer": nothing is launched
+    h = ctypes.c_void_p()
+    assert lib.gptq_layer_prepare(ctypes.byref(h), one, one, one, None, None, None, None, None, None, K, N, 5, 128, None, 0, None) == -1
+    assert lib.gptq_layer_prepare(ctypes.byref(h), one, one, one, None, None, None, None, None, None, K + 8, N, 4, 128, None, 0, None) == -2
+    assert lib.gptq_layer_prepare(ctypes.byref(h), None, one, one, None, None, None, None, None, None, K, N, 4, 128, None, 0, None) == -4
+    assert lib.gptq_layer_prepare(ctypes.byref(h), one + 2, one, one, None, None, None, None, None, None, K, N, 4, 128, None, 0, None) == -3
+    assert lib.gptq_layer_prepare(ctypes.byref(h), one, one, one, None, None, one, None, None, None, K, N, 4, 128, None, 0, None) == -4   # pair without scales_up
+    assert lib.gptq_layer_prepare(ctypes.byref(h), one, one, one, None, None, None, None, None, None, K, N, 4, 128, None, 0, None) == 0 and h.value
+    try:
+        assert lib.gptq_layer_kind(h) == 0
+        st, nb, p16 = ctypes.c_void_p(1), ctypes.c_size_t(1), ctypes.c_void_p(1)
+        assert lib.gptq_layer_stripe_image(h, ctypes.byref(st), ctypes.byref(nb), ctypes.byref(p16)) == 0 and not st.value and nb.value == 0 and not p16.value
+        assert lib.gptq_layer_scratch_bytes(h, 1) == 0 and lib.gptq_layer_scratch_bytes(h, 64) == 0
+        assert lib.gptq_layer_scratch_bytes(h, 65) == lib.gptq_prefill_workspace_bytes(65, K, N, 1)                  # no image: dense route from 65 rows
+        ws = lib.gptq_layer_workspace_bytes()
+        assert lib.gptq_layer_forward(h, one, K, one, N, 0, None, 0, None, 0, None) == 0                              # empty batch
+        assert lib.gptq_layer_forward(h, one, K, one, N, -1, one, ws, None, 0, None) == -2
+        assert lib.gptq_layer_forward(h, one, K - 8, one, N, 1, one, ws, None, 0, None) == -2                        # ldx < K
+        assert lib.gptq_layer_forward(h, None, K, one, N, 1, one, ws, None, 0, None) == -4
+        assert lib.gptq_layer_forward(h, one + 2, K, one, N, 1, one, ws, None, 0, None) == -3
+        assert lib.gptq_layer_forward(h, one, K, one, N, 1, None, 0, None, 0, None) == -5                            # no workspace
+        assert lib.gptq_layer_forward(h, one, K, one, N, 1, one, ws - 1, None, 0, None) == -5
+    finally:
+        lib.gptq_layer_destroy(h)
+    assert lib.gptq_layer_forward(None, one, K, one, N, 1, one, 1 << 30, None, 0, None) == -4 and lib.gptq_layer_kind(None) == -4
+
+
+def test_p2p_allreduce_protocol_simulation():
+    """csrc/p2p.hip's epoch / parity protocol as a host-side model: P ranks run a sequence of all-reduces, a random
+    scheduler advances ONE atomic action of ONE rank at a time (a slot write at one peer, a flag write at one peer, one poll, one slot
+    read), i.e. every interleaving the device could produce under sequential consistency -- including a rank that races one whole
+    collective ahead of a slow peer.  Claims checked: every rank reads exactly the partials of ITS epoch (two slot sets by epoch
+    parity suffice: nobody can be two collectives ahead), every sum is the rank-ordered sum, and no rank ever blocks for ever."""
+    import random
+    for world in (2, 3, 8):
+        for seed in range(6):
+            rnd = random.Random(1000 * world + seed)
+            calls = 7
+            slots = [[[None] * world for _ in range(2)] for _ in range(world)]     # slots[peer][parity][source rank]
+            flags = [[[0] * world for _ in range(2)] for _ in range(world)]        # flags[peer][parity][source rank] = epoch
+            part = lambda r, e: (r + 1) * 1000 + e                                  # rank r's partial in its e-th collective
+            # per rank: program counter over (epoch, phase, index); phases 0 push, 1 flag, 2 poll, 3 sum
+            st = [dict(e=1, ph=0, i=0, acc=[], sums=[]) for _ in range(world)]
+            steps = 0
+            while any(s['e'] <= calls for s in st):
+                steps += 1
+                assert steps < 200000, 'protocol model dead-locked'
+                r = rnd.randrange(world)
+                if rnd.random() < 0.3:
+                    r = 0                                                           # rank 0 is fast: it tries to run ahead
+                s = st[r]
+                if s['e'] > calls:
+                    continue
+                e, par = s['e'], s['e'] & 1
+                if s['ph'] == 0:
+                    slots[s['i']][par][r] = (e, part(r, e))                         # write-through store into peer i's slot set
+                    s['i'] += 1
+                elif s['ph'] == 1:
+                    flags[s['i']][par][r] = e                                       # release store of the flag at peer i
+                    s['i'] += 1
+                elif s['ph'] == 2:
+                    if flags[r][par][s['i']] != e:                                  # relaxed poll of ONE source rank's flag: not yet -> try again later
+                        continue
+                    s['i'] += 1
+                else:
+                    got = slots[r][par][s['i']]
+                    assert got == (e, part(s['i'], e)), ('rank %d read a slot of another epoch' % r, got, e)
+                    s['acc'].append(got[1])
+                    s['i'] += 1
+                if s['i'] == world:
+                    s['i'] = 0
+                    s['ph'] += 1
+                    if s['ph'] == 4:
+                        s['sums'].append(sum(s['acc']))
+                        s['acc'], s['ph'], s['e'] = [], 0, e + 1
+            for r in range(world):
+                assert st[r]['sums'] == [sum(part(q, e) for q in range(world)) for e in range(1, calls + 1)]

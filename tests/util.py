@@ -49,3 +49,20 @@ def within(name, err, tol):
         with open(path, 'a') as f:
             f.write('%s %.3e %.1e\n' % (name, float(err), tol))
     assert err < tol, (name, float(err), tol)
+
+
+def fp16_ulp(v):
+    """spacing of fp16 at |v| (elementwise; subnormal spacing 2^-24 below 2^-14)"""
+    a = np.maximum(np.abs(np.asarray(v, dtype=np.float64)), 2.0 ** -14)
+    return 2.0 ** (np.floor(np.log2(a)) - 10)
+
+
+def assert_not_worse_than_reference(hip, faithful, exact, extra_ulp=1.0, name=''):
+    """'more exact than the reference' as a TESTED claim: per element, the HIP result may be further from the
+    float64 result than the reference-faithful oracle only by ``extra_ulp`` fp16 spacings of the value (one rounding flip), and its
+    max-normalised error against the float64 result stays below the op-level bar."""
+    hip, faithful, exact = (np.asarray(t, dtype=np.float64) for t in (hip, faithful, exact))
+    slack = extra_ulp * fp16_ulp(exact) + 1e-30
+    worse = np.abs(hip - exact) - np.abs(faithful - exact) - slack
+    assert worse.max() <= 0, (name, 'element further from the exact result than the reference by more than %.1f ulp' % extra_ulp, float(worse.max()))
+    assert rel_err(hip, exact) < TOL, (name, rel_err(hip, exact))

@@ -959,6 +959,7 @@ struct gptq_layer {
     int32_t *perm32;               // kind == 1: sorted position -> original k
     uint16_t *perm16;
     int32_t *qw_sorted[2];         // kind == 1: group-sorted qweight copies
+    bool released;                 // the caller freed the checkpoint buffers: qw / sc / qz are gone, the image is the only copy
 };
 
 namespace {
@@ -1111,15 +1112,42 @@ int gptq_layer_stripe_image(const gptq_layer_t *layer, const void **stripe, size
     return GPTQ_OK;
 }
 
+/* Memory mode: the caller is about to FREE the checkpoint buffers (the stripe16 image is a bijection of them: one copy of the packed
+ * weights per layer instead of two).  Only for layers whose every decode / small-batch route runs on the image: trivial g_idx, bits
+ * 2 / 4 / 8, an image present (else GPTQ_E_VARIANT and nothing changes).  Afterwards the routes that read the checkpoint layout
+ * (prefill, fall-backs) first unpack it from the image into `scratch` -- gptq_layer_scratch_bytes() accounts for that. */
+static size_t layer_unpacked_bytes(const gptq_layer &L) {
+    const size_t G = L.groupsize >= L.K ? 1 : (size_t)L.K / L.groupsize;
+    return (size_t)L.nsets * (a256((size_t)(L.K / 32 * L.bits) * L.N * 4) + a256(G * L.N * 2) + a256(G * (size_t)(L.N / 32 * L.bits) * 4));
+}
+int gptq_layer_release_checkpoint(gptq_layer_t *layer) {
+    if (!layer) return GPTQ_E_NULL;
+    if (layer->kind != 0 || !layer->stripe || (layer->bits != 2 && layer->bits != 4 && layer->bits != 8)) return GPTQ_E_VARIANT;
+    layer->released = true;
+    for (int i = 0; i < 2; i++) layer->qw[i] = nullptr, layer->sc[i] = nullptr, layer->qz[i] = nullptr, layer->gi[i] = nullptr;
+    return GPTQ_OK;
+}
+/* the checkpoint buffers of weight set `set` reproduced from the image (bit-exact): for state_dict() of a released layer */
+int gptq_layer_unpack_checkpoint(const gptq_layer_t *layer, int set, int32_t *qweight, void *scales, int32_t *qzeros, gptq_stream_t stream) {
+    if (!layer || !qweight || !scales || !qzeros) return GPTQ_E_NULL;
+    if (!layer->stripe || layer->kind != 0) return GPTQ_E_VARIANT;
+    return stripe_unpack_launch(layer->stripe, layer->K, layer->N, layer->bits, layer->groupsize, layer->nsets, set, (uint32_t *)qweight, (half_t *)scales,
+                                qzeros, (hipStream_t)stream);
+}
+
 /* persistent workspace every forward takes: [split-K words, zero on first use and left zero][scratch of the 16-row MFMA tiles] */
 size_t gptq_layer_workspace_bytes(void) { return WS_BYTES + STRIPE_MM_WS_BYTES; }
 
 /* transient scratch that gives forward(M) its fast route: the gathered x of an act-order batch, the per-call dequantised weight */
 size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M) {
     if (!layer || M <= 0) return 0;
-    if (M >= LAYER_PREFILL_MIN_M && (M > LAYER_STRIPE_MM_MAX_M || !layer->stripe)) return gptq_prefill_workspace_bytes(M, layer->K, layer->N, layer->nsets);
-    return layer->kind == 1 && M > 1 ? a256((size_t)M * layer->K * 2) : 0;
+    const size_t unpack = (layer->released && M > 1) ? layer_unpacked_bytes(*layer) : 0;   // (M == 1 always runs on the image)
+    if (M >= LAYER_PREFILL_MIN_M && (M > LAYER_STRIPE_MM_MAX_M || !layer->stripe)) return unpack + gptq_prefill_workspace_bytes(M, layer->K, layer->N, layer->nsets);
+    return unpack + (layer->kind == 1 && M > 1 ? a256((size_t)M * layer->K * 2) : 0);
 }
+
+static int layer_forward_checkpoint(const gptq_layer &L, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, void *scratch,
+                                    size_t scratch_bytes, gptq_stream_t stream);
 
 int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, size_t workspace_bytes,
                        void *scratch, size_t scratch_bytes, gptq_stream_t stream) {
@@ -1161,6 +1189,32 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
             if (rc != GPTQ_E_VARIANT) return rc;
         }
     }
+    gptq_layer Lr;   // a released layer: the checkpoint layout is rebuilt from the image into the head of `scratch` for the routes below
+    const gptq_layer *Lp = &L;
+    if (L.released) {
+        const size_t ub = layer_unpacked_bytes(L);
+        if (!scratch || !aligned(scratch, 256) || scratch_bytes < ub) return GPTQ_E_WORKSPACE;
+        Lr = L;
+        char *p = (char *)scratch;
+        const size_t G = gs >= K ? 1 : (size_t)K / gs;
+        for (int i = 0; i < ns; i++) {
+            int32_t *qw_i = (int32_t *)p; p += a256((size_t)(K / 32 * bits) * N * 4);
+            void *sc_i = p; p += a256(G * N * 2);
+            int32_t *qz_i = (int32_t *)p; p += a256(G * (size_t)(N / 32 * bits) * 4);
+            if (int rc = stripe_unpack_launch(L.stripe, K, N, bits, gs, ns, i, (uint32_t *)qw_i, (half_t *)sc_i, qz_i, (hipStream_t)stream)) return rc;
+            Lr.qw[i] = qw_i; Lr.sc[i] = sc_i; Lr.qz[i] = qz_i;
+        }
+        scratch = p;
+        scratch_bytes -= ub;
+        Lp = &Lr;
+    }
+    return layer_forward_checkpoint(*Lp, x, ldx, y, ldy, M, workspace, scratch, scratch_bytes, stream);
+}
+
+// routes 2 and 3 of gptq_layer_forward: everything that reads the checkpoint layout
+static int layer_forward_checkpoint(const gptq_layer &L, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, void *scratch,
+                                    size_t scratch_bytes, gptq_stream_t stream) {
+    const int K = L.K, N = L.N, bits = L.bits, gs = L.groupsize, ns = L.nsets;
     // ---- 2. the dense route: dequantise once per call + tile GEMM (any width, any g_idx; no gather of x) ----
     if (M >= LAYER_PREFILL_MIN_M && scratch && aligned(scratch, 256) && scratch_bytes >= gptq_prefill_workspace_bytes(M, K, N, ns)) {
         const int rc = ns == 2 ? gptq_prefill_fused_mlp_f16(x, ldx, L.qw[0], L.sc[0], L.qz[0], L.gi[0], L.qw[1], L.sc[1], L.qz[1], L.gi[1], y, ldy, M, K, N, bits, gs,

@@ -123,6 +123,9 @@ size_t stripe_total_bytes(int K, int N, int bits, int groupsize, int nsets);
 int stripe_repack_launch(const uint32_t *qw0, const half_t *sc0, const int32_t *qz0, const uint32_t *qw1, const half_t *sc1,
                          const int32_t *qz1, void *out, int K, int N, int bits, int groupsize, hipStream_t s);
 int stripe_gemv_dispatch(const StripeParams &p, hipStream_t s);
+// inverse of stripe_repack_launch for ONE set (bits 2 / 4 / 8): qweight [K/32*bits][N], scales [G][N], qzeros [G][N/32*bits]
+int stripe_unpack_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, int set, uint32_t *qw, half_t *sc, int32_t *qz,
+                         hipStream_t s);
 
 int gptq_block_launch(const float *W, int64_t ldw, const float *Hinv, int64_t ldh, int rows, int i1, int count, int groupsize, int maxq,
                       const float *scale, const float *zero, int64_t ldg, float *Q, int64_t ldq, float *Err, int64_t lde, float *loss_rows,

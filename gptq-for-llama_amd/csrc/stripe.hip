@@ -111,7 +111,61 @@ __global__ void __launch_bounds__(256) stripe_table_kernel(const half_t *__restr
     }
 }
 
+// ---- the inverse (bits 2 / 4 / 8): checkpoint buffers of ONE weight set back out of an image.  The image is a bijection of
+// (qweight, scales, qzeros) -- oracle.stripe16_unpack states it, tests hold both directions bit-exact -- so a model that has
+// released its checkpoint buffers (GPTQ_RELEASE_CHECKPOINT, DESIGN.md "memory") can still produce its state_dict and feed the
+// per-call dequantise pass of the prefill route.
+__global__ void __launch_bounds__(256) stripe_unpack_kernel(const uint32_t *__restrict__ R, uint32_t *__restrict__ qw, int N, int nrb, int NS, int set,
+                                                            int bits, size_t total) {
+    const int F = 32 / bits;
+    const uint32_t fm = (1u << bits) - 1u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % N), row = (int)(i / N);
+        const int stripe = col >> 4, c = col & 15, rb = row >> 4, rr = row & 15;
+        const int l = (rr >> 2) * 16 + c, j = rr & 3;
+        const uint32_t o = R[((((size_t)stripe * nrb + rb) * NS + set) * 64 + l) * 4 + j];
+        uint32_t w = 0;
+        for (int p = 0; p < F; p++) w |= ((o >> (bits * p)) & fm) << (bits * stripe_k_of_pos(p, F));
+        qw[i] = w;
+    }
+}
+
+template <int BITS>
+__global__ void __launch_bounds__(256) stripe_untable_kernel(const uint32_t *__restrict__ tab, half_t *__restrict__ sc, uint32_t *__restrict__ qz, int N,
+                                                             int G, int NS, int set) {
+    constexpr int F = 32 / BITS;
+    const size_t total = (size_t)G * (N / F);   // one thread per qzeros word = F columns of one group
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int wcol = (int)(i % (N / F)), g = (int)(i / (N / F));
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < F; j++) {
+            const int n = wcol * F + j;
+            const half2_t e = as_half2(tab[(((size_t)(n >> 4) * NS + set) * G + g) * 16 + (n & 15)]);
+            sc[(size_t)g * N + n] = e[0];
+            const uint32_t stored = ((uint32_t)(int)(float)e[1] - 1u) & ((1u << BITS) - 1u);   // the table holds zero + 1 (not re-masked: 16 for a stored 15)
+            word |= stored << (BITS * j);
+        }
+        qz[i] = word;
+    }
+}
+
 }  // namespace
+
+int stripe_unpack_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, int set, uint32_t *qw, half_t *sc, int32_t *qz,
+                         hipStream_t s) {
+    if (bits != 2 && bits != 4 && bits != 8) return GPTQ_E_VARIANT;
+    if (stripe_gq_shift(K, N, bits, groupsize) == -2 || set < 0 || set >= nsets || N % (32 / bits) != 0) return GPTQ_E_VARIANT;
+    const int G = groupsize >= K ? 1 : K / groupsize;
+    const uint32_t *R = (const uint32_t *)image;
+    const uint32_t *tab = (const uint32_t *)((const char *)image + stripe_tab_offset(K, N, bits, nsets));
+    const size_t words = (size_t)(K / 32 * bits) * N;
+    hipLaunchKernelGGL(stripe_unpack_kernel, dim3(2048), dim3(256), 0, s, R, qw, N, K / (16 * (32 / bits)), nsets, set, bits, words);
+    if (bits == 2) hipLaunchKernelGGL(stripe_untable_kernel<2>, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
+    else if (bits == 4) hipLaunchKernelGGL(stripe_untable_kernel<4>, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
+    else hipLaunchKernelGGL(stripe_untable_kernel<8>, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
+    return (int)hipGetLastError();
+}
 
 // groupsize is the effective one (K for the reference's -1).  Returns log2(groupsize / (4 KPW)), -1 for one group, -2 if ineligible.
 int stripe_gq_shift(int K, int N, int bits, int groupsize) {

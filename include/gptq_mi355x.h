@@ -398,6 +398,12 @@ int gptq_layer_prepare(gptq_layer_t **layer, const int32_t *qweight, const void 
 void gptq_layer_destroy(gptq_layer_t *layer);
 int gptq_layer_kind(const gptq_layer_t *layer);
 int gptq_layer_stripe_image(const gptq_layer_t *layer, const void **stripe, size_t *stripe_bytes, const uint16_t **perm16);
+/* Memory mode (reference README.md:23-29 quotes 4891 MiB for 7B 4-bit g128: ONE copy of the packed weights): after this call the
+ * caller may free qweight / scales / qzeros -- the stripe16 image is a bijection of them.  Trivial g_idx, bits 2 / 4 / 8 and an image
+ * only (GPTQ_E_VARIANT otherwise, nothing changes).  Routes that read the checkpoint layout (prefill, fall-backs) then rebuild it
+ * from the image into `scratch` per call; gptq_layer_unpack_checkpoint reproduces one weight set bit-exactly (state_dict()). */
+int gptq_layer_release_checkpoint(gptq_layer_t *layer);
+int gptq_layer_unpack_checkpoint(const gptq_layer_t *layer, int set, int32_t *qweight, void *scales, int32_t *qzeros, gptq_stream_t stream);
 size_t gptq_layer_workspace_bytes(void);
 size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M);
 int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace,

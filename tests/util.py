@@ -62,7 +62,11 @@ def assert_not_worse_than_reference(hip, faithful, exact, extra_ulp=1.0, name=''
     float64 result than the reference-faithful oracle only by ``extra_ulp`` fp16 spacings of the value (one rounding flip), and its
     max-normalised error against the float64 result stays below the op-level bar."""
     hip, faithful, exact = (np.asarray(t, dtype=np.float64) for t in (hip, faithful, exact))
-    slack = extra_ulp * fp16_ulp(exact) + 1e-30
+    # elements more than 2^10 times smaller than the largest output sit on cancelled sums: BOTH results carry the same fp32
+    # accumulation-order noise there (~1e-6 of the partial sums), which exceeds the fp16 spacing of such a tiny value -- the slack never
+    # drops below the spacing at max|exact| / 1024 (observed on the MI355X: excess of 1e-7 .. 1.4e-5 on outputs of magnitude <= 1e-3)
+    floor = np.abs(exact).max() * 2.0 ** -10
+    slack = extra_ulp * fp16_ulp(np.maximum(np.abs(exact), floor)) + 1e-30
     worse = np.abs(hip - exact) - np.abs(faithful - exact) - slack
     assert worse.max() <= 0, (name, 'element further from the exact result than the reference by more than %.1f ulp' % extra_ulp, float(worse.max()))
     assert rel_err(hip, exact) < TOL, (name, rel_err(hip, exact))

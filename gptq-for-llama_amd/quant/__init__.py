@@ -5,7 +5,7 @@ exactly as with the reference tree: every public name of the reference's ``quant
 re-exported below from the sub-module of the same file name, plus the two spellings of the old-cuda
 branch that ``BASELINE.json``'s north_star uses (``make_quant``, ``autotune_warmup``).
 """
-from . import quantizer, quant_linear, fused_attn, fused_mlp, triton_norm, tensor_parallel, decode  # noqa: F401
+from . import layer, quantizer, quant_linear, fused_attn, fused_mlp, triton_norm, tensor_parallel, decode  # noqa: F401
 
 _PUBLIC = {
     quantizer: ('Quantizer', ),
@@ -19,3 +19,27 @@ for _mod, _names in _PUBLIC.items():
         globals()[_n] = getattr(_mod, _n)
 __all__ = [n for names in _PUBLIC.values() for n in names]
 del _mod, _names, _n
+
+
+def release_checkpoint(model):
+    """Memory mode for a whole model (extension; GPTQ_RELEASE_CHECKPOINT=1 applies it when the decode engine is first built): every
+    QuantLinear / QuantLlamaMLP whose decode path runs on its stripe16 image frees qweight / scales / qzeros and keeps that ONE copy
+    of the packed weights -- the footprint the reference quotes (README.md:23-29: 4891 MiB for 7B 4-bit g128) instead of two
+    copies.  ``state_dict()`` is unchanged (tensors reproduced bit-exactly from the images).  Returns (released, kept) counts."""
+    import torch
+    done = kept = 0
+    for m in model.modules():
+        if isinstance(m, (quant_linear.QuantLinear, fused_mlp.QuantLlamaMLP)):
+            if m.release_checkpoint():
+                done += 1
+            else:
+                kept += 1
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    return done, kept
+
+
+def restore_checkpoint(model):
+    for m in model.modules():
+        if isinstance(m, (quant_linear.QuantLinear, fused_mlp.QuantLlamaMLP)):
+            m.restore_checkpoint()

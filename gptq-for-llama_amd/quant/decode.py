@@ -188,16 +188,23 @@ class DecodeEngine:
             attn, mlp = layer.self_attn, layer.mlp
             if not isinstance(attn, fused_attn.QuantLlamaAttention) or not isinstance(mlp, fused_mlp.QuantLlamaMLP):
                 raise RuntimeError('DecodeEngine needs make_quant_attn / make_fused_mlp applied first')
+            if getattr(mlp, '_released', None) is not None:     # memory mode: the pair's image is the only copy of gate / up
+                gpack = self._released_pack(mlp._released, mlp.bits, mlp.groupsize, mlp.infeatures, mlp.intermediate_size, None)
+                upack = dict(gpack)
+            else:
+                gpack = self._pack_raw(mlp.gate_proj_qweight, mlp.gate_proj_scales, mlp.gate_proj_qzeros, mlp.gate_proj_g_idx,
+                                       mlp.bits, mlp.groupsize, mlp.infeatures, mlp.intermediate_size)
+                upack = self._pack_raw(mlp.up_proj_qweight, mlp.up_proj_scales, mlp.up_proj_qzeros, mlp.up_proj_g_idx, mlp.bits,
+                                       mlp.groupsize, mlp.infeatures, mlp.intermediate_size)
             self.layers.append(dict(
                 ln1=layer.input_layernorm.weight, ln2=layer.post_attention_layernorm.weight,
                 qkv=self._pack(attn.qkv_proj), o=self._pack(attn.o_proj), down=self._pack(mlp.down_proj),
-                gate=self._pack_raw(mlp.gate_proj_qweight, mlp.gate_proj_scales, mlp.gate_proj_qzeros, mlp.gate_proj_g_idx,
-                                    mlp.bits, mlp.groupsize, mlp.infeatures, mlp.intermediate_size),
-                up=self._pack_raw(mlp.up_proj_qweight, mlp.up_proj_scales, mlp.up_proj_qzeros, mlp.up_proj_g_idx, mlp.bits,
-                                  mlp.groupsize, mlp.infeatures, mlp.intermediate_size),
-                theta=float(attn.rope_theta)))
+                gate=gpack, up=upack, theta=float(attn.rope_theta)))
             L = self.layers[-1]   # gate and up share their input, hence (normally) their act-order permutation: checked ONCE here
             g, u = L['gate'], L['up']
+            if getattr(mlp, '_released', None) is not None:
+                g['pair_sorted'], g['st2'], g['st'] = False, mlp._released.stripe, None
+                continue
             g['pair_sorted'] = (g['srt'] is not None and u['srt'] is not None and bool(torch.equal(g['srt'][1], u['srt'][1])))
             g['st2'] = None     # gate and up in ONE stripe16 image (silu(gate) * up in the kernel epilogue)
             if g['bits'] in (2, 3, 4, 8) and ((g['gi'] is None and u['gi'] is None) or g['pair_sorted']):
@@ -235,7 +242,14 @@ class DecodeEngine:
         st = quant_linear.stripe_copy(srt[0] if srt is not None else qw, scales, qz, bits, groupsize) if (gi is None or srt is not None) else None
         return dict(qw=qw, sc=scales, qz=qz, gi=gi, bits=bits, gs=groupsize, K=K, N=N, bias=bias, srt=srt, st=st)
 
+    @staticmethod
+    def _released_pack(pl, bits, groupsize, K, N, bias):
+        """a module in memory mode (release_checkpoint): its PreparedLayer's image is all there is -- and all the decode kernels need"""
+        return dict(qw=None, sc=None, qz=None, gi=None, bits=bits, gs=groupsize, K=K, N=N, bias=bias, srt=None, st=pl.stripe, _keep=pl)
+
     def _pack(self, ql):
+        if getattr(ql, '_released', None) is not None:
+            return self._released_pack(ql._released, ql.bits, ql.groupsize, ql.infeatures, ql.outfeatures, ql.bias)
         return self._pack_raw(ql.qweight, ql.scales, ql.qzeros, ql.g_idx, ql.bits, ql.groupsize, ql.infeatures, ql.outfeatures,
                               ql.bias)
 
@@ -487,6 +501,9 @@ def engine_generate(model, input_ids, max_new_tokens, eos_token_id=None, engine=
 def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fuse_norm=True, fuse_attn=True, start_pos=0):
     """the llama.py:385-438 protocol on the DecodeEngine (hipGraph replay per token)."""
     dev = next(model.parameters()).device
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
     eng = DecodeEngine(model, t_max=t_max, fuse_norm=fuse_norm, fuse_attn=fuse_attn)
     if graph:
         eng.capture()
@@ -511,4 +528,6 @@ def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fu
             't_max': t_max, 'start_pos': start_pos, 'fused_norm': fuse_norm, 'fused_attention': fuse_attn,
             # per layer: [norm,] qkv, [rope+append, attention partial, merge | one fused launch], o+residual, [norm,] gate/up, down+residual
             'launches_per_token': (9 - 2 * int(fuse_norm) - 2 * int(fuse_attn)) * len(eng.layers) + 4, 'median_s_per_token': round(med, 6),
-            'tokens_per_s': round(1.0 / med, 1)}
+            'tokens_per_s': round(1.0 / med, 1),
+            # the llama.py:426-438 figure: peak bytes in use by tensors while decoding (model + derived copies + KV cache of t_max + engine buffers)
+            'max_memory_MiB': round(torch.cuda.max_memory_allocated(dev) / 1024 / 1024, 1)}

@@ -32,6 +32,7 @@ import weakref
 import torch
 
 ENABLED = os.environ.get('GPTQ_DECODE_ENGINE', '1') != '0'
+RELEASE_CHECKPOINT = os.environ.get('GPTQ_RELEASE_CHECKPOINT', '0') == '1'
 
 
 class _State:
@@ -119,6 +120,10 @@ def _engine_forward(model, st, input_ids, cache, attention_mask, position_ids, k
         return None
     if st.engine is None or st.sig != sig:
         t_max = int(min(max(getattr(model.config, 'max_position_embeddings', 2048), 256), 8192))
+        if RELEASE_CHECKPOINT:      # memory mode: from the first decode step on ONE copy of the packed weights (quant.release_checkpoint)
+            from . import release_checkpoint
+            release_checkpoint(model)
+            sig = _signature(model)     # the placeholders are new tensor objects
         st.engine = DecodeEngine(model, t_max=t_max).capture()
         st.sig, st.cache_ref = sig, None
     eng = st.engine

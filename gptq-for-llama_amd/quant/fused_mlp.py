@@ -74,12 +74,61 @@ class QuantLlamaMLP(nn.Module):
         self.groupsize = gate_proj.groupsize
 
         self.down_proj = down_proj
+        self._released = None     # memory mode: the pair's PreparedLayer holds the only copy of gate / up (release_checkpoint)
 
     def forward(self, x):
         return self.down_proj(self.hip_llama_mlp(x))
 
+    # memory mode, see QuantLinear.release_checkpoint: gate | up live on in ONE stripe16 image of the pair
+    def release_checkpoint(self):
+        if self._released is not None:
+            return True
+        if not self.gate_proj_qweight.is_cuda:
+            return False
+        from .layer import prepared
+        pl = prepared(((self.gate_proj_qweight, self.gate_proj_scales, self.gate_proj_qzeros, self.gate_proj_g_idx),
+                       (self.up_proj_qweight, self.up_proj_scales, self.up_proj_qzeros, self.up_proj_g_idx)), None, self.bits,
+                      self.groupsize if self.groupsize != -1 else self.infeatures, self.infeatures, self.intermediate_size)
+        if not pl.release():
+            return False
+        self._released = pl
+        dev, N = self.gate_proj_qweight.device, self.intermediate_size
+        for p in ('gate_proj_', 'up_proj_'):
+            setattr(self, p + 'qweight', torch.empty((0, N), dtype=torch.int32, device=dev))
+            setattr(self, p + 'qzeros', torch.empty((0, N // 32 * self.bits), dtype=torch.int32, device=dev))
+            setattr(self, p + 'scales', torch.empty((0, N), dtype=torch.float16, device=dev))
+        return True
+
+    def restore_checkpoint(self):
+        if self._released is not None:
+            pl, self._released = self._released, None
+            for i, p in enumerate(('gate_proj_', 'up_proj_')):
+                qw, sc, qz = pl.unpack(i)
+                setattr(self, p + 'qweight', qw), setattr(self, p + 'scales', sc), setattr(self, p + 'qzeros', qz)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self._released is not None:
+            for i, p in enumerate(('gate_proj_', 'up_proj_')):
+                qw, sc, qz = self._released.unpack(i)
+                destination[prefix + p + 'qweight'], destination[prefix + p + 'scales'], destination[prefix + p + 'qzeros'] = qw, sc, qz
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.restore_checkpoint()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def hip_llama_mlp(self, x):
         out_shape = x.shape[:-1] + (self.intermediate_size, )
+        if self._released is not None:
+            from . import quant_linear
+            _native.require_device(x, 'QuantLlamaMLP')
+            x2 = _as_rows(x.reshape(-1, x.shape[-1]))
+            quant_linear._apply_prefill_route()
+            with torch.cuda.device(x2.device):
+                c = torch.empty((x2.shape[0], self.intermediate_size), device=x2.device, dtype=torch.float16)
+                if x2.shape[0]:
+                    self._released.forward(x2, c)
+            return c.reshape(out_shape)
         c = fused_gate_up(x, (self.gate_proj_qweight, self.gate_proj_scales, self.gate_proj_qzeros, self.gate_proj_g_idx),
                           (self.up_proj_qweight, self.up_proj_scales, self.up_proj_qzeros, self.up_proj_g_idx), self.bits,
                           self.groupsize)

@@ -67,6 +67,7 @@ class PreparedLayer:
                                         ptr(s1[2]), ptr(s1[3]), K, N, bits, groupsize, ptr(self.image), nbytes, stream)
         _native.check(rc, 'gptq_layer_prepare')
         self.handle = h
+        self.released = False
         self.kind = lib.gptq_layer_kind(h)
         st, nb, p16 = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_void_p()
         lib.gptq_layer_stripe_image(h, ctypes.byref(st), ctypes.byref(nb), ctypes.byref(p16))
@@ -84,6 +85,29 @@ class PreparedLayer:
                 self.lib.gptq_layer_destroy(h)
             except Exception:   # interpreter shutdown
                 pass
+
+    def release(self):
+        """memory mode (gptq_layer_release_checkpoint): the handle stops reading the checkpoint buffers -- the stripe16 image is a
+        bijection of them -- and this object lets go of its references, so the caller can free them.  False (nothing changed) for
+        layers that need the checkpoint layout: act-order, 3-bit, no image."""
+        if self.lib.gptq_layer_release_checkpoint(self.handle) != 0:
+            return False
+        bias = self._keep[-1] if self._keep else None      # the handle still reads the bias
+        self._keep = [bias]
+        self.released = True
+        return True
+
+    def unpack(self, which=0):
+        """(qweight, scales, qzeros) of weight set ``which`` reproduced bit-exactly from the image (gptq_layer_unpack_checkpoint)"""
+        K, N, bits = self.K, self.N, self.bits
+        G = 1 if self.groupsize >= K else K // self.groupsize
+        with torch.cuda.device(self.device):
+            qw = torch.empty((K // 32 * bits, N), dtype=torch.int32, device=self.device)
+            sc = torch.empty((G, N), dtype=torch.float16, device=self.device)
+            qz = torch.empty((G, N // 32 * bits), dtype=torch.int32, device=self.device)
+            rc = self.lib.gptq_layer_unpack_checkpoint(self.handle, which, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), _native.stream_ptr(self.device))
+        _native.check(rc, 'gptq_layer_unpack_checkpoint')
+        return qw, sc, qz
 
     def forward(self, x, out):
         """out[M, N] = layer(x[M, K]) on the current stream of x's device.  x: fp16, unit column stride, 16-byte aligned rows."""

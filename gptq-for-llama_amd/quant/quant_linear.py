@@ -461,6 +461,44 @@ class QuantLinear(nn.Module):
             self.register_buffer('bias', torch.zeros((outfeatures), dtype=torch.float16))
         else:
             self.bias = None
+        self._released = None     # memory mode: the PreparedLayer that now holds the ONLY copy of the packed weights (release_checkpoint)
+
+    # ------------------------------------------------------------------------------ memory mode
+    def release_checkpoint(self):
+        """Keep ONE copy of the packed weights instead of two (the reference's footprint, README.md:23-29): the stripe16 image the
+        decode kernels read is a bijection of qweight / scales / qzeros, so those buffers are freed (they become empty
+        placeholders) and forward() goes straight to the prepared handle.  ``state_dict()`` still returns the original tensors
+        (reproduced bit-exactly from the image), ``load_state_dict`` restores the buffers first.  Inference only.  Returns False
+        -- and changes nothing -- for layers that need the checkpoint layout (act-order g_idx, 3-bit, K not served by the image)."""
+        if self._released is not None:
+            return True
+        if not self.qweight.is_cuda:
+            return False
+        pl = prepared(((self.qweight, self.scales, self.qzeros, self.g_idx),), self.bias, self.bits, self.groupsize, self.infeatures, self.outfeatures)
+        if not pl.release():
+            return False
+        self._released = pl
+        dev = self.qweight.device
+        self.qweight = torch.empty((0, self.outfeatures), dtype=torch.int32, device=dev)
+        self.qzeros = torch.empty((0, self.outfeatures // 32 * self.bits), dtype=torch.int32, device=dev)
+        self.scales = torch.empty((0, self.outfeatures), dtype=torch.float16, device=dev)
+        return True
+
+    def restore_checkpoint(self):
+        """undo release_checkpoint: the buffers come back out of the image (bit-exact)"""
+        if self._released is not None:
+            pl, self._released = self._released, None
+            self.qweight, self.scales, self.qzeros = pl.unpack(0)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self._released is not None:        # the checkpoint format does not change with the memory mode
+            qw, sc, qz = self._released.unpack(0)
+            destination[prefix + 'qweight'], destination[prefix + 'scales'], destination[prefix + 'qzeros'] = qw, sc, qz
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.restore_checkpoint()
+        return super()._load_from_state_dict(*args, **kwargs)
 
     # ------------------------------------------------------------------------------------ pack
     def pack(self, linear, scales, zeros, g_idx=None):
@@ -512,6 +550,17 @@ class QuantLinear(nn.Module):
     def forward(self, x):
         out_shape = x.shape[:-1] + (self.outfeatures, )
         x2 = x.reshape(-1, x.shape[-1])
+        if self._released is not None:
+            if torch.is_grad_enabled() and x2.requires_grad:
+                raise RuntimeError('QuantLinear: release_checkpoint() is an inference mode; restore_checkpoint() before a backward pass')
+            _native.require_device(x2, 'QuantLinear.forward')
+            xr = _as_rows(x2)
+            _apply_prefill_route()
+            with torch.cuda.device(xr.device):
+                out = torch.empty((xr.shape[0], self.outfeatures), device=xr.device, dtype=torch.float16)
+                if xr.shape[0]:
+                    self._released.forward(xr, out)
+            return out.reshape(out_shape)
         if torch.is_grad_enabled() and x2.requires_grad:
             out = QuantLinearFunction.apply(x2, self.qweight, self.scales, self.qzeros, self.g_idx, self.bits, self.maxq)
             out = out + self.bias if self.bias is not None else out

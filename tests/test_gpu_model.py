@@ -560,6 +560,53 @@ def test_left_padded_prompt_is_left_to_the_module_chain():
     assert torch.equal(outs[0], outs[1])
 
 
+def test_release_checkpoint_memory_mode():
+    """quant.release_checkpoint(model): ONE copy of the packed weights (the stripe16 images) instead of two -- the reference's
+    footprint (README.md:23-29).  Logits of a prefill (M = 9: MFMA tiles on the image; M = 200: the dense route on buffers unpacked
+    from the image per call) and greedy decode through the engine are BIT-identical before and after, state_dict() still returns
+    the original checkpoint tensors bit for bit, load_state_dict / restore_checkpoint bring the buffers back."""
+    import quant
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=17, fused=True, **HOOK_CFG)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator(device=DEV).manual_seed(8)
+    ids9, ids200 = torch.randint(0, 512, (1, 9), device=DEV, generator=g), torch.randint(0, 512, (1, 200), device=DEV, generator=g)
+
+    def probe():
+        with torch.no_grad():
+            a = model(ids9).logits.clone()
+            b = model(ids200).logits.clone()
+            c = model.generate(ids9, do_sample=False, max_new_tokens=12, min_new_tokens=12)
+        return a, b, c
+    before = probe()
+    torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_allocated()
+    done, kept = quant.release_checkpoint(model)
+    assert (done, kept) == (4 * HOOK_CFG['num_hidden_layers'], 0)          # qkv, o, down + the gate/up pair of every layer
+    packed = sum(v.numel() * v.element_size() for k, v in sd0.items() if k.endswith(('qweight', 'qzeros', 'scales')))
+    assert mem0 - torch.cuda.memory_allocated() >= 0.9 * packed              # the checkpoint copies are really gone
+    assert all(m.qweight.numel() == 0 for m in model.modules() if isinstance(m, quant.QuantLinear))
+    after = probe()
+    for x, y in zip(before, after):
+        assert torch.equal(x, y)
+    sd1 = model.state_dict()
+    assert list(sd1) == list(sd0)
+    for k in sd0:
+        assert sd1[k].shape == sd0[k].shape and torch.equal(sd1[k], sd0[k]), k
+    lin = next(m for m in model.modules() if isinstance(m, quant.QuantLinear))
+    with pytest.raises(RuntimeError):
+        with torch.enable_grad():
+            lin(torch.randn(2, lin.infeatures, device=DEV, dtype=torch.float16, requires_grad=True))
+    model.load_state_dict(sd0)                                              # restores the buffers first, then copies
+    assert all(m.qweight.numel() > 0 and m._released is None for m in model.modules() if isinstance(m, quant.QuantLinear))
+    again = probe()
+    for x, y in zip(before, again):
+        assert torch.equal(x, y)
+    quant.release_checkpoint(model)
+    quant.restore_checkpoint(model)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+
+
 # ---------------------------------------------------------------------------------------
 # BASELINE config 5 at the model level: tensor-parallel decode (quant/tp_decode.py), two ranks sharing the one GPU of the test box,
 # the exchanges through the one-shot all-reduce captured in each rank's hipGraph

@@ -1378,3 +1378,73 @@ def test_p2p_allreduce_two_processes_one_gpu(world):
             p.kill()
         assert p.exitcode == 0
     assert ret.get(timeout=5) == 1
+
+
+@pytest.mark.parametrize('bits,gs,K,N,act,pair', [(4, 128, 4096, 4096, False, False), (4, 128, 1024, 512, True, False), (4, 128, 4096, 11008, False, True),
+                                                 (4, 128, 1024, 288, True, True), (8, 64, 1024, 96, False, False), (3, -1, 512, 320, False, False),
+                                                 (2, 128, 1024, 64, True, False), (4, 32, 416, 288, False, False)])
+def test_prepared_layer_abi_direct(bits, gs, K, N, act, pair):
+    """the product's ONE call site used the way a non-Python consumer uses it: gptq_layer_inspect ->
+    gptq_layer_image_bytes -> gptq_layer_prepare -> gptq_layer_forward for M = 1 .. 300 with nothing but raw pointers; act-order layers
+    (group-sorted image + permutation inside the handle), the gate/up pair, shapes without an image; against the oracle on the original
+    buffers.  Then memory mode: release_checkpoint, free the buffers, same answers; unpack_checkpoint reproduces them bit for bit."""
+    import ctypes
+    lib = _native.lib()
+    A = make_random_layer(bits, gs, K, N, act_order=act, seed=K + N)
+    B = make_random_layer(bits, gs, K, N, act_order=act, seed=K + N + 1)
+    if act:
+        B['g_idx'] = A['g_idx']
+    gsz = K if gs == -1 else gs
+    a = [dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx')]
+    b = [dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx')] if pair else [None] * 4
+    bias = None if pair else np.random.default_rng(5).standard_normal(N).astype(np.float16)
+    dbias = None if bias is None else dev(bias)
+    s = torch.cuda.current_stream().cuda_stream
+    kind = lib.gptq_layer_inspect(a[3].data_ptr(), K, gsz, s)
+    assert kind == (1 if act else 0)
+    nbytes = lib.gptq_layer_image_bytes(K, N, bits, gsz, 2 if pair else 1, kind)
+    image = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=DEV)
+    h = ctypes.c_void_p()
+    p = _native.ptr
+    rc = lib.gptq_layer_prepare(ctypes.byref(h), a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), p(dbias), p(b[0]), p(b[1]), p(b[2]), p(b[3]),
+                                K, N, bits, gsz, image.data_ptr() if nbytes else None, nbytes, s)
+    assert rc == 0 and lib.gptq_layer_kind(h) == kind
+    ws = torch.zeros(lib.gptq_layer_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    rng = np.random.default_rng(K)
+
+    def run(M):
+        x = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+        dx, y = dev(x), torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+        need = lib.gptq_layer_scratch_bytes(h, M)
+        scratch = torch.empty(max(need, 1), dtype=torch.uint8, device=DEV)
+        rc = lib.gptq_layer_forward(h, dx.data_ptr(), K, y.data_ptr(), N, M, ws.data_ptr(), ws.numel(), scratch.data_ptr() if need else None, need, s)
+        assert rc == 0, (M, rc)
+        torch.cuda.synchronize()
+        return x, y.cpu().numpy()
+
+    def check(M):
+        x, y = run(M)
+        ta = (A['qweight'], A['scales'], A['qzeros'], A['g_idx'])
+        if pair:
+            ref = oracle.fused_mlp(x, ta, (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits)
+            assert rel_err(y, ref) < TOL, (M, rel_err(y, ref))
+        else:
+            assert rel_err(y, exact_forward(x, A, bias)) < TOL, M          # bias: two roundings -> float64 bar
+        return y
+    ys = {M: check(M) for M in (1, 3, 8, 17, 64, 100, 300)}
+    if kind == 0 and nbytes and bits != 3:
+        assert lib.gptq_layer_release_checkpoint(h) == 0
+        keep = [t.clone() for t in a[:3]]
+        for t in a[:3] + (b[:3] if pair else []):
+            t.fill_(0)                                                       # the "freed" buffers must never be read again
+        rng = np.random.default_rng(K)
+        for M in (1, 3, 8, 17, 64, 100, 300):
+            _, y = run(M)
+            assert np.array_equal(y.view(np.uint16), ys[M].view(np.uint16)), M
+        qw, sc, qz = torch.empty_like(keep[0]), torch.empty_like(keep[1]), torch.empty_like(keep[2])
+        assert lib.gptq_layer_unpack_checkpoint(h, 0, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), s) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(qw, keep[0]) and torch.equal(sc, keep[1]) and torch.equal(qz, keep[2])
+    else:
+        assert lib.gptq_layer_release_checkpoint(h) == -6 or not nbytes
+    lib.gptq_layer_destroy(h)

@@ -623,7 +623,6 @@ def decode_tokens_per_s(dev, tokens=64):
     # memory mode (quant.release_checkpoint / GPTQ_RELEASE_CHECKPOINT=1): ONE copy of the packed weights -- the stripe16 images -- like
     # the reference's 4891 MiB for 7B 4-bit g128 (README.md:26, protocol llama.py:426-438); same kernels, same tokens/s
     import quant
-    model._gptq_engine_state.engine = None          # the hook's engine holds its own buffers: drop it before measuring
     done, kept = quant.release_checkpoint(model)
     out['engine_graph_memory_mode'] = dict(benchmark_decode_engine(model, tokens=tokens, graph=True), released_modules=done, kept_modules=kept,
                                            reference_published_MiB=4891)

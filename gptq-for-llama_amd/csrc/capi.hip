@@ -715,6 +715,7 @@ int gptq_prefill_route_for(int M, int K, int N, int nsets, int trans) {
     return (gemm8_wanted(M, N, nsets == 2) && K % 128 == 0) ? 1 : 0;
 }
 int gptq_set_library_enabled(int on) { return dense_gemm_set_enabled(on); }
+int gptq_set_gemm8_mfma(int shape) { return gemm8_set_mfma(shape); }
 int gptq_prefill_plan_count(void) { return dense_gemm_plan_count(); }
 
 int gptq_set_prefill_route(int route) {

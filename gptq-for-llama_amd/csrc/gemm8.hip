@@ -31,6 +31,7 @@
 //    issues DMA.  Waits sit at the END of an R section, i.e. one barrier before the staggered partner's first read
 //    (guide: "one barrier MORE when two wave groups run staggered");
 //  * workgroups are numbered so that all n tiles of an m tile run on one XCD (X panel fetched once per XCD-group).
+#include <atomic>
 #include <type_traits>
 
 #include "gptq_device.h"
@@ -66,7 +67,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define G8_VMCNT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define G8_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <bool PAIR>
+// MF32: v_mfma_f32_32x32x16_f16 instead of 16x16x32 (8 instead of 16 MFMAs per phase at the same LDS traffic; the larger shape reaches
+// the full 1024 flop / cycle / SIMD, the smaller one ~85-94 % of it) -- same units, phases and waits, other fragment maps.
+template <bool PAIR, bool MF32>
 __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ALL of the kernel's LDS (one object: see the guide's .s traps)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -112,41 +115,50 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
     // ---- fragment reads.  A 16x16x32 operand: lane l holds row l % 16, k = 8 (l / 16) .. +7 of a 32-k step; both operands
     // come out of LDS the same way.  Chunk of k-step ks: (4 ks + l / 16) ^ swz, swz = ((l % 16) >> 1) & 7 (unit rows start at
     // multiples of 16, so only the low row bits reach the swizzle): the ks = 1 address is the ks = 0 address ^ 64.
-    const int swz = (lane & 15) >> 1;
-    const int lb0 = (lane & 15) * 128 + (((lane >> 4) ^ swz) << 4);
+    // A 32x32x16 operand (MF32): row l % 32, k = 8 (l / 32) .. +7 of a 16-k step: chunk (2 ks + l / 32) ^ swz, swz = ((l % 32) >> 1) & 7,
+    // i.e. the ks address is the ks = 0 address ^ (32 ks).
+    constexpr int RL = MF32 ? 32 : 16;                       // rows of a fragment
+    const int frow = lane & (RL - 1), fkb = MF32 ? (lane >> 5) : (lane >> 4);
+    const int swz = (frow >> 1) & 7;
+    const int lb0 = frow * 128 + ((fkb ^ swz) << 4);
     const int lb1 = lb0 ^ 64;
     const int xbase = wr * 64 * 128, wbase = wc * 32 * 128;
-    half8_t xf[4][2], wf[2][2][2];   // X fragments of the current m half [ii][ks]; W fragments [nh][jj][ks]
+    constexpr int XF = MF32 ? 2 : 4, WF = MF32 ? 1 : 2, KS = MF32 ? 4 : 2;   // m reps of an X unit, n reps of a W unit, k steps of a tile
+    half8_t xf[XF][KS], wf[2][WF][KS];   // X fragments of the current m half [ii][ks]; W fragments [nh][jj][ks]
     auto read_x = [&](int buf, int mh) {
         const char *b = smem + buf * BUF_BYTES + (mh ? OFF_X1 : OFF_X0) + xbase;
 #pragma unroll
-        for (int ii = 0; ii < 4; ii++) {
-            xf[ii][0] = *(const half8_t *)(b + ii * 2048 + lb0);
-            xf[ii][1] = *(const half8_t *)(b + ii * 2048 + lb1);
-        }
+        for (int ii = 0; ii < XF; ii++)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) xf[ii][ks] = *(const half8_t *)(b + ii * (RL * 128) + (MF32 ? (lb0 ^ (ks * 32)) : (ks ? lb1 : lb0)));
     };
     auto read_w = [&](int buf, int nh) {
         const char *b = smem + buf * BUF_BYTES + (nh ? OFF_W1 : OFF_W0) + wbase;
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            wf[nh][jj][0] = *(const half8_t *)(b + jj * 2048 + lb0);
-            wf[nh][jj][1] = *(const half8_t *)(b + jj * 2048 + lb1);
-        }
+        for (int jj = 0; jj < WF; jj++)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) wf[nh][jj][ks] = *(const half8_t *)(b + jj * (RL * 128) + (MF32 ? (lb0 ^ (ks * 32)) : (ks ? lb1 : lb0)));
     };
-    f32x4 acc[8][4];   // [m rep][n rep]; n rep j = 2 nh + jj
+    // accumulators: 16x16: [8 m reps][4 n reps] x 4 floats; 32x32: [4 m reps][2 n reps] x 16 floats -- 128 registers either way
+    typedef typename std::conditional<MF32, float16_t, f32x4>::type acc_t;
+    constexpr int AM = MF32 ? 4 : 8, AN = MF32 ? 2 : 4;
+    acc_t acc[AM][AN];   // n rep j = WF nh + jj
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < AM; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < AN; j++) acc[i][j] = (acc_t)0.f;
     auto mma = [&](int mh, int nh) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++)
+        for (int ks = 0; ks < KS; ks++)
 #pragma unroll
-            for (int ii = 0; ii < 4; ii++)
+            for (int ii = 0; ii < XF; ii++)
 #pragma unroll
-                for (int jj = 0; jj < 2; jj++)
-                    acc[mh * 4 + ii][nh * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nh][jj][ks], xf[ii][ks], acc[mh * 4 + ii][nh * 2 + jj], 0, 0, 0);
+                for (int jj = 0; jj < WF; jj++) {
+                    acc_t &a = acc[mh * XF + ii][nh * WF + jj];
+                    if constexpr (MF32) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nh][jj][ks], xf[ii][ks], a, 0, 0, 0);
+                    else a = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nh][jj][ks], xf[ii][ks], a, 0, 0, 0);
+                }
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -206,49 +218,59 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
     if (wr == 0) G8_BAR();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: no LDS-DMA may outlive the workgroup
 
-    // ---- epilogue: lane l holds, per (i, j), m = m0 + 128 wr + 16 i + l % 16 and four consecutive n starting at 4 (l / 16)
-    const int mloc = wr * 128 + (lane & 15);
-    const int n4 = (lane >> 4) * 4;
+    // ---- epilogue.  16x16: lane l holds, per (i, j), m = m0 + 128 wr + 16 i + l % 16 and four consecutive n starting at 4 (l / 16).
+    // 32x32: per (i, j) and register group rg = reg / 4: m = m0 + 128 wr + 32 i + l % 32, n starting at 8 rg + 4 (l / 32).
+    // Either way: one 8-byte store per four accumulators.
+    constexpr int NG = MF32 ? 4 : 1;                  // groups of four consecutive n per accumulator tile
+    const int mloc = wr * 128 + frow;
+    const int n4 = MF32 ? (lane >> 5) * 4 : (lane >> 4) * 4;
+    auto acc4 = [&](const acc_t &a, int rg, int r) -> float {
+        if constexpr (MF32) return a[4 * rg + r];
+        else return a[r];
+    };
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int m = m0 + mloc + i * 16;
+    for (int i = 0; i < AM; i++) {
+        const int m = m0 + mloc + i * RL;
         if (m >= M) continue;
         half_t *crow = p.c + (size_t)m * p.ldc;
-        if constexpr (PAIR) {
 #pragma unroll
-            for (int jj = 0; jj < 2; jj++) {
-                const int n = n0 + wc * 32 + jj * 16 + n4;
-                if (n >= N) continue;
-                half4_t h;
+        for (int rg = 0; rg < NG; rg++) {
+            if constexpr (PAIR) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float g = acc[i][jj][r], u = acc[i][2 + jj][r];
-                    h[r] = (half_t)(g * (1.0f / (1.0f + __expf(-g))) * u);   // SiLU on the fp32 accumulator (fused_mlp.py:160-165)
+                for (int jj = 0; jj < WF; jj++) {
+                    const int n = n0 + wc * 32 + jj * RL + (MF32 ? 8 * rg : 0) + n4;
+                    if (n >= N) continue;
+                    half4_t h;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float g = acc4(acc[i][jj], rg, r), u = acc4(acc[i][WF + jj], rg, r);
+                        h[r] = (half_t)(g * (1.0f / (1.0f + __expf(-g))) * u);   // SiLU on the fp32 accumulator (fused_mlp.py:160-165)
+                    }
+                    *(half4_t *)(crow + n) = h;
                 }
-                *(half4_t *)(crow + n) = h;
-            }
-        } else {
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int n = n0 + wc * 64 + (j >> 1) * 32 + (j & 1) * 16 + n4;
-                if (n >= N) continue;
-                half4_t h;
+                for (int j = 0; j < AN; j++) {
+                    const int n = n0 + wc * 64 + (j / WF) * 32 + (j % WF) * RL + (MF32 ? 8 * rg : 0) + n4;
+                    if (n >= N) continue;
+                    half4_t h;
 #pragma unroll
-                for (int r = 0; r < 4; r++) h[r] = (half_t)acc[i][j][r];
-                if (p.bias) {   // fp16(fp16(acc) + bias): the reference adds the bias to the rounded product (quant_linear.py:376)
-                    const half4_t bv = *(const half4_t *)(p.bias + n);
+                    for (int r = 0; r < 4; r++) h[r] = (half_t)acc4(acc[i][j], rg, r);
+                    if (p.bias) {   // fp16(fp16(acc) + bias): the reference adds the bias to the rounded product (quant_linear.py:376)
+                        const half4_t bv = *(const half4_t *)(p.bias + n);
 #pragma unroll
-                    for (int r = 0; r < 4; r++) h[r] = (half_t)((float)h[r] + (float)bv[r]);
+                        for (int r = 0; r < 4; r++) h[r] = (half_t)((float)h[r] + (float)bv[r]);
+                    }
+                    *(half4_t *)(crow + n) = h;
                 }
-                *(half4_t *)(crow + n) = h;
             }
         }
     }
 }
 
-template <bool PAIR>
+template <bool PAIR, bool MF32>
 int gemm8_launch(const Gemm8Params &p, hipStream_t s) {
-    auto kern = gemm8_kernel<PAIR>;
+    auto kern = gemm8_kernel<PAIR, MF32>;
     constexpr int lds = 2 * BUF_BYTES;   // 131 072 B
     static LdsOptIn opt_in;   // per instantiation; per device inside
     if (int rc = opt_in.ensure((const void *)kern, lds)) return rc;
@@ -256,6 +278,8 @@ int gemm8_launch(const Gemm8Params &p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(groups_of_8 * 8 * p.ntn), dim3(512), lds, s, p);
     return (int)hipGetLastError();
 }
+
+std::atomic<int> g_gemm8_mfma{16};   // MFMA shape of the tile GEMM: 16 = 16x16x32, 32 = 32x32x16 (gemm8_set_mfma: tests / A-B runs)
 
 }  // namespace
 
@@ -272,7 +296,10 @@ int gemm8_dense_f16(const half_t *x, int64_t ldx, const half_t *wt, int64_t ldw,
     p.M = M; p.K = K; p.N = N;
     p.ntm = (M + TM - 1) / TM;
     p.ntn = (N + (pair ? 128 : 256) - 1) / (pair ? 128 : 256);
-    return pair ? gemm8_launch<true>(p, s) : gemm8_launch<false>(p, s);
+    if (g_gemm8_mfma.load() == 32) return pair ? gemm8_launch<true, true>(p, s) : gemm8_launch<false, true>(p, s);
+    return pair ? gemm8_launch<true, false>(p, s) : gemm8_launch<false, false>(p, s);
 }
+
+int gemm8_set_mfma(int shape) { return (shape == 16 || shape == 32) ? g_gemm8_mfma.exchange(shape) : GPTQ_E_VARIANT; }
 
 }  // namespace gptq

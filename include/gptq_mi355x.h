@@ -86,6 +86,8 @@ int gptq_prefill_route_for(int M, int K, int N, int nsets, int trans);
 /* test hooks: make every library call answer GPTQ_E_LIBRARY as if hipBLASLt were not installed (returns the previous setting);
  * number of hipBLASLt plans currently cached (bounded LRU of 64) */
 int gptq_set_library_enabled(int on);
+/* MFMA shape of the tile GEMM (tests / A-B runs): 16 = v_mfma_f32_16x16x32_f16, 32 = v_mfma_f32_32x32x16_f16; returns the previous value */
+int gptq_set_gemm8_mfma(int shape);
 int gptq_prefill_plan_count(void);
 /* Development aid: when non-NULL, the decode kernels write per-wave s_memtime checkpoints
  * ([block][wave][8] uint64) into this device buffer.  Returns the previous pointer. */

@@ -169,9 +169,13 @@ def perf():
 
 
 if __name__ == '__main__':
-    t = time.time()
-    good = check()
-    print('correctness: %s (%.1f s)' % ('ALL OK' if good else 'FAILURES', time.time() - t))
-    if good or os.environ.get('FORCE_PERF'):
-        perf()
+    for shape in (int(v) for v in os.environ.get('MFMA', '16,32').split(',')):
+        prev = lib.gptq_set_gemm8_mfma(shape)
+        print('######## tile GEMM on v_mfma_f32_%s_f16 ########' % ('16x16x32' if shape == 16 else '32x32x16'))
+        t = time.time()
+        good = check()
+        print('correctness: %s (%.1f s)' % ('ALL OK' if good else 'FAILURES', time.time() - t))
+        if good or os.environ.get('FORCE_PERF'):
+            perf()
+        lib.gptq_set_gemm8_mfma(prev)
     lib.gptq_set_prefill_route(1)

@@ -1,18 +1,29 @@
+# one gpurun call: tests, smoke, bench, rocprofv3 kernel stats, PMC traffic, PMC counters of the prefill tile GEMM, decode engine profile
 set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r2f}; mkdir -p $O
-timeout 700 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt
+O=gpurun_out/${1:-r3f}; mkdir -p $O
+if [ -z "$SKIP_TESTS" ]; then
+timeout 500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -6 $O/pytest_gpu.txt
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
-timeout 900 python bench.py > $O/bench.json.txt 2> $O/bench.err; tail -c 600 $O/bench.json.txt
+timeout 900 python bench.py > $O/bench.json.txt 2> $O/bench.err; tail -c 400 $O/bench.json.txt
+fi
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-decode --no-cpu-baseline --no-per-shape --no-prefill --no-config4 --no-small-batch > $GRAFT_REPO_ROOT/$O/prof_bench.txt 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $GRAFT_REPO_ROOT/$O/pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --eager --no-decode --no-cpu-baseline --no-per-shape --no-prefill --no-config4 --no-small-batch > $GRAFT_REPO_ROOT/$O/pmc_bench.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$O/prof_engine -- python $GRAFT_REPO_ROOT/tools/profile_engine.py > $GRAFT_REPO_ROOT/$O/prof_engine.txt 2>&1
-cd $GRAFT_REPO_ROOT
-ST=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp "$ST" $O/kernel_stats.csv; head -5 $O/kernel_stats.csv
-ST=$(find $O/prof_engine -name "*kernel_stats.csv" | head -1); cp "$ST" $O/decode_engine_kernel_stats.csv; head -12 $O/decode_engine_kernel_stats.csv
-CC=$(find $O/pmc -name "*counter_collection.csv" | head -1); python tools/pmc_traffic.py "$CC" $O/traffic.json | tail -5
-MS=8,16,32,64,128 timeout 300 python tools/bench_stripe_mm.py 2>&1 | grep -v amdgpu.ids > $O/stripe_mm_4bit.txt
-BITS=8 MS=16,64 timeout 200 python tools/bench_stripe_mm.py 2>&1 | grep -v amdgpu.ids > $O/stripe_mm_8bit.txt
-for sp in 0 500 1500; do timeout 200 python tools/profile_engine.py --start $sp 2>&1 | grep -o "{.*}" | tail -1; done > $O/engine_context.txt
-rm -rf $O/prof $O/pmc $O/prof_engine
+R=$GRAFT_REPO_ROOT
+if [ -z "$SKIP_TESTS" ]; then
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/prof -- python $R/bench.py --steps 5 --warmup 1 --no-decode --no-cpu-baseline --no-per-shape --no-prefill --no-config4 --no-small-batch > $R/$O/prof_bench.txt 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $R/$O/pmc -- python $R/bench.py --steps 2 --warmup 1 --eager --no-decode --no-cpu-baseline --no-per-shape --no-prefill --no-config4 --no-small-batch > $R/$O/pmc_bench.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/prof_engine -- python $R/tools/profile_engine.py > $R/$O/prof_engine.txt 2>&1
+fi
+timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/prof_gemm -- python $R/tools/run_prefill_once.py 16384 > $R/$O/prof_gemm.txt 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace -f csv -d $R/$O/pmc_gemm1 -- python $R/tools/run_prefill_once.py 16384 > $R/$O/pmc_gemm1.txt 2>&1
+timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU --kernel-trace -f csv -d $R/$O/pmc_gemm2 -- python $R/tools/run_prefill_once.py 16384 > $R/$O/pmc_gemm2.txt 2>&1
+cd $R
+if [ -z "$SKIP_TESTS" ]; then
+ST=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp "$ST" $O/kernel_stats.csv
+ST=$(find $O/prof_engine -name "*kernel_stats.csv" | head -1); cp "$ST" $O/decode_engine_kernel_stats.csv
+CC=$(find $O/pmc -name "*counter_collection.csv" | head -1); python tools/pmc_traffic.py "$CC" $O/traffic.json | tail -4
+fi
+ST=$(find $O/prof_gemm -name "*kernel_stats.csv" | head -1); cp "$ST" $O/prefill_kernel_stats.csv; cut -c1-150 $O/prefill_kernel_stats.csv | head -6
+C1=$(find $O/pmc_gemm1 -name "*counter_collection.csv" | head -1); C2=$(find $O/pmc_gemm2 -name "*counter_collection.csv" | head -1); python tools/pmc_gemm.py $O/gemm8_pmc.json "$C1" "$C2" | tail -30
+tail -3 $O/pmc_gemm1.txt
+rm -rf $O/prof $O/pmc $O/prof_engine $O/prof_gemm $O/pmc_gemm1 $O/pmc_gemm2

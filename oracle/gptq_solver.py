@@ -58,6 +58,22 @@ def quantize(x, scale, zero, maxq):
     return (scale * (level - zero)).astype(F)
 
 
+def inverse_factor(H, percdamp):
+    """damped Hessian -> upper Cholesky factor of its inverse (reference gptq.py:157-163), LAPACK fp32 like torch on the CPU."""
+    H = np.array(H, dtype=F, copy=True)
+    cols = H.shape[0]
+    damp = F(percdamp) * np.mean(np.diag(H), dtype=F)
+    H[np.arange(cols), np.arange(cols)] += damp
+    L, info = lapack.spotrf(H, lower=1)
+    assert info == 0, 'Hessian not positive definite'
+    Hi, info = lapack.spotri(L, lower=1)
+    assert info == 0
+    Hi = np.tril(Hi) + np.tril(Hi, -1).T                      # potri fills one triangle
+    U, info = lapack.spotrf(Hi, lower=0)
+    assert info == 0
+    return np.triu(U).astype(F)
+
+
 def fasterquant(W, H, bits, blocksize=128, percdamp=0.01, groupsize=-1, actorder=False, sym=False):
     """W [rows, cols] fp32 (nn.Linear.weight), H [cols, cols] fp32.  Returns Q (fp32, same shape, original column
     order), scale [rows, groups], zero [rows, groups], g_idx [cols] int32, error (float)."""
@@ -76,16 +92,7 @@ def fasterquant(W, H, bits, blocksize=128, percdamp=0.01, groupsize=-1, actorder
         W = W[:, perm]
         H = H[perm][:, perm]
 
-    damp = F(percdamp) * np.mean(np.diag(H), dtype=F)
-    H[np.arange(cols), np.arange(cols)] += damp
-    L, info = lapack.spotrf(H, lower=1)
-    assert info == 0, 'Hessian not positive definite'
-    Hi, info = lapack.spotri(L, lower=1)
-    assert info == 0
-    Hi = np.tril(Hi) + np.tril(Hi, -1).T                      # potri fills one triangle
-    U, info = lapack.spotrf(Hi, lower=0)
-    assert info == 0
-    Hinv = np.triu(U).astype(F)
+    Hinv = inverse_factor(H, percdamp)
 
     Q = np.zeros_like(W)
     loss_total = 0.0

@@ -20,8 +20,11 @@ GOLDEN_DIR = os.path.join(ROOT_DIR, 'tests', 'golden')
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-TWIN_TOL = 1.2e-2    # logits of a 2-layer model vs its dense fp16 twin with STOCK HF norm / RoPE numerics (observed 0.9e-3 .. 6.3e-3)
-ENGINE_TOL = 5e-3    # DecodeEngine vs the module chain on the same drop-in modules (observed 6e-4 .. 1.8e-3); was 2e-2 for both in round 1
+# model-level bars = 1.5 x the maxima observed on the MI355X (GPTQ_TEST_ERRLOG=<file> logs every `within` call; profiles/r3f_final/model_test_errors.txt)
+TWIN_TOL = 1.2e-2    # logits of a 2-layer model vs its dense fp16 twin with STOCK HF norm / RoPE numerics (observed 0.9e-3 .. 8.7e-3; 9.5e-3 at batch 40)
+TWIN_TOL_100 = 2.5e-2  # the same at batch 100 (observed 1.65e-2: the maximum runs over 100 x vocab x steps logits, the fp16 twin itself moves that much)
+ENGINE_TOL = 2.7e-3  # DecodeEngine vs the module chain on the same drop-in modules (observed 4e-4 .. 1.8e-3); was 5e-3 in round 2, 2e-2 in round 1
+HOOK_TOL = 2e-2      # generate() / model(...) through the engine hook vs the eager chain, up to 48 tokens deep (fp16 KV cache on both sides)
 TINY = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
             vocab_size=512, max_position_embeddings=128)
 
@@ -99,7 +102,7 @@ def test_tiny_llama_batched_decode_matches_dense_twin(batch):
     # the maximum runs over batch x vocab x steps logits of a random two-layer model: at batch 100 the fp16 twin itself sits 0.9-2.4e-2
     # from its own fp32 copy (measured), so the bound there is the model's fp16 noise, not a kernel tolerance (per-op parity at
     # these M: test_stripe_mm_vs_oracle / test_stripe_mm_fused_mlp, 1e-3 / 2e-3 against the oracle)
-    within('twin_batched_%d' % batch, np.abs(a - c).max() / scale, TWIN_TOL if batch <= 40 else 2.5e-2)
+    within('twin_batched_%d' % batch, np.abs(a - c).max() / scale, TWIN_TOL if batch <= 40 else TWIN_TOL_100)
 
 
 def test_benchmark_decode_protocol_runs():
@@ -352,8 +355,46 @@ def test_gpu_gptq_solver_vs_reference_gptq(name):
     assert np.mean(zero != f['zero']) < 2e-3
     assert np.max(np.abs(scale - f['scale']) / f['scale']) < 1e-4
     mism = np.mean(_levels(Q, scale, zero, g_idx) != _levels(f['Q'], f['scale'], f['zero'], f['g_idx']))
-    assert mism < 5e-3, mism                                                     # rocSOLVER/hipBLASLt vs LAPACK: rounding ties only
+    # not bit-exact: rocSOLVER's factorisation and the trailing-update GEMM sum in another order than LAPACK / OpenBLAS; the block kernel itself
+    # is (test_gpu_solver_block_kernel_is_bit_exact_given_the_reference_inverse_factor)
+    assert mism < 5e-3, mism
     assert abs(err - float(f['error'])) / float(f['error']) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,cols,bits,gs,act,sym', [(256, 128, 4, 32, False, False), (192, 128, 4, -1, False, False), (128, 128, 3, 64, True, False),
+                                                        (320, 96, 2, 32, False, True), (64, 128, 8, 128, True, False), (512, 64, 4, 16, False, False)])
+def test_gpu_solver_block_kernel_is_bit_exact_given_the_reference_inverse_factor(monkeypatch, rows, cols, bits, gs, act, sym):
+    """Where the < 0.5 % of flipped levels in the tests around this one come from: NOT from the block kernel.  With the Hessian and
+    the inverse factor taken from the host (LAPACK, what the reference's CPU run computes) and ONE block (no trailing GEMM), the
+    column loop of csrc/gptq_solver.hip -- quantise, error, in-block update (reference gptq.py:171-202) -- reproduces the restatement's
+    integer levels, grids and dequantised weights BIT FOR BIT.  What is left in the multi-block tests is the summation order of
+    rocSOLVER's factorisation and of the trailing-update GEMM against LAPACK / OpenBLAS -- arithmetic the reference itself does not pin
+    (its own results move with the BLAS build)."""
+    import gptq as product_gptq
+    from oracle import gptq_solver as G
+    rng = np.random.default_rng(rows * 7 + cols + bits)
+    W = (rng.standard_normal((rows, cols)) * 0.05).astype(np.float32)
+    mix = (rng.standard_normal((cols, cols)) * 0.1 + np.eye(cols)).astype(np.float32)
+    X = (rng.standard_normal((512, cols)).astype(np.float32) @ mix) * np.exp(rng.standard_normal(cols) * 0.5).astype(np.float32)
+    H = np.zeros((cols, cols), np.float32)
+    H, n = G.hessian_add_batch(H, 0, X[None])
+    monkeypatch.setattr(product_gptq, '_inverse_factor',
+                        lambda hess, percdamp: torch.from_numpy(G.inverse_factor(hess.cpu().numpy(), percdamp)).to(hess.device).contiguous())
+    layer = torch.nn.Linear(cols, rows, bias=False)
+    layer.weight.data = torch.from_numpy(W).clone()
+    layer = layer.to(DEV)
+    g = product_gptq.GPTQ(layer)
+    g.quantizer.configure(bits, perchannel=True, sym=sym, mse=False)
+    g.H, g.nsamples = torch.from_numpy(H).to(DEV), n
+    scale, zero, g_idx, err = g.fasterquant(blocksize=128, percdamp=0.01, groupsize=gs, actorder=act, name='t')
+    Q = layer.weight.data.float().cpu().numpy()
+    Qo, so, zo, go, eo = G.fasterquant(W, H, bits, 128, 0.01, gs, act, sym)
+    assert np.array_equal(g_idx.cpu().numpy(), go)
+    assert np.array_equal(scale.cpu().numpy(), so) and np.array_equal(zero.cpu().numpy(), zo)
+    assert np.array_equal(Q, Qo), ('dequantised weights differ in', int((Q != Qo).sum()), 'of', Q.size)
+    assert np.array_equal(_levels(Q, so, zo, go), _levels(Qo, so, zo, go))
+    assert abs(err - eo) / eo < 1e-5          # the loss is a sum over rows: order only
 
 
 @pytest.mark.gpu
@@ -420,10 +461,10 @@ def test_generate_goes_through_the_decode_engine_and_matches_the_module_chain():
     assert engine_steps(model) == n - 1                                       # every step after the prefill
     compared = 0
     for i in range(n):
-        assert np.abs(log_h[i] - log_e[i]).max() < 2e-2 * max(1.0, np.abs(log_e[i]).max())
+        within('hook_generate_step', np.abs(log_h[i] - log_e[i]).max() / max(1.0, np.abs(log_e[i]).max()), HOOK_TOL)
         if tok_e[i] != tok_h[i]:
             top2 = np.sort(log_e[i])[-2:]
-            assert top2[1] - top2[0] < 2e-2 * max(1.0, np.abs(log_e[i]).max()), 'engine token differs at a step with a clear winner'
+            assert top2[1] - top2[0] < HOOK_TOL * max(1.0, np.abs(log_e[i]).max()), 'engine token differs at a step with a clear winner'
             break
         compared += 1
     assert compared >= 32, compared
@@ -475,7 +516,7 @@ def test_engine_hook_keeps_the_callers_cache_consistent():
     ref, len_e = run(False)
     got, len_h = run(True)
     assert len_e == 18 and len_h >= 17          # the last engine token may still be engine-only (it is synced on demand)
-    assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
+    within('hook_forward_mixed', np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), HOOK_TOL)
 
 
 def test_generate_hands_back_a_complete_cache_and_can_be_continued():

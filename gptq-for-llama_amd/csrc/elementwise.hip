@@ -328,53 +328,69 @@ __global__ void __launch_bounds__(256) dequant4_fast_kernel(const uint32_t *__re
 
 // The same weight TRANSPOSED: Wt[n][k] (k contiguous, row stride ldo >= K) -- the operand layout of the hand-written prefill GEMM
 // (gemm8.hip: both operands by LDS-DMA, a fragment = 16 contiguous bytes of one row).  Identical arithmetic, element for element.
-// A thread owns one column and one 32-k block: its BITS packed words are read coalesced across the workgroup, its 32 values leave
-// as four 16-byte stores (one full 64-byte sector of its row).
-template <int BITS, bool UNIFORM>   // UNIFORM: trivial g_idx and groupsize % 32 == 0 -> one (scale, zero) per thread
+// Workgroup tile: 64 columns x 256 k.  A thread owns one column and two of the tile's eight 32-k blocks: its BITS packed words per
+// block are read coalesced across the 64 columns, its 32 values go to LDS as row n of the transposed tile; the tile then leaves as
+// full 512-byte row segments (32 lanes x 16 B per row: whole 128-byte lines).  The first version stored straight from registers --
+// 64 rows x 16 B per wave store -- and ran at 1.7 TB/s (20.6 us for a 4096^2 layer, profiles/r3f_final/prefill_kernel_stats.csv).
+constexpr int DQT_COLS = 64, DQT_K = 256, DQT_PITCH = DQT_K + 8;   // halves; 16 bytes of padding per LDS row
+template <int BITS, bool UNIFORM>   // UNIFORM: trivial g_idx and groupsize % 32 == 0 -> one (scale, zero) per thread and block
 __global__ void __launch_bounds__(256) dequant_t_kernel(const uint32_t *__restrict__ qw, const half_t *__restrict__ sc,
                                                         const int32_t *__restrict__ qz, const int32_t *__restrict__ gi, int K, int N,
                                                         int G, int groupsize, half_t *__restrict__ out, int64_t ldo) {
-    const int blk = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ __attribute__((aligned(16))) half_t tile[DQT_COLS * DQT_PITCH];
+    const int tid = threadIdx.x, c = tid & 63, n = blockIdx.x * DQT_COLS + c, k0 = blockIdx.y * DQT_K;
     const int ldz = N / 32 * BITS;
-    uint32_t col[BITS];
 #pragma unroll
-    for (int i = 0; i < BITS; i++) col[i] = qw[((size_t)blk * BITS + i) * N + n];
-    int g_prev = -1;
-    half_t s = (half_t)0, z = (half_t)0;
-    half_t v[32];
-    if constexpr (UNIFORM) {
-        const int g = (blk * 32) / groupsize;
-        g_prev = g;
-        s = sc[(size_t)g * N + n];
-        z = (half_t)(float)zero_of<BITS>(qz + (size_t)g * ldz, n);
-    }
+    for (int h = 0; h < 2; h++) {
+        const int b32 = (tid >> 6) + 4 * h, blk = k0 / 32 + b32;   // 32-k block inside the tile / inside the layer
+        if (n >= N || blk * 32 >= K) continue;
+        uint32_t col[BITS];
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-        const int k = blk * 32 + j;
-        int g = g_prev;
-        if constexpr (!UNIFORM) {
-            g = gi ? gi[k] : k / groupsize;
-            g = (g < 0 || g >= G) ? 0 : g;
-        }
-        if (g != g_prev) {
+        for (int i = 0; i < BITS; i++) col[i] = qw[((size_t)blk * BITS + i) * N + n];
+        int g_prev = -1;
+        half_t s = (half_t)0, z = (half_t)0;
+        half_t v[32];
+        if constexpr (UNIFORM) {
+            const int g = (blk * 32) / groupsize;
             g_prev = g;
             s = sc[(size_t)g * N + n];
             z = (half_t)(float)zero_of<BITS>(qz + (size_t)g * ldz, n);
         }
-        const int q = field_of_block<BITS>(col, j);
-        v[j] = (half_t)((half_t)(float)q - z) * s;
-    }
-    half_t *dst = out + (size_t)n * ldo + (size_t)blk * 32;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-        *(half8_t *)(dst + 8 * i) = half8_t{v[8 * i], v[8 * i + 1], v[8 * i + 2], v[8 * i + 3], v[8 * i + 4], v[8 * i + 5], v[8 * i + 6], v[8 * i + 7]};
+        for (int j = 0; j < 32; j++) {
+            const int k = blk * 32 + j;
+            int g = g_prev;
+            if constexpr (!UNIFORM) {
+                g = gi ? gi[k] : k / groupsize;
+                g = (g < 0 || g >= G) ? 0 : g;
+            }
+            if (g != g_prev) {
+                g_prev = g;
+                s = sc[(size_t)g * N + n];
+                z = (half_t)(float)zero_of<BITS>(qz + (size_t)g * ldz, n);
+            }
+            const int q = field_of_block<BITS>(col, j);
+            v[j] = (half_t)((half_t)(float)q - z) * s;
+        }
+        half_t *dst = tile + c * DQT_PITCH + b32 * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            *(half8_t *)(dst + 8 * i) = half8_t{v[8 * i], v[8 * i + 1], v[8 * i + 2], v[8 * i + 3], v[8 * i + 4], v[8 * i + 5], v[8 * i + 6], v[8 * i + 7]};
+    }
+    __syncthreads();
+    // 64 rows x 32 pieces of 16 bytes; thread t: piece t % 32 of rows t / 32 + 8 i
+    const int pc = tid & 31;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int r = (tid >> 5) + 8 * i, nn = blockIdx.x * DQT_COLS + r, k = k0 + pc * 8;
+        if (nn < N && k < K) *(half8_t *)(out + (size_t)nn * ldo + k) = *(const half8_t *)(tile + r * DQT_PITCH + pc * 8);
+    }
 }
 
 int dequant_t_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, const int32_t *gi, int K, int N, int G, int groupsize,
                      int bits, half_t *out, int64_t ldo, hipStream_t s) {
     if (ldo % 8 != 0 || ((uintptr_t)out % 16) != 0) return GPTQ_E_ALIGN;
-    dim3 grid((N + 255) / 256, K / 32), block(256);
+    dim3 grid((N + DQT_COLS - 1) / DQT_COLS, (K + DQT_K - 1) / DQT_K), block(256);
     const bool uni = !gi && groupsize % 32 == 0;
 #define GPTQ_DQT(B)                                                                                                                  \
     if (uni) hipLaunchKernelGGL((dequant_t_kernel<B, true>), grid, block, 0, s, qw, sc, qz, gi, K, N, G, groupsize, out, ldo);      \

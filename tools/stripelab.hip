@@ -623,12 +623,16 @@ struct WSet { uint32_t *R; uint32_t *tab; };
 
 static float time_graph(launch_fn fn, SP base, const std::vector<WSet> &sets, hipStream_t s, int reps) {
     hipGraph_t g; hipGraphExec_t ge;
-    CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
     static const bool freshx = getenv("LAB_FRESHX") != nullptr;   // x rewritten by a producer launch before every kernel (as in a real decode chain)
+    static const int freshx_mode = freshx ? atoi(getenv("LAB_FRESHX")) : 0;
+    static half_t *dummy_x = nullptr;
+    if (freshx && !dummy_x) CK(hipMalloc(&dummy_x, 65536 * 2));
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
     int it = 0;
     for (auto &w : sets) {
         SP p = base; p.R = w.R; p.tab = w.tab;
-        if (freshx) hipLaunchKernelGGL(fill_x, dim3(64), dim3(256), 0, s, (half_t *)base.x, (size_t)base.K, 77u + (it++ % 2));
+        // LAB_FRESHX=1: x itself is rewritten; LAB_FRESHX=2 (control): the same producer launch writes a buffer nobody reads
+        if (freshx) hipLaunchKernelGGL(fill_x, dim3(64), dim3(256), 0, s, freshx_mode == 2 ? dummy_x : (half_t *)base.x, (size_t)base.K, 77u + (it++ % 2));
         fn(p, s);
     }
     CK(hipStreamEndCapture(s, &g));

@@ -589,6 +589,7 @@ int gptq_dequant_ld_f16(const int32_t *qweight, const void *scales, const int32_
 // route 1 (default) = the hand-written GEMM of gemm8.hip on the transposed dequantised weight; route 0 = hipBLASLt on the
 // dequantised weight (the reported ceiling; also the fallback for shapes gemm8 does not serve: K % 128 != 0 ...).
 static std::atomic<int> g_prefill_route{1};
+std::atomic<int> g_stripe_mm_pass_rows{128};   // rows per pass of the 16-row MFMA tiles: 128, or 64 (round 2's schedule: A/B runs)
 namespace {
 // The tile GEMM works in 256 x 256 (pair: 256 x 128) output tiles, one per CU at a time: below one full round of tiles (or a
 // couple of thousand rows) a launch costs a whole tile's latency however small the batch, and the library's smaller tiles win
@@ -721,6 +722,11 @@ int gptq_prefill_plan_count(void) { return dense_gemm_plan_count(); }
 int gptq_set_prefill_route(int route) {
     if (route < 0 || route > 2) return GPTQ_E_VARIANT;
     return g_prefill_route.exchange(route);
+}
+
+int gptq_set_stripe_mm_pass_rows(int rows) {
+    if (rows != 64 && rows != 128) return GPTQ_E_VARIANT;
+    return g_stripe_mm_pass_rows.exchange(rows);
 }
 
 int gptq_silu_mul_f16(const void *gate, int64_t ldg, const void *up, int64_t ldu, void *c, int64_t ldc, int M, int N, gptq_stream_t stream) {
@@ -895,20 +901,30 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.NS = nsets;
     p.gq_shift = gq;
     p.bits = bits;
-    if (mm_ws) {   // row tiles on the matrix core (stripe_mm.inc): passes of up to 64 rows, each streams the weights once
+    if (mm_ws) {   // row tiles on the matrix core (stripe_mm.inc): passes of up to 128 rows (64 when the partial tiles of a 128-row pass
+                   // do not fit the scratch, or with gptq_set_stripe_mm_pass_rows(64)), each streams the weights once
         const int forced = g_force_split_k.load();
-        for (int m0 = 0; m0 < M; m0 += 64) {
+        auto pass = [&](int m0, int rows) {
             p.x = (const half_t *)x + (size_t)m0 * ldx;
             p.y = (half_t *)y + (size_t)m0 * ldy;
-            p.M = std::min(64, M - m0);
-            int rc;
+            p.M = rows;
             switch (bits) {
-                case 2: rc = stripe_mm_dispatch_b2(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream); break;
-                case 3: rc = stripe_mm_dispatch_b3(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream); break;
-                case 4: rc = stripe_mm_dispatch_b4(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream); break;
-                default: rc = stripe_mm_dispatch_b8(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream); break;
+                case 2: return stripe_mm_dispatch_b2(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
+                case 3: return stripe_mm_dispatch_b3(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
+                case 4: return stripe_mm_dispatch_b4(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
+                default: return stripe_mm_dispatch_b8(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
+            }
+        };
+        const int pass_rows = g_stripe_mm_pass_rows.load();
+        for (int m0 = 0; m0 < M;) {
+            int rows = std::min(pass_rows, M - m0);
+            int rc = pass(m0, rows);
+            if (rc == GPTQ_E_WORKSPACE && rows > 64) {   // nothing was launched: the same rows in 64-row passes
+                rows = 64;
+                rc = pass(m0, rows);
             }
             if (rc != 0) return rc;
+            m0 += rows;
         }
         return 0;
     }

@@ -80,6 +80,9 @@ int gptq_set_gemm_kernel(int version);
  * on par (M >= 2048 and one full round of 256 x 256 tiles), hipBLASLt below that; 2 = the tile GEMM wherever it can run
  * (K % 128 == 0); 0 = hipBLASLt only (the reported ceiling).  Returns the previous value. */
 int gptq_set_prefill_route(int route);
+/* Rows per pass of the 16-row MFMA tiles on the stripe16 image (gptq_stripe_matmul_f16, the 5..128-row route of gptq_layer_forward):
+ * 128 (default: 65..128 rows in ONE pass over the weights) or 64 (round 2's schedule; A-B runs).  Returns the previous value. */
+int gptq_set_stripe_mm_pass_rows(int rows);
 /* which engine a dense product of this shape takes under the current switch: 1 = tile GEMM, 0 = hipBLASLt (host logic only;
  * nsets = 2: gate/up pair; trans = 1: the backward product) */
 int gptq_prefill_route_for(int M, int K, int N, int nsets, int trans);

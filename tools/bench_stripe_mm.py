@@ -9,6 +9,8 @@ from bench import alg_bytes, GS
 from quant import _native, quant_linear as QL
 dev = 'cuda:0'; lib = _native.lib(); ws = _native.workspace(torch.device(dev))
 gen = torch.Generator(device=dev); gen.manual_seed(0)
+if os.environ.get('PASS_ROWS'):      # 64 = round 2's schedule (two passes for 65..128 rows), 128 = one pass with six / eight row tiles
+    lib.gptq_set_stripe_mm_pass_rows(int(os.environ['PASS_ROWS']))
 MS = [int(v) for v in os.environ.get('MS', '1,4,5,8,16,17,32,48,64').split(',')]
 BITS = int(os.environ.get('BITS', '4'))
 SKS = [-1] + [int(v) for v in os.environ.get('SKS', '').split(',') if v]

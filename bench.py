@@ -6,7 +6,7 @@ One "step" = one batch-1 decode pass over ALL quantised linears of a LLaMA-7B-sh
 down_proj 11008x4096], 4-bit, groupsize 128; synthetic random-init packed weights),
 issued through the C ABI (include/gptq_mi355x.h) exactly as the drop-in modules issue it after
 make_quant_attn / make_fused_mlp: 4 launches per layer, 128 per step, 3.37 GB of distinct
-weights per step (> the 256 MiB Infinity Cache, so every step streams from HBM).
+weights per step (> the 256 MiB Infinity Cache, so every step streams from HBM),
 issued through the C ABI exactly as the drop-in modules issue it: gptq_layer_forward on handles prepared once at load time
 (gptq_layer_prepare builds the stripe16 image from the checkpoint buffers; --kernel rowwave = the split-K kernels on the
 checkpoint layout, for A/B runs).  The step is captured once into a hipGraph and replayed; inputs are resident in HBM.
@@ -15,12 +15,13 @@ value      = algorithmic GB/s of the whole job (SURVEY 8(d) byte model), all ran
 roofline   = the GEMV kernel family against the 8 TB/s HBM3E spec peak.
 cpu_baseline = the C/OpenMP oracle (oracle/gptq_oracle.c, a port of the reference kernel
              arithmetic) on the host cores, on a bounded sample of the same workload.
---gpus N   = N data-parallel replicas (one process per GPU, no data-path collective; weak scaling) -- the default, = --dp.
---gpus N --tp row|megatron = BASELINE config 5: LLaMA-65B-shaped decode linears sharded over the N ranks (strong scaling):
-             'row' K-shards every linear on group boundaries with ONE fp32 all-reduce per linear (north_star's layout),
-             'megatron' N-shards qkv / gate / up and K-shards o / down (2 all-reduces per layer).  RCCL over xGMI; the
-             collectives are captured into the hipGraph.  quant/tensor_parallel.py is the module-level counterpart
-             (world_size-2 gloo tests).
+--gpus 1   = the BASELINE configs[1] pass above (the headline line).
+--gpus N>1 = BASELINE config 5 (north_star's multi-GPU mode), the default since round 3: `--tp row --allreduce rccl` -- LLaMA-65B-shaped
+             decode linears K-sharded over the N ranks on group boundaries, ONE fp32 all-reduce per linear (RCCL over xGMI, captured into
+             the hipGraph), strong scaling; the N-replica figure of the 7B pass (weak scaling, no collective; `--dp` makes it the line)
+             rides along as `replicas_reported_only`.  `--tp megatron` N-shards qkv / gate / up and K-shards o / down (2 all-reduces
+             per layer); `--allreduce p2p` is the one-shot exchange over IPC peer mappings (csrc/p2p.hip).  quant/tensor_parallel.py is
+             the module-level counterpart (world_size-2 gloo tests).
 """
 import argparse
 import json
@@ -697,6 +698,7 @@ def main():
                 pass
             torch.cuda.synchronize()
     run = graph.replay if graph is not None else work.step
+    launch_mode = 'hipGraph replay' if graph is not None else 'eager'
 
     for _ in range(args.warmup):
         run()
@@ -782,7 +784,7 @@ def main():
                            'backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if distributed else 'none',
                            'collective': ('one-shot push + local sum over IPC peer mappings (gptq_p2p_allreduce_f32), fp32' if work.p2p is not None
                                           else 'torch.distributed.all_reduce (RCCL over xGMI), fp32'),
-                           'collectives_per_step': work.collectives_per_step, 'launch_mode': 'hipGraph replay' if graph is not None else 'eager',
+                           'collectives_per_step': work.collectives_per_step, 'launch_mode': launch_mode,
                            'algorithmic_bytes_per_step': work.bytes_per_step},
                 'allreduce_us': tp_lat,
                 'replicas_reported_only': replicas,

@@ -589,7 +589,10 @@ int gptq_dequant_ld_f16(const int32_t *qweight, const void *scales, const int32_
 // route 1 (default) = the hand-written GEMM of gemm8.hip on the transposed dequantised weight; route 0 = hipBLASLt on the
 // dequantised weight (the reported ceiling; also the fallback for shapes gemm8 does not serve: K % 128 != 0 ...).
 static std::atomic<int> g_prefill_route{1};
-std::atomic<int> g_stripe_mm_pass_rows{128};   // rows per pass of the 16-row MFMA tiles: 128, or 64 (round 2's schedule: A/B runs)
+std::atomic<int> g_stripe_mm_pass_rows{128};
+// batches of 129 .. this many rows run the fused tile GEMM on the stripe16 image (0: never).  Measured crossover against the dense route
+// (tools/bench_mid_prefill.py, profiles/r3g_mid_m/mid_prefill.txt): 1.03-1.70x up to 1024 rows, 0.85-0.95x at 2048
+std::atomic<int> g_stripe_gemm_max_rows{1024};   // rows per pass of the 16-row MFMA tiles: 128, or 64 (round 2's schedule: A/B runs)
 namespace {
 // The tile GEMM works in 256 x 256 (pair: 256 x 128) output tiles, one per CU at a time: below one full round of tiles (or a
 // couple of thousand rows) a launch costs a whole tile's latency however small the batch, and the library's smaller tiles win
@@ -722,6 +725,11 @@ int gptq_prefill_plan_count(void) { return dense_gemm_plan_count(); }
 int gptq_set_prefill_route(int route) {
     if (route < 0 || route > 2) return GPTQ_E_VARIANT;
     return g_prefill_route.exchange(route);
+}
+
+int gptq_set_stripe_gemm_max_rows(int rows) {
+    if (rows < 0) return GPTQ_E_VARIANT;
+    return g_stripe_gemm_max_rows.exchange(rows);
 }
 
 int gptq_set_stripe_mm_pass_rows(int rows) {
@@ -870,12 +878,14 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
 
 static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, float *y32,
                          int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
-                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0) {
+                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
     const int gq = stripe_gq_shift(K, N, bits, groupsize);
-    if (gq == -2 || M > (mm_ws ? 256 : 16) || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
+    const int gemm_max = g_stripe_gemm_max_rows.load();
+    const bool gemm_rows = mm_ws && M > 128 && M <= gemm_max;
+    if (gq == -2 || (M > (mm_ws ? 256 : 16) && !gemm_rows) || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
     if (M > 1 && (norm_weight || perm || y32)) return GPTQ_E_VARIANT;
     if (stripes_bytes < stripe_total_bytes(K, N, bits, groupsize, nsets)) return GPTQ_E_WORKSPACE;
     if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || !aligned(y32, 4) || (norm_weight && !aligned(norm_weight, 16)) ||
@@ -901,6 +911,17 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.NS = nsets;
     p.gq_shift = gq;
     p.bits = bits;
+    if (gemm_rows) {   // 2-D tiles, weights kept packed (stripe_gemm_kernel)
+        int rc;
+        switch (bits) {
+            case 2: rc = stripe_gemm_dispatch_b2(p, (hipStream_t)stream); break;
+            case 3: rc = stripe_gemm_dispatch_b3(p, (hipStream_t)stream); break;
+            case 4: rc = stripe_gemm_dispatch_b4(p, (hipStream_t)stream); break;
+            default: rc = stripe_gemm_dispatch_b8(p, (hipStream_t)stream); break;
+        }
+        if (rc != GPTQ_E_VARIANT) return rc;
+    }
+    if (mm_ws && M > 128 && (gemm_only_above_128 || M > 256)) return GPTQ_E_VARIANT;
     if (mm_ws) {   // row tiles on the matrix core (stripe_mm.inc): passes of up to 128 rows (64 when the partial tiles of a 128-row pass
                    // do not fit the scratch, or with gptq_set_stripe_mm_pass_rows(64)), each streams the weights once
         const int forced = g_force_split_k.load();
@@ -1184,9 +1205,9 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
             const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream);
             if (rc != GPTQ_E_VARIANT) return rc;
         }
-        if (M > 4 && M <= LAYER_STRIPE_MM_MAX_M) {
+        if (M > 4 && M <= std::max(LAYER_STRIPE_MM_MAX_M, g_stripe_gemm_max_rows.load())) {   // ... 128 rows: 16-row tiles; above: the fused tile GEMM
             const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, mm_ws,
-                                         STRIPE_MM_WS_BYTES);
+                                         STRIPE_MM_WS_BYTES, true);
             if (rc != GPTQ_E_VARIANT) return rc;
         }
     }
@@ -1194,7 +1215,7 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
         if (M == 1) {   // the decode kernel gathers x through the permutation itself
             const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, 1, K, N, bits, gs, ns, nullptr, 0.f, L.perm16, stream);
             if (rc != GPTQ_E_VARIANT) return rc;
-        } else if (M <= LAYER_STRIPE_MM_MAX_M && scratch && aligned(scratch, 16) && scratch_bytes >= (size_t)M * K * 2) {
+        } else if (M <= std::max(LAYER_STRIPE_MM_MAX_M, g_stripe_gemm_max_rows.load()) && scratch && aligned(scratch, 16) && scratch_bytes >= (size_t)M * K * 2) {
             // batches: ONE gather of x, then the trivial-g_idx kernels on the image of the group-sorted rows
             if (int rc = gather_cols_launch((const half_t *)x, ldx, L.perm32, (half_t *)scratch, K, M, K, (hipStream_t)stream)) return rc;
             if (M <= rows_max) {
@@ -1202,7 +1223,7 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
                 if (rc != GPTQ_E_VARIANT) return rc;
             }
             const int rc = stripe_matvec(scratch, K, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, mm_ws,
-                                         STRIPE_MM_WS_BYTES);
+                                         STRIPE_MM_WS_BYTES, true);
             if (rc != GPTQ_E_VARIANT) return rc;
         }
     }

@@ -31,6 +31,7 @@ _SIGNATURES = {
     'gptq_set_gemm_kernel': [c_int],
     'gptq_set_prefill_route': [c_int],
     'gptq_set_stripe_mm_pass_rows': [c_int],
+    'gptq_set_stripe_gemm_max_rows': [c_int],
     'gptq_prefill_route_for': [c_int, c_int, c_int, c_int, c_int],
     'gptq_set_library_enabled': [c_int],
     'gptq_set_gemm8_mfma': [c_int],

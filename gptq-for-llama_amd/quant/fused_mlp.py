@@ -33,7 +33,7 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
     if family == 'stripe_mm':
         from .quant_linear import stripe_copy, stripe_matmul
         st = None
-        if M <= 256 and all(gi is None for gi in gis):
+        if M <= 1024 and all(gi is None for gi in gis):
             st = stripe_copy(_int32c(gate[0]), gate[1], _int32c(gate[2]), bits, groupsize, up=(_int32c(up[0]), up[1], _int32c(up[2])))
         with torch.cuda.device(x.device):
             c = torch.empty((M, N), device=x.device, dtype=torch.float16)

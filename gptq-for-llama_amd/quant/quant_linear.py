@@ -168,8 +168,9 @@ def stripe_matvec(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, norm_we
 
 
 def stripe_matmul(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, strict=True):
-    """out[M, N] = x[M, K] (1 <= M <= 64) through a stripe16 image with 16-row MFMA tiles (gptq_stripe_matmul_f16, csrc/stripe_mm.inc):
-    exact q - z on the matrix core, fp32 group scales; bits 4 / 8, group size a multiple of the row block.  strict=False: False
+    """out[M, N] = x[M, K] through a stripe16 image on the matrix core (gptq_stripe_matmul_f16, csrc/stripe_mm.inc): 16-row MFMA tiles up
+    to 128 rows, the 2-D tiled fused-dequantise GEMM above (up to gptq_set_stripe_gemm_max_rows, default 1024); exact q - z, fp32 group
+    scales.  strict=False: False
     instead of raising on GPTQ_E_VARIANT (the caller takes another kernel family)."""
     M = x.shape[0]
     ws = _native.mm_workspace(x.device)
@@ -344,10 +345,10 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
                     return out
             raise RuntimeError('matmul248: the stripe16 path does not serve this shape (M <= 16, K a multiple of the row block ...)')
         if family == 'stripe_mm':
-            st = stripe_copy(qweight, scales, qzeros, bits, groupsize) if (gi is None and M <= 256) else None
+            st = stripe_copy(qweight, scales, qzeros, bits, groupsize) if (gi is None and M <= 1024) else None
             if st is not None and stripe_matmul(x, st, out, K, N, bits, groupsize, bias=bias, strict=False):
                 return out
-            raise RuntimeError('matmul248: the stripe16 MFMA kernel does not serve this shape (M <= 256, a stripe16 image of the layer)')
+            raise RuntimeError('matmul248: the stripe16 MFMA kernels do not serve this shape (M <= 1024, a stripe16 image of the layer)')
         rc = getattr(_native.lib(), _FAMILIES[family])(
             x.data_ptr(), x.stride(0) if M > 1 else K, qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
             _native.ptr(gi), _native.ptr(bias), out.data_ptr(), N, M, K, N, bits, groupsize,

@@ -83,6 +83,10 @@ int gptq_set_prefill_route(int route);
 /* Rows per pass of the 16-row MFMA tiles on the stripe16 image (gptq_stripe_matmul_f16, the 5..128-row route of gptq_layer_forward):
  * 128 (default: 65..128 rows in ONE pass over the weights) or 64 (round 2's schedule; A-B runs).  Returns the previous value. */
 int gptq_set_stripe_mm_pass_rows(int rows);
+/* Batches of 129 .. `rows` rows of a layer with a stripe16 image run the fused-dequantise tile GEMM on the image (csrc/stripe_mm.inc,
+ * stripe_gemm_kernel: weights stay packed, no per-call dequantise pass) instead of the dense route; 0 = never (tests / A-B runs).
+ * Returns the previous value. */
+int gptq_set_stripe_gemm_max_rows(int rows);
 /* which engine a dense product of this shape takes under the current switch: 1 = tile GEMM, 0 = hipBLASLt (host logic only;
  * nsets = 2: gate/up pair; trans = 1: the backward product) */
 int gptq_prefill_route_for(int M, int K, int N, int nsets, int trans);
@@ -338,7 +342,7 @@ int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size
  * complete sums). */
 int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t stripes_bytes, float *y_partial, int K, int N, int bits,
                                    int groupsize, int nsets, const uint16_t *perm, gptq_stream_t stream);
-/* Small decode batches, 1 <= M <= 256 (passes of up to 64 rows, each streams the weights once), on the same image (csrc/stripe_mm.inc): 16-row MFMA tiles (v_mfma_f32_16x16x32_f16) on exactly
+/* Batches on the same image (csrc/stripe_mm.inc).  1 <= M <= 128 (to 256 in passes of 128): 16-row MFMA tiles (v_mfma_f32_16x16x32_f16) on exactly
  * dequantised q - z, fp32 group scales; either one launch (a stripe x whole K per workgroup, x streamed through LDS) or K slices
  * (128 columns x one slice per workgroup) that meet through fp32 partial tiles in `workspace` and a reduce kernel (summed in
  * slice order: bit-reproducible; no atomics).  Every layer with a stripe image (bits 2 / 3 / 4 / 8): groups of at least a row block
@@ -346,7 +350,9 @@ int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t st
  * reference's own dequantisation, quant_linear.py:128); GPTQ_E_VARIANT when there is no image (callers fall back to gptq_matmul248_f16).  The workspace
  * (gptq_query(GPTQ_Q_STRIPE_MM_WORKSPACE_BYTES), 256-byte aligned) is pure scratch for the partial tiles: no initialisation, no state
  * between launches; do not share it between launches that may overlap, nor with the zero-invariant split-K workspace of the
- * rowwave kernels.  Reference semantics:
+ * rowwave kernels.  129 <= M <= gptq_set_stripe_gemm_max_rows() (default 1024; groups of at least a row block, bits 3 / 4 / 8): ONE launch of
+ * the 2-D tiled fused-dequantise GEMM (stripe_gemm_kernel: 128 x 128 tiles, weights stay packed, x through LDS) -- no workspace use,
+ * no per-call dequantise pass.  Reference semantics:
  * quant/quant_linear.py:103-137, :415-419; nsets = 2: quant/fused_mlp.py:128-168 (no bias). */
 int gptq_stripe_matmul_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
                            int K, int N, int bits, int groupsize, int nsets, void *workspace, size_t workspace_bytes, gptq_stream_t stream);

@@ -706,3 +706,30 @@ def test_tensor_parallel_decode_engine_two_ranks_one_gpu(world):
             p.kill()
         assert p.exitcode == 0
     assert ret.get(timeout=5) == 1
+
+
+# ---------------------------------------------------------------------------------------
+# the line the driver's scaling tier collects: `bench.py --gpus N` with N > 1 (BASELINE config 5, --tp row by default).  Two ranks
+# on the one GPU of the test box through gloo (RCCL refuses two ranks on one device): the contract fields of the TP line.
+# ---------------------------------------------------------------------------------------
+def test_bench_gpus2_prints_the_tensor_parallel_contract_line():
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, GPTQ_BENCH_BACKEND='gloo', GPTQ_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT_DIR, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--tp-layers', '2']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                       # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'strong' and d['higher_is_better'] is True
+    assert d['config']['parallelism'] == 'tp2 row' and d['config']['world_size_reported_by_backend'] == 2
+    assert d['value'] > 0 and d['ms_per_step'] > 0 and d['unit'] == 'GB/s' and d['config']['collectives_per_step'] == 4 * 2
+    assert 'GBps_whole_job' in d['replicas_reported_only'], d['replicas_reported_only']

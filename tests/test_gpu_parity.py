@@ -892,6 +892,56 @@ def test_stripe_mm_vs_oracle(bits, K, N, gs, M):
         assert rel_err(yp, y[perm]) < TOL
 
 
+@pytest.mark.parametrize('M', [129, 200, 256, 384, 1000])
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 4096, 128), (4, 4096, 11008, 128), (4, 11008, 4096, 128), (4, 1152, 288, 128), (4, 2048, 96, -1),
+                                         (4, 3072, 64, 256), (8, 2048, 288, 64), (8, 1088, 96, -1), (3, 4096, 512, -1), (3, 1152, 160, 128)])
+def test_stripe_gemm_vs_oracle(bits, K, N, gs, M):
+    """batches above 128 rows on the stripe16 image: the 2-D tiled fused-dequantise GEMM (csrc/stripe_mm.inc stripe_gemm_kernel, reached
+    through gptq_stripe_matmul_f16 and through gptq_layer_forward up to gptq_set_stripe_gemm_max_rows): ragged last row tile (M % 128),
+    column groups that are not full (N % 128), K that is not a multiple of the four-chunk round, one group, 3 / 8 bits; against the
+    oracle at 1e-3, bit-reproducible, rows independent of their position"""
+    if K * M > 3e6 and N > 4096:
+        M = min(M, 384)                  # keep the oracle's share of the run time bounded on the widest layer
+    L = make_random_layer(bits, gs, K, N, seed=K + N + M)
+    x = np.random.default_rng(M).standard_normal((M, K)).astype(np.float16)
+    y, ref = check_forward(x, L, family='stripe_mm')
+    y2 = hip_forward(x, L, family='stripe_mm')
+    assert np.array_equal(y.view(np.uint16), y2.view(np.uint16))
+    perm = np.random.default_rng(1).permutation(M)
+    yp = hip_forward(np.ascontiguousarray(x[perm]), L, family='stripe_mm')
+    assert np.array_equal(yp.view(np.uint16), y[perm].view(np.uint16))      # one schedule for every row tile
+    ya = hip_forward(x, L)                                                   # the layer ABI takes the same kernel (M <= 1024)
+    assert np.array_equal(ya.view(np.uint16), y.view(np.uint16))
+    lib = _native.lib()
+    prev = lib.gptq_set_stripe_gemm_max_rows(0)                              # ... and the dense route when it is switched off
+    try:
+        yd = hip_forward(x, L)
+    finally:
+        lib.gptq_set_stripe_gemm_max_rows(prev)
+    assert rel_err(yd, ref) < TOL
+
+
+@pytest.mark.parametrize('M', [130, 300])
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 11008, 128), (8, 1024, 288, 64), (4, 1280, 96, 128)])
+def test_stripe_gemm_fused_mlp_and_bias(bits, K, N, gs, M):
+    """the pair instance (gate | up of one stripe per wave, SiLU on the fp32 sums) and the bias epilogue of the single-set instance"""
+    A, B = make_random_layer(bits, gs, K, N, seed=81), make_random_layer(bits, gs, K, N, seed=82)
+    x = (np.random.default_rng(M).standard_normal((M, K)) * 0.5).astype(np.float16)
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs, family='stripe_mm').cpu().numpy()
+    sets = ((A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']))
+    ref = oracle.fused_mlp(x, sets[0], sets[1], bits)
+    assert rel_err(c, ref) < TOL
+    assert_not_worse_than_reference(c, ref, oracle.fused_mlp_exact(x, sets[0], sets[1], bits))
+    c2 = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs).cpu().numpy()     # the default dispatch takes the same kernel
+    assert np.array_equal(c.view(np.uint16), c2.view(np.uint16))
+    bias = (np.random.default_rng(3).standard_normal(N) * 0.1).astype(np.float16)
+    yb, _ = check_forward(x, A, bias=bias)
+    yf, _ = check_forward(x, A, bias=bias, family='stripe_mm')
+    assert np.array_equal(yb.view(np.uint16), yf.view(np.uint16))
+
+
 @pytest.mark.parametrize('M', [6, 33, 70])
 def test_stripe_mm_strided_rows(M):
     """x as a column slice of a wider buffer (row stride K + 64, the way a fused qkv / hidden-state view arrives): same bits as

@@ -294,7 +294,10 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert lib.gptq_query(5) == 64 << 20
     assert mm(ws=None) == -4 and mm(y=None) == -4 and mm(x=None) == -4
     assert mm(ws=260) == -3 and mm(ldx=252) == -3
-    assert mm(M=257) == -6 and mm(bits=5) == -1
+    assert mm(M=1025) == -6 and mm(bits=5) == -1                       # 129 .. 1024 rows: the fused tile GEMM (gptq_set_stripe_gemm_max_rows)
+    prev = lib.gptq_set_stripe_gemm_max_rows(0)
+    assert prev == 1024 and mm(M=257) == -6                            # without it: passes of 128 rows up to 256
+    assert lib.gptq_set_stripe_gemm_max_rows(prev) == 0 and lib.gptq_set_stripe_gemm_max_rows(-1) == -6
     assert mm(nbytes=nb - 1) == -5
     assert mm(M=0) == 0
 

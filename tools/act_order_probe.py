@@ -1,0 +1,43 @@
+import os, sys, json
+ROOT = '/root/repo'
+sys.path.insert(0, os.path.join(ROOT, 'gptq-for-llama_amd')); sys.path.insert(0, ROOT)
+import torch
+from quant import _native, quant_linear as QL
+dev = 'cuda:0'
+gen = torch.Generator(device=dev); gen.manual_seed(0)
+def make(K, N, mode):
+    G = K // 128
+    qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=dev, generator=gen)
+    qz = torch.randint(-2**31, 2**31 - 1, (G, N // 8), dtype=torch.int32, device=dev, generator=gen)
+    sc = (torch.rand((G, N), device=dev, generator=gen) * 0.01 + 0.001).half()
+    gi = (torch.arange(K, device=dev) // 128).to(torch.int32)
+    if mode == 'swap':       # regular act-order whose permutation is the identity except for two rows of different groups
+        gi = gi.clone(); gi[0], gi[K - 1] = gi[K - 1].clone(), gi[0].clone()
+    elif mode == 'random':
+        gi = gi[torch.argsort(torch.randperm(K, device=dev, generator=gen))].contiguous()
+    return qw, sc, qz, gi
+for K, N in [(4096, 4096), (11008, 4096)]:
+    for mode in ['trivial', 'swap', 'random']:
+        nb = K * N // 2
+        nsets = int(300e6 // nb) + 1
+        sets = [make(K, N, mode) for _ in range(nsets)]
+        x = torch.randn((1, K), device=dev, generator=gen).half()
+        def run(i):
+            qw, sc, qz, gi = sets[i]
+            return QL.matmul248(x, qw, sc, qz, gi, 4, 15)
+        for i in range(nsets): run(i)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(nsets): run(i)
+        g.replay(); torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): g.replay()
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / (5 * nsets))
+        print('%dx%d %-8s %.2f us' % (K, N, mode, best), flush=True)
+        del sets, g
+        torch.cuda.empty_cache()

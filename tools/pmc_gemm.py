@@ -8,12 +8,15 @@ import csv
 import json
 import sys
 
+import os
+KERNEL = os.environ.get('PMC_KERNEL', 'gemm8_kernel')      # substring of the kernel name (PMC_KERNEL=stripe_gemm_kernel for csrc/stripe_mm.inc)
 acc = collections.defaultdict(list)
 for path in sys.argv[2:]:
     for r in csv.DictReader(open(path)):
-        if 'gemm8_kernel' in r['Kernel_Name']:
+        if KERNEL in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
-out = {'kernel': 'gptq::gemm8_kernel<false, false> (csrc/gemm8.hip), M = 16384, K = N = 4096 (tools/run_prefill_once.py)',
+out = {'kernel': ('gptq::gemm8_kernel<false, false> (csrc/gemm8.hip), M = 16384, K = N = 4096 (tools/run_prefill_once.py)' if KERNEL == 'gemm8_kernel' else
+                  KERNEL + ' (' + os.environ.get('PMC_NOTE', 'tools/run_prefill_once.py') + ')'),
        'note': 'rocprofv3 --pmc, separate passes; SQ_*_CYCLES in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles); GRBM_GUI_ACTIVE summed over 8 XCDs'}
 for k, v in sorted(acc.items()):
     out[k] = sum(v) / len(v)

@@ -474,6 +474,52 @@ def small_batch_leg(dev):
     return out
 
 
+def prompt_leg(dev):
+    """A single request's prompt (reported only): batches of 256 / 512 / 1024 rows through gptq_layer_forward on the LLaMA-7B shapes --
+    the fused-dequantise tile GEMM on the stripe16 image (csrc/stripe_mm.inc stripe_gemm_kernel, the product for 129 .. 1024 rows)
+    against the dense route (dequantise per call + gemm8 / hipBLASLt) on the same prepared layer; us per call from a hipGraph of 8
+    calls, TFLOP/s = 2 M N K / t (reference kernel for every M: quant_linear.py:72-137, fused_mlp.py:84-168)."""
+    from quant import _native, layer as QLayer
+    lib = _native.lib()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    out = {'unit': 'us per call (hipGraph of 8 calls, warm weights)', 'shapes': {}}
+
+    def timed(fn, calls=8):
+        fn(); fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(calls):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); g.replay(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / calls)
+        return sorted(ts)[2]
+
+    for K, N, pair in [(HIDDEN, HIDDEN, False), (HIDDEN, 3 * HIDDEN, False), (INTER, HIDDEN, False), (HIDDEN, INTER, True)]:
+        sets = tuple((w.qweight, w.scales, w.qzeros, None) for w in (PackedSet(K, N, dev, gen), PackedSet(K, N, dev, gen))[:2 if pair else 1])
+        pl = QLayer.PreparedLayer(sets, None, BITS, GS, K, N)
+        row = {}
+        for M in (256, 512, 1024):
+            x = torch.randn((M, K), device=dev, generator=gen).half()
+            y = torch.empty((M, N), dtype=torch.float16, device=dev)
+            prev = lib.gptq_set_stripe_gemm_max_rows(0)
+            t_dense = timed(lambda: pl.forward(x, y))
+            lib.gptq_set_stripe_gemm_max_rows(prev)
+            t = timed(lambda: pl.forward(x, y))
+            fl = (4.0 if pair else 2.0) * M * N * K
+            row['M%d' % M] = {'us': round(t, 1), 'TFLOPs': round(fl / t / 1e6, 1), 'dense_route_us': round(t_dense, 1), 'vs_dense_route': round(t_dense / t, 2)}
+        out['shapes'][('gate_up_silu_2x%dx%d' if pair else '%dx%d') % (K, N)] = row
+        del pl, sets
+    return out
+
+
 def config4_leg(dev):
     """BASELINE config 4 (reported only): LLaMA-7B-shaped 3-bit no-group and 4-bit g128 act-order, batch 1, cold weights,
     through the drop-in matmul248 (3-bit: rowwave3 kernel, an extension -- the reference raises for bits == 3,
@@ -840,6 +886,7 @@ def main():
             leg('prefill_config3_reported_only', lambda: prefill_leg(dev))
         if not args.no_small_batch and world == 1:
             leg('small_batch_reported_only', lambda: small_batch_leg(dev))
+            leg('prompt_reported_only', lambda: prompt_leg(dev))
         if not args.no_config4 and world == 1:
             leg('config4_reported_only', lambda: config4_leg(dev))
         if not args.no_decode and world == 1:

@@ -2,9 +2,11 @@
 set -x
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r3f}; mkdir -p $O
-if [ -z "$SKIP_TESTS" ]; then
-timeout 500 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -6 $O/pytest_gpu.txt
+# a sick box (seen once: 'Memory access fault by GPU' in the first torch op of every process) must not burn the GPU budget: smoke first, stop if it fails
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
+grep -q 'smoke ok' $O/smoke.txt || { echo 'SMOKE FAILED -- stopping'; exit 3; }
+if [ -z "$SKIP_TESTS" ]; then
+timeout 600 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -6 $O/pytest_gpu.txt
 timeout 900 python bench.py > $O/bench.json.txt 2> $O/bench.err; tail -c 400 $O/bench.json.txt
 fi
 cd /tmp && export TMPDIR=/tmp

@@ -184,8 +184,7 @@ def stripe_matmul(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, strict=
 
 
 STRIPE_MAX_M = 16  # rows of x one stripe16 decode launch serves (four per MFMA row group; 8 / 16 rows only while they fit in LDS)
-STRIPE_MM_MAX_M = 128  # rows served by the 16-row-tile MFMA kernel on the same image (gptq_stripe_matmul_f16: passes of 64 rows; the C ABI
-# takes up to 256, where dequantise + dense GEMM is already faster: profiles/r2c_mm/mid_m.txt)
+
 
 
 def _as_rows(t):

@@ -298,6 +298,8 @@ def test_stripe_abi_validation_needs_no_gpu():
     prev = lib.gptq_set_stripe_gemm_max_rows(0)
     assert prev == 1024 and mm(M=257) == -6                            # without it: passes of 128 rows up to 256
     assert lib.gptq_set_stripe_gemm_max_rows(prev) == 0 and lib.gptq_set_stripe_gemm_max_rows(-1) == -6
+    assert lib.gptq_set_stripe_mm_pass_rows(96) == -6                  # rows per pass of the 16-row tiles: 64 or 128
+    assert lib.gptq_set_stripe_mm_pass_rows(64) == 128 and lib.gptq_set_stripe_mm_pass_rows(128) == 64
     assert mm(nbytes=nb - 1) == -5
     assert mm(M=0) == 0
 

@@ -1187,6 +1187,32 @@ size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M) {
 static int layer_forward_checkpoint(const gptq_layer &L, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, void *scratch,
                                     size_t scratch_bytes, gptq_stream_t stream);
 
+// The table of gptq_layer_forward as a host-only query (no launch): which kernel family a batch of M rows takes for a layer of this
+// shape, given that the caller supplies gptq_layer_scratch_bytes() of scratch.  It mirrors the ladder below; a kernel may still decline at
+// launch (LDS limits of the row groups ...) and hand the batch to the next rung.
+int gptq_layer_route_for_shape(int M, int K, int N, int bits, int groupsize, int nsets, int kind, int has_image) {
+    if (M <= 0 || K <= 0 || N <= 0 || nsets < 1 || nsets > 2 || kind < 0 || kind > 2) return GPTQ_E_SHAPE;
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    const int gq = stripe_gq_shift(K, N, bits, groupsize);
+    const bool image = has_image && gq != -2 && kind != 2;
+    const int rows_max = N <= 4608 ? 8 : 4;
+    const int gemm_max = g_stripe_gemm_max_rows.load();
+    if (image && (kind == 0 || M == 1) && M <= rows_max && (M <= 4 || K <= 9216)) return GPTQ_ROUTE_STRIPE_DECODE;
+    if (image && M > 1) {
+        if (M <= rows_max && kind == 1 && (M <= 4 || K <= 9216)) return GPTQ_ROUTE_STRIPE_DECODE;       // after one gather of x
+        if (M <= LAYER_STRIPE_MM_MAX_M) return GPTQ_ROUTE_STRIPE_TILES;
+        if (M <= gemm_max && bits != 2 && (gq == -1 || gq >= 2)) return GPTQ_ROUTE_STRIPE_GEMM;       // groups of at least a row block
+    }
+    if (M >= LAYER_PREFILL_MIN_M)
+        return (gemm8_wanted(M, N, nsets == 2) && K % 128 == 0) ? GPTQ_ROUTE_DENSE_TILE_GEMM : GPTQ_ROUTE_DENSE_LIBRARY;
+    return GPTQ_ROUTE_CHECKPOINT_KERNELS;
+}
+
+int gptq_layer_route_for(const gptq_layer_t *layer, int M) {
+    if (!layer) return GPTQ_E_NULL;
+    return gptq_layer_route_for_shape(M, layer->K, layer->N, layer->bits, layer->groupsize, layer->nsets, layer->kind, layer->stripe != nullptr);
+}
+
 int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, size_t workspace_bytes,
                        void *scratch, size_t scratch_bytes, gptq_stream_t stream) {
     if (!layer) return GPTQ_E_NULL;

@@ -109,6 +109,8 @@ _SIGNATURES = {
     'gptq_layer_stripe_image': [c_void_p, c_void_p, c_void_p, c_void_p],
     'gptq_layer_release_checkpoint': [c_void_p],
     'gptq_layer_unpack_checkpoint': [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    'gptq_layer_route_for_shape': [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int],
+    'gptq_layer_route_for': [c_void_p, c_int],
     'gptq_layer_workspace_bytes': [],
     'gptq_layer_scratch_bytes': [c_void_p, c_int],
     'gptq_layer_forward': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p],

@@ -419,6 +419,20 @@ size_t gptq_layer_workspace_bytes(void);
 size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M);
 int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace,
                        size_t workspace_bytes, void *scratch, size_t scratch_bytes, gptq_stream_t stream);
+/* The M -> kernel table of gptq_layer_forward as a host-only query (no launch, no GPU needed): the kernel family a batch of M rows takes,
+ * assuming the caller passes gptq_layer_scratch_bytes() of scratch.  It replaces what the reference's Autotuner decides at run time
+ * (quant/custom_autotune.py:76-102) by something a caller can read.  A kernel may still decline at launch (LDS limits) and hand the
+ * batch to the next rung of the ladder.  kind: the value of gptq_layer_inspect(); has_image: an image was given to gptq_layer_prepare. */
+enum {
+    GPTQ_ROUTE_STRIPE_DECODE = 1,        /* stripe16 decode kernel (M = 1) / its row groups (2 .. 8 rows) */
+    GPTQ_ROUTE_STRIPE_TILES = 2,         /* 16-row MFMA tiles on the image, up to 128 rows (csrc/stripe_mm.inc) */
+    GPTQ_ROUTE_STRIPE_GEMM = 3,          /* fused-dequantise tile GEMM on the image, 129 .. gptq_set_stripe_gemm_max_rows() rows */
+    GPTQ_ROUTE_DENSE_TILE_GEMM = 4,      /* dequantise per call + the tile GEMM of csrc/gemm8.hip */
+    GPTQ_ROUTE_DENSE_LIBRARY = 5,        /* dequantise per call + hipBLASLt */
+    GPTQ_ROUTE_CHECKPOINT_KERNELS = 6    /* rowwave / stream / generic kernels on the checkpoint layout */
+};
+int gptq_layer_route_for_shape(int M, int K, int N, int bits, int groupsize, int nsets, int kind, int has_image);
+int gptq_layer_route_for(const gptq_layer_t *layer, int M);
 
 /* ---- GPTQ solver (the caller that PRODUCES the weights; reference gptq.py:128-228) -------------------------------
  * One column block [i1, i1 + count), count <= 128, of the sequential quantise / error-feedback loop (gptq.py:177-199)

@@ -485,3 +485,41 @@ def test_p2p_allreduce_protocol_simulation():
                         s['acc'], s['ph'], s['e'] = [], 0, e + 1
             for r in range(world):
                 assert st[r]['sums'] == [sum(part(q, e) for q in range(world)) for e in range(1, calls + 1)]
+
+
+def test_layer_route_table_is_host_logic():
+    """gptq_layer_route_for_shape: the M -> kernel table of gptq_layer_forward (include/gptq_mi355x.h) as a host-only query -- what the
+    reference's Autotuner decides per (M, N, K) at run time (quant/custom_autotune.py:76-102), readable and pinned here for the LLaMA-7B
+    shapes of BASELINE.json (4-bit, g128)."""
+    lib = _native.lib()
+    DEC, TILES, SGEMM, OWN, LIBR, CKPT = 1, 2, 3, 4, 5, 6
+
+    def route(M, K, N, bits=4, gs=128, nsets=1, kind=0, image=1):
+        return lib.gptq_layer_route_for_shape(M, K, N, bits, gs, nsets, kind, image)
+    for K, N, ns in [(4096, 4096, 1), (4096, 12288, 1), (11008, 4096, 1), (4096, 11008, 2)]:
+        assert route(1, K, N, nsets=ns) == DEC and route(4, K, N, nsets=ns) == DEC
+        assert route(16, K, N, nsets=ns) == TILES and route(128, K, N, nsets=ns) == TILES
+        assert route(129, K, N, nsets=ns) == SGEMM and route(1024, K, N, nsets=ns) == SGEMM      # a single prompt: weights stay packed
+        assert route(1025, K, N, nsets=ns) == LIBR                                                # below one round of 256 x 256 tiles
+        assert route(65536, K, N, nsets=ns) == OWN                                                # BASELINE config 3
+    assert route(8, 4096, 4096) == DEC and route(8, 4096, 12288) == TILES        # row groups only while one round of workgroups covers N
+    assert route(8, 11008, 4096) == TILES                                       # eight rows of x do not fit LDS at K = 11008
+    assert route(2048, 4096, 4096) == LIBR and route(2048, 4096, 12288) == OWN   # 128 vs 384 tiles of 256 x 256
+    assert route(2048, 4096, 11008, nsets=2) == OWN                              # the pair: 256 x 128 tiles
+    # act-order: regular (group-sorted image + gather) like trivial; irregular: no image
+    assert route(1, 4096, 4096, kind=1) == DEC and route(64, 4096, 4096, kind=1) == TILES and route(300, 4096, 4096, kind=1) == SGEMM
+    assert route(1, 4096, 4096, kind=2) == CKPT and route(64, 4096, 4096, kind=2) == CKPT and route(65, 4096, 4096, kind=2) == LIBR
+    # groups smaller than a row block have tiles (prescale mode) but no fused GEMM; 2-bit likewise; no image at all
+    assert route(100, 4096, 4096, gs=32) == TILES and route(300, 4096, 4096, gs=32) == LIBR
+    assert route(300, 4096, 4096, bits=2) == LIBR and route(300, 4096, 4096, bits=8) == SGEMM and route(300, 4096, 4096, bits=3, gs=4096) == SGEMM
+    assert route(1, 4096, 4096, image=0) == CKPT and route(64, 4096, 4096, image=0) == CKPT and route(1000, 4096, 4096, image=0) == LIBR and route(4096, 4096, 4096, image=0) == OWN
+    # the switches move the table
+    prev = lib.gptq_set_stripe_gemm_max_rows(0)
+    assert route(300, 4096, 4096) == LIBR
+    lib.gptq_set_stripe_gemm_max_rows(prev)
+    prev = lib.gptq_set_prefill_route(2)
+    assert route(1025, 4096, 4096) == OWN
+    lib.gptq_set_prefill_route(0)
+    assert route(65536, 4096, 4096) == LIBR
+    lib.gptq_set_prefill_route(prev)
+    assert route(0, 4096, 4096) == -2 and route(1, 4096, 4096, bits=5) == -1 and lib.gptq_layer_route_for(None, 1) == -4

@@ -913,6 +913,7 @@ def test_stripe_gemm_vs_oracle(bits, K, N, gs, M):
     ya = hip_forward(x, L)                                                   # the layer ABI takes the same kernel (M <= 1024)
     assert np.array_equal(ya.view(np.uint16), y.view(np.uint16))
     lib = _native.lib()
+    assert lib.gptq_layer_route_for_shape(M, K, N, bits, K if gs == -1 else gs, 1, 0, 1) == 3     # ... and the host-side table says so (GPTQ_ROUTE_STRIPE_GEMM)
     prev = lib.gptq_set_stripe_gemm_max_rows(0)                              # ... and the dense route when it is switched off
     try:
         yd = hip_forward(x, L)

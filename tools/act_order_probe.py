@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""tools/act_order_probe.py -- what does act-order cost at M = 1?  The same 4-bit g128 layer shape with a trivial g_idx, with a regular act-order
+g_idx whose permutation is the identity except for two swapped rows, and with a random one (cold weights, hipGraph): the gather PATTERN is
+irrelevant (swap == random); profiles/r3i_act_order/."""
 import os, sys, json
-ROOT = '/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'gptq-for-llama_amd')); sys.path.insert(0, ROOT)
 import torch
 from quant import _native, quant_linear as QL

@@ -70,6 +70,7 @@ class DecodeLinears:
         self.lib = _native.lib()
         self.dev = dev
         self.kernel = kernel
+        self.prefetch_kib = int(os.environ.get('GPTQ_BENCH_PREFETCH_KIB', '0'))   # head of the next op's stripes a launch pulls on chip (0: off)
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
         self.layers = []
@@ -95,24 +96,29 @@ class DecodeLinears:
                                         alg_bytes(1, HIDDEN, INTER, nsets=2) + alg_bytes(1, INTER, HIDDEN))
         self.launches_per_step = 4 * layers
 
-    def _layer(self, x, pl, y, stream):
-        """the product's ONE call site (include/gptq_mi355x.h "Prepared layers"): the M -> kernel table is inside"""
-        rc = self.lib.gptq_layer_forward(pl.handle, x.data_ptr(), pl.K, y.data_ptr(), pl.N, 1, self.lws.data_ptr(), self.lws.numel(), None, 0, stream)
+    def _layer(self, x, pl, y, stream, nxt=None):
+        """the product's ONE call site (include/gptq_mi355x.h "Prepared layers"): the M -> kernel table is inside.  nxt = the layer the
+        chain runs next: gptq_layer_forward_next lets this launch pull the head of its stripes on chip behind its own weight stream"""
+        if nxt is not None and self.prefetch_kib > 0:
+            rc = self.lib.gptq_layer_forward_next(pl.handle, nxt.handle, self.prefetch_kib, x.data_ptr(), pl.K, y.data_ptr(), pl.N, 1,
+                                                  self.lws.data_ptr(), self.lws.numel(), None, 0, stream)
+        else:
+            rc = self.lib.gptq_layer_forward(pl.handle, x.data_ptr(), pl.K, y.data_ptr(), pl.N, 1, self.lws.data_ptr(), self.lws.numel(), None, 0, stream)
         self.native.check(rc, 'gptq_layer_forward')
 
-    def _mm(self, x, L, name, y, stream):
+    def _mm(self, x, L, name, y, stream, nxt=None):
         w = L[name]
         if self.kernel == 'stripe':
-            return self._layer(x, L['pl_' + name], y, stream)
+            return self._layer(x, L['pl_' + name], y, stream, nxt)
         rc = self.lib.gptq_matmul248_f16(x.data_ptr(), w.K, w.qweight.data_ptr(), w.scales.data_ptr(), w.qzeros.data_ptr(),
                                          None, None, y.data_ptr(), w.N, 1, w.K, w.N, BITS, GS, self.ws.data_ptr(),
                                          self.ws.numel(), stream)
         self.native.check(rc, 'gptq_matmul248_f16')
 
-    def _mlp(self, x, L, y, stream):
+    def _mlp(self, x, L, y, stream, nxt=None):
         g, u = L['gate'], L['up']
         if self.kernel == 'stripe':
-            return self._layer(x, L['pl_mlp'], y, stream)
+            return self._layer(x, L['pl_mlp'], y, stream, nxt)
         rc = self.lib.gptq_fused_mlp_f16(x.data_ptr(), g.K, g.qweight.data_ptr(), g.scales.data_ptr(), g.qzeros.data_ptr(),
                                          None, u.qweight.data_ptr(), u.scales.data_ptr(), u.qzeros.data_ptr(), None,
                                          y.data_ptr(), g.N, 1, g.K, g.N, BITS, GS, self.ws.data_ptr(), self.ws.numel(), stream)
@@ -120,11 +126,13 @@ class DecodeLinears:
 
     def step(self):
         s = torch.cuda.current_stream().cuda_stream
-        for L in self.layers:
-            self._mm(self.x_h, L, 'qkv', self.y_qkv, s)
-            self._mm(self.x_h, L, 'o', self.y_h, s)
-            self._mlp(self.x_h, L, self.y_i, s)
-            self._mm(self.x_i, L, 'down', self.y_h, s)
+        st = self.kernel == 'stripe'
+        for i, L in enumerate(self.layers):
+            N = self.layers[(i + 1) % len(self.layers)]      # the pass repeats token after token: the last layer is followed by the first
+            self._mm(self.x_h, L, 'qkv', self.y_qkv, s, L['pl_o'] if st else None)
+            self._mm(self.x_h, L, 'o', self.y_h, s, L['pl_mlp'] if st else None)
+            self._mlp(self.x_h, L, self.y_i, s, L['pl_down'] if st else None)
+            self._mm(self.x_i, L, 'down', self.y_h, s, N['pl_qkv'] if st else None)
 
     def per_shape(self, reps=20):
         """event-timed launches per shape, rotating over the 32 layers' distinct weights (cold)."""

@@ -878,7 +878,8 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
 
 static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, float *y32,
                          int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
-                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false) {
+                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false,
+                         const StripePrefetch *pf = nullptr) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
@@ -911,6 +912,8 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.NS = nsets;
     p.gq_shift = gq;
     p.bits = bits;
+    p.progress = M == 1 ? stripe_progress_counter() : nullptr;
+    if (pf && M == 1 && !mm_ws) p.pf = *pf;
     if (gemm_rows) {   // 2-D tiles, weights kept packed (stripe_gemm_kernel)
         int rc;
         switch (bits) {
@@ -1213,8 +1216,39 @@ int gptq_layer_route_for(const gptq_layer_t *layer, int M) {
     return gptq_layer_route_for_shape(M, layer->K, layer->N, layer->bits, layer->groupsize, layer->nsets, layer->kind, layer->stripe != nullptr);
 }
 
+static int layer_forward_impl(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, size_t workspace_bytes,
+                              void *scratch, size_t scratch_bytes, gptq_stream_t stream, const StripePrefetch *pf);
+
 int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, size_t workspace_bytes,
                        void *scratch, size_t scratch_bytes, gptq_stream_t stream) {
+    return layer_forward_impl(layer, x, ldx, y, ldy, M, workspace, workspace_bytes, scratch, scratch_bytes, stream, nullptr);
+}
+
+// The decode chain knows which layer runs next: at M = 1 the launch of `layer` also touches the first head_kib KiB of every stripe of
+// `next` (capped by what two wave loads per wave of this launch cover), into the L2 of the XCD that will read them (stripe_kernel.inc, PF).
+// Anything the tail prefetch does not apply to (M > 1, no image on either side, a route other than the stripe decode kernel) behaves
+// exactly like gptq_layer_forward.
+int gptq_layer_forward_next(const gptq_layer_t *layer, const gptq_layer_t *next, int head_kib, const void *x, int64_t ldx, void *y, int64_t ldy, int M,
+                            void *workspace, size_t workspace_bytes, void *scratch, size_t scratch_bytes, gptq_stream_t stream) {
+    StripePrefetch pf{};
+    if (layer && next && M == 1 && head_kib > 0 && layer->stripe && next->stripe && (next->N / 16) % 8 == 0 && (layer->N / 16) % 8 == 0) {
+        const size_t toff = stripe_tab_offset(next->K, next->N, next->bits, next->nsets);
+        const uint32_t nstripes = (uint32_t)(next->N / 16), stripe_bytes = (uint32_t)(toff / nstripes);
+        const uint64_t capacity_kib = 2ull * (uint64_t)(layer->N / 16) * STRIPE_NW;   // two 1-KiB loads per wave of this launch
+        uint32_t lg = 0;
+        while ((2u << lg) <= (uint32_t)head_kib && (2u << lg) * 1024u <= stripe_bytes && (uint64_t)nstripes * (2u << lg) <= capacity_kib) lg++;
+        if ((1u << lg) * 1024u <= stripe_bytes && (uint64_t)nstripes * (1u << lg) <= capacity_kib * 2) {
+            pf.weights = (const char *)next->stripe;
+            pf.nstripes = nstripes;
+            pf.stripe_bytes = stripe_bytes;
+            pf.log2_head_kib = lg;
+        }
+    }
+    return layer_forward_impl(layer, x, ldx, y, ldy, M, workspace, workspace_bytes, scratch, scratch_bytes, stream, pf.weights ? &pf : nullptr);
+}
+
+static int layer_forward_impl(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, size_t workspace_bytes,
+                              void *scratch, size_t scratch_bytes, gptq_stream_t stream, const StripePrefetch *pf) {
     if (!layer) return GPTQ_E_NULL;
     const gptq_layer &L = *layer;
     if (M < 0 || ldx < L.K || ldy < L.N) return GPTQ_E_SHAPE;
@@ -1228,7 +1262,8 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
     // ---- 1. decode and small batches on the stripe16 image ----
     if (L.stripe && L.kind == 0) {
         if (M <= rows_max) {
-            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream);
+            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, nullptr, 0,
+                                         false, pf);
             if (rc != GPTQ_E_VARIANT) return rc;
         }
         if (M > 4 && M <= std::max(LAYER_STRIPE_MM_MAX_M, g_stripe_gemm_max_rows.load())) {   // ... 128 rows: 16-row tiles; above: the fused tile GEMM
@@ -1239,7 +1274,8 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
     }
     if (L.stripe && L.kind == 1) {
         if (M == 1) {   // the decode kernel gathers x through the permutation itself
-            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, 1, K, N, bits, gs, ns, nullptr, 0.f, L.perm16, stream);
+            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, 1, K, N, bits, gs, ns, nullptr, 0.f, L.perm16, stream, nullptr, 0,
+                                         false, pf);
             if (rc != GPTQ_E_VARIANT) return rc;
         } else if (M <= std::max(LAYER_STRIPE_MM_MAX_M, g_stripe_gemm_max_rows.load()) && scratch && aligned(scratch, 16) && scratch_bytes >= (size_t)M * K * 2) {
             // batches: ONE gather of x, then the trivial-g_idx kernels on the image of the group-sorted rows

@@ -629,7 +629,11 @@ static float time_graph(launch_fn fn, SP base, const std::vector<WSet> &sets, hi
     if (freshx && !dummy_x) CK(hipMalloc(&dummy_x, 65536 * 2));
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
     int it = 0;
-    for (auto &w : sets) {
+    // round 4 fix: >= 128 kernel nodes per graph, cycling through the weight sets.  Round 3 captured sets.size() nodes, so with LAB_NBUF=1..3
+    // the figure was the cadence of launching a 1-3 node graph (~10.4 us), not a read path (tools/warmlab.hip A).
+    const size_t nodes = ((std::max<size_t>(128, sets.size()) + sets.size() - 1) / sets.size()) * sets.size();
+    for (size_t node = 0; node < nodes; node++) {
+        const WSet &w = sets[node % sets.size()];
         SP p = base; p.R = w.R; p.tab = w.tab;
         // LAB_FRESHX=1: x itself is rewritten; LAB_FRESHX=2 (control): the same producer launch writes a buffer nobody reads
         if (freshx) hipLaunchKernelGGL(fill_x, dim3(64), dim3(256), 0, s, freshx_mode == 2 ? dummy_x : (half_t *)base.x, (size_t)base.K, 77u + (it++ % 2));
@@ -644,7 +648,7 @@ static float time_graph(launch_fn fn, SP base, const std::vector<WSet> &sets, hi
     CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
-    return ms * 1e3f / (reps * sets.size());
+    return ms * 1e3f / (reps * nodes);
 }
 static float best_of(launch_fn fn, SP base, const std::vector<WSet> &sets, hipStream_t s) {
     float t = 1e9f;

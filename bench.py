@@ -333,6 +333,32 @@ class TPLayers:
                 self._reduce_round(self.p_h, self.y_h)
 
 
+def tp_world1_leg(dev, mode, layers, steps=20):
+    """The like-for-like origin of the --gpus N > 1 curve: the SAME LLaMA-65B-shaped stack (same layers, same launches, fp32 partials,
+    fp16 rounding after the would-be reduce) on ONE GPU with nothing sharded and no collective."""
+    work = TPLayers(dev, 0, 1, mode, layers)
+    for _ in range(2):
+        work.step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        work.step()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {'workload': 'the same %d-layer LLaMA-65B-shaped stack, unsharded on one GPU (world 1), hipGraph replay' % layers,
+           'GBps': round(work.bytes_per_step * steps / dt / 1e9, 1), 'ms_per_step': round(dt * 1e3 / steps, 4), 'n_gpus': 1,
+           'frac_of_8TBps': round(work.bytes_per_step * steps / dt / 1e9 / HBM_PEAK_GBS, 4)}
+    del g, work
+    torch.cuda.empty_cache()
+    return out
+
+
 def allreduce_latency_us(dev, world, nfloats, reps=50, p2p=None):
     """mean us of one fp32 all-reduce of nfloats elements, back to back on the stream (reported next to the TP line)."""
     if world == 1:
@@ -705,10 +731,32 @@ def main():
     ap.add_argument('--no-config4', action='store_true')
     ap.add_argument('--no-small-batch', action='store_true')
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under torch.distributed.run,
+        # rendezvous on 127.0.0.1) -- the reference spreads over GPUs from one command too (llama.py:328-382).  Rank 0 prints the line.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get('GPTQ_BENCH_SPAWN_DRY'):      # CPU test hook: show the launch, do not run it
+            print(json.dumps({'spawn': cmd}))
+            return
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        sys.exit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to print a line for the wrong N\n'
+                         % (args.gpus, world))
+        sys.exit(2)
     import torch.distributed as dist
     distributed = world > 1
     if distributed:
@@ -722,6 +770,7 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     torch.cuda.set_device(local_rank)
     dev = 'cuda:%d' % local_rank
     if world > 1 and args.tp is None and not args.dp:
@@ -824,6 +873,10 @@ def main():
         achieved = bytes_per_launch / us_per_launch / 1e3
         traffic, traffic_src = pmc_traffic()
         if args.tp:
+            try:   # rank 0 alone (the other ranks wait in the final barrier): same stack, world 1
+                tp1 = tp_world1_leg(dev, args.tp, args.tp_layers) if not os.environ.get('GPTQ_BENCH_NO_TP1') else None
+            except Exception as e:
+                tp1 = {'error': repr(e)[:200]}
             out = {
                 'metric': 'int4 g128 matvec GB/s (LLaMA-65B-shaped 4-bit batch-1 decode linears, sharded over the ranks)',
                 'value': round(work.bytes_per_step / (ms_per_step * 1e-3) / 1e9, 1), 'unit': 'GB/s', 'n_gpus': world, 'steps': args.steps,
@@ -841,6 +894,7 @@ def main():
                            'collectives_per_step': work.collectives_per_step, 'launch_mode': launch_mode,
                            'algorithmic_bytes_per_step': work.bytes_per_step},
                 'allreduce_us': tp_lat,
+                'tp1_same_workload': tp1,
                 'replicas_reported_only': replicas,
                 'roofline': {'bound': 'hbm', 'achieved': round(work.bytes_per_step / world / (ms_per_step * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS,
                              'unit': 'GB/s', 'frac': round(work.bytes_per_step / world / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -897,6 +951,9 @@ def main():
             leg('prompt_reported_only', lambda: prompt_leg(dev))
         if not args.no_config4 and world == 1:
             leg('config4_reported_only', lambda: config4_leg(dev))
+        if world == 1 and not os.environ.get('GPTQ_BENCH_NO_TP1'):
+            # the N = 1 point of the OTHER curve: `--gpus N > 1` runs BASELINE configs[4] (65B stack, row-sharded); this is that stack at world 1
+            leg('tp1_same_workload_as_gpus_gt_1', lambda: tp_world1_leg(dev, 'row', args.tp_layers))
         if not args.no_decode and world == 1:
             leg('decode', lambda: decode_tokens_per_s(dev))
         if not args.no_cpu_baseline and world == 1:

@@ -523,3 +523,22 @@ def test_layer_route_table_is_host_logic():
     assert route(65536, 4096, 4096) == LIBR
     lib.gptq_set_prefill_route(prev)
     assert route(0, 4096, 4096) == -2 and route(1, 4096, 4096, bits=5) == -1 and lib.gptq_layer_route_for(None, 1) == -4
+
+
+def test_bench_gpus_n_spawns_n_ranks_and_refuses_a_wrong_world_size():
+    """bench.py --gpus N without a launcher re-executes itself under torch.distributed.run with N ranks (dry run: the command only);
+    with a launcher whose WORLD_SIZE differs from --gpus it refuses to print a line for the wrong N."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '2'], env=dict(env, GPTQ_BENCH_SPAWN_DRY='1'),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    cmd = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])['spawn']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-4:] == ['--gpus', '4', '--steps', '2'] and 'torch.distributed.run' in cmd
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=dict(env, WORLD_SIZE='4', RANK='0'),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and 'refusing' in out.stderr

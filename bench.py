@@ -70,7 +70,6 @@ class DecodeLinears:
         self.lib = _native.lib()
         self.dev = dev
         self.kernel = kernel
-        self.prefetch_kib = int(os.environ.get('GPTQ_BENCH_PREFETCH_KIB', '0'))   # head of the next op's stripes a launch pulls on chip (0: off)
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
         self.layers = []
@@ -96,29 +95,24 @@ class DecodeLinears:
                                         alg_bytes(1, HIDDEN, INTER, nsets=2) + alg_bytes(1, INTER, HIDDEN))
         self.launches_per_step = 4 * layers
 
-    def _layer(self, x, pl, y, stream, nxt=None):
-        """the product's ONE call site (include/gptq_mi355x.h "Prepared layers"): the M -> kernel table is inside.  nxt = the layer the
-        chain runs next: gptq_layer_forward_next lets this launch pull the head of its stripes on chip behind its own weight stream"""
-        if nxt is not None and self.prefetch_kib > 0:
-            rc = self.lib.gptq_layer_forward_next(pl.handle, nxt.handle, self.prefetch_kib, x.data_ptr(), pl.K, y.data_ptr(), pl.N, 1,
-                                                  self.lws.data_ptr(), self.lws.numel(), None, 0, stream)
-        else:
-            rc = self.lib.gptq_layer_forward(pl.handle, x.data_ptr(), pl.K, y.data_ptr(), pl.N, 1, self.lws.data_ptr(), self.lws.numel(), None, 0, stream)
+    def _layer(self, x, pl, y, stream):
+        """the product's ONE call site (include/gptq_mi355x.h "Prepared layers"): the M -> kernel table is inside"""
+        rc = self.lib.gptq_layer_forward(pl.handle, x.data_ptr(), pl.K, y.data_ptr(), pl.N, 1, self.lws.data_ptr(), self.lws.numel(), None, 0, stream)
         self.native.check(rc, 'gptq_layer_forward')
 
-    def _mm(self, x, L, name, y, stream, nxt=None):
+    def _mm(self, x, L, name, y, stream):
         w = L[name]
         if self.kernel == 'stripe':
-            return self._layer(x, L['pl_' + name], y, stream, nxt)
+            return self._layer(x, L['pl_' + name], y, stream)
         rc = self.lib.gptq_matmul248_f16(x.data_ptr(), w.K, w.qweight.data_ptr(), w.scales.data_ptr(), w.qzeros.data_ptr(),
                                          None, None, y.data_ptr(), w.N, 1, w.K, w.N, BITS, GS, self.ws.data_ptr(),
                                          self.ws.numel(), stream)
         self.native.check(rc, 'gptq_matmul248_f16')
 
-    def _mlp(self, x, L, y, stream, nxt=None):
+    def _mlp(self, x, L, y, stream):
         g, u = L['gate'], L['up']
         if self.kernel == 'stripe':
-            return self._layer(x, L['pl_mlp'], y, stream, nxt)
+            return self._layer(x, L['pl_mlp'], y, stream)
         rc = self.lib.gptq_fused_mlp_f16(x.data_ptr(), g.K, g.qweight.data_ptr(), g.scales.data_ptr(), g.qzeros.data_ptr(),
                                          None, u.qweight.data_ptr(), u.scales.data_ptr(), u.qzeros.data_ptr(), None,
                                          y.data_ptr(), g.N, 1, g.K, g.N, BITS, GS, self.ws.data_ptr(), self.ws.numel(), stream)
@@ -126,13 +120,11 @@ class DecodeLinears:
 
     def step(self):
         s = torch.cuda.current_stream().cuda_stream
-        st = self.kernel == 'stripe'
-        for i, L in enumerate(self.layers):
-            N = self.layers[(i + 1) % len(self.layers)]      # the pass repeats token after token: the last layer is followed by the first
-            self._mm(self.x_h, L, 'qkv', self.y_qkv, s, L['pl_o'] if st else None)
-            self._mm(self.x_h, L, 'o', self.y_h, s, L['pl_mlp'] if st else None)
-            self._mlp(self.x_h, L, self.y_i, s, L['pl_down'] if st else None)
-            self._mm(self.x_i, L, 'down', self.y_h, s, N['pl_qkv'] if st else None)
+        for L in self.layers:
+            self._mm(self.x_h, L, 'qkv', self.y_qkv, s)
+            self._mm(self.x_h, L, 'o', self.y_h, s)
+            self._mlp(self.x_h, L, self.y_i, s)
+            self._mm(self.x_i, L, 'down', self.y_h, s)
 
     def per_shape(self, reps=20):
         """event-timed launches per shape, rotating over the 32 layers' distinct weights (cold)."""
@@ -695,18 +687,27 @@ def decode_tokens_per_s(dev, tokens=64):
       drop_in_generate model.generate(...) as llama_inference.py:119-127 calls it
       engine_graph     quant.decode.DecodeEngine driven directly (one hipGraph replay per token)"""
     from quant.decode import build_random_llama, benchmark_decode, benchmark_decode_engine, benchmark_generate
+    import quant
     model = build_random_llama(dev)
     out = {'hf_eager': benchmark_decode(model, 24, engine_hook=False)}
+    # A/B leg first, on the untouched model: the engine next to BOTH copies of the packed weights (checkpoint buffers + stripe16 images;
+    # what GPTQ_RELEASE_CHECKPOINT=0 keeps).  Same kernels, same tokens/s: the difference is memory.
+    out['engine_graph_two_copies'] = benchmark_decode_engine(model, tokens=tokens, graph=True)
+    # the product's default from here on: the first decode step through the hook builds the engine and releases the checkpoint buffers
+    # (quant/engine_hook.py RELEASE_CHECKPOINT): ONE copy of the packed weights, like the reference's 4891 MiB for 7B 4-bit g128
+    # (README.md:26, protocol llama.py:426-438)
     out['drop_in_forward'] = benchmark_decode(model, tokens)
     out['drop_in_generate'] = benchmark_generate(model)
-    out['engine_graph'] = benchmark_decode_engine(model, tokens=tokens, graph=True)
+    st = getattr(model, '_gptq_engine_state', None)
+    if st is not None:         # the hook's engine (its own 1 GB K/V cache + graph) would sit next to the one measured below: one engine at a time
+        quant.engine_hook.flush_decode_engine(model)
+        st.engine, st.sig = None, None
+    torch.cuda.empty_cache()
+    done = sum(1 for m in model.modules() if getattr(m, '_released', None) is not None)
+    kept = sum(1 for m in model.modules() if isinstance(m, (quant.QuantLinear, quant.fused_mlp.QuantLlamaMLP)) and getattr(m, '_released', None) is None)
+    out['engine_graph'] = dict(benchmark_decode_engine(model, tokens=tokens, graph=True), released_modules=done, kept_modules=kept,
+                               reference_published_MiB=4891)
     out['tokens_per_s'] = out['engine_graph']['tokens_per_s']
-    # memory mode (quant.release_checkpoint / GPTQ_RELEASE_CHECKPOINT=1): ONE copy of the packed weights -- the stripe16 images -- like
-    # the reference's 4891 MiB for 7B 4-bit g128 (README.md:26, protocol llama.py:426-438); same kernels, same tokens/s
-    import quant
-    done, kept = quant.release_checkpoint(model)
-    out['engine_graph_memory_mode'] = dict(benchmark_decode_engine(model, tokens=tokens, graph=True), released_modules=done, kept_modules=kept,
-                                           reference_published_MiB=4891)
     return out
 
 

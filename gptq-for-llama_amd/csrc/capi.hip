@@ -375,11 +375,21 @@ static int run_auto(const Problem &q, hipStream_t s) {
     return run_skinny(q, s);
 }
 
+// debug hook: a device uint32 every stripe decode launch (M = 1) increments when it starts (tools/warmlab.hip B paces its run-ahead
+// prefetcher on it); NULL = no tick (the product never sets it)
+static std::atomic<uint32_t *> g_progress_counter{nullptr};
+uint32_t *stripe_progress_counter() { return g_progress_counter.load(std::memory_order_relaxed); }
+
 }  // namespace gptq
 
 using namespace gptq;
 
 extern "C" {
+
+int gptq_set_progress_counter(void *device_u32) {
+    g_progress_counter.store((uint32_t *)device_u32);
+    return 0;
+}
 
 int gptq_query(int what) {
     switch (what) {
@@ -589,10 +599,10 @@ int gptq_dequant_ld_f16(const int32_t *qweight, const void *scales, const int32_
 // route 1 (default) = the hand-written GEMM of gemm8.hip on the transposed dequantised weight; route 0 = hipBLASLt on the
 // dequantised weight (the reported ceiling; also the fallback for shapes gemm8 does not serve: K % 128 != 0 ...).
 static std::atomic<int> g_prefill_route{1};
-std::atomic<int> g_stripe_mm_pass_rows{128};
+std::atomic<int> g_stripe_mm_pass_rows{128};     // rows per pass of the 16-row MFMA tiles: 128, or 64 (round 2's schedule: A/B runs)
 // batches of 129 .. this many rows run the fused tile GEMM on the stripe16 image (0: never).  Measured crossover against the dense route
 // (tools/bench_mid_prefill.py, profiles/r3g_mid_m/mid_prefill.txt): 1.03-1.70x up to 1024 rows, 0.85-0.95x at 2048
-std::atomic<int> g_stripe_gemm_max_rows{1024};   // rows per pass of the 16-row MFMA tiles: 128, or 64 (round 2's schedule: A/B runs)
+std::atomic<int> g_stripe_gemm_max_rows{1024};
 namespace {
 // The tile GEMM works in 256 x 256 (pair: 256 x 128) output tiles, one per CU at a time: below one full round of tiles (or a
 // couple of thousand rows) a launch costs a whole tile's latency however small the batch, and the library's smaller tiles win
@@ -878,8 +888,7 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
 
 static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, float *y32,
                          int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
-                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false,
-                         const StripePrefetch *pf = nullptr) {
+                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
@@ -887,7 +896,7 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     const int gemm_max = g_stripe_gemm_max_rows.load();
     const bool gemm_rows = mm_ws && M > 128 && M <= gemm_max;
     if (gq == -2 || (M > (mm_ws ? 256 : 16) && !gemm_rows) || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
-    if (M > 1 && (norm_weight || perm || y32)) return GPTQ_E_VARIANT;
+    if (M > 1 && (norm_weight || perm || (y32 && M > 4))) return GPTQ_E_VARIANT;
     if (stripes_bytes < stripe_total_bytes(K, N, bits, groupsize, nsets)) return GPTQ_E_WORKSPACE;
     if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || !aligned(y32, 4) || (norm_weight && !aligned(norm_weight, 16)) ||
         (perm && !aligned(perm, 16)) || (M > 1 && (ldx % 8 != 0 || ldy < N)))
@@ -913,7 +922,6 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.gq_shift = gq;
     p.bits = bits;
     p.progress = M == 1 ? stripe_progress_counter() : nullptr;
-    if (pf && M == 1 && !mm_ws) p.pf = *pf;
     if (gemm_rows) {   // 2-D tiles, weights kept packed (stripe_gemm_kernel)
         int rc;
         switch (bits) {
@@ -953,6 +961,14 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
         return 0;
     }
     return stripe_gemv_dispatch(p, (hipStream_t)stream);
+}
+
+int gptq_stripe_matmul_partial_f32(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, float *y_partial, int M, int K, int N,
+                                   int bits, int groupsize, int nsets, gptq_stream_t stream) {
+    if (!y_partial) return GPTQ_E_NULL;
+    if (M < 1 || M > 4) return GPTQ_E_VARIANT;
+    return stripe_matvec(x, ldx, stripes, stripes_bytes, nullptr, nullptr, (int64_t)nsets * N, y_partial, M, K, N, bits, groupsize, nsets, nullptr, 0.f, nullptr,
+                         stream);
 }
 
 int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
@@ -1182,6 +1198,10 @@ size_t gptq_layer_workspace_bytes(void) { return WS_BYTES + STRIPE_MM_WS_BYTES; 
 /* transient scratch that gives forward(M) its fast route: the gathered x of an act-order batch, the per-call dequantised weight */
 size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M) {
     if (!layer || M <= 0) return 0;
+    // the fused tile GEMM on the image (129 .. gptq_set_stripe_gemm_max_rows() rows) needs no scratch beyond the gather of x for an
+    // act-order layer: no K * N dequantised copy per call on the prompt path.  Should that kernel decline at launch, the ladder goes on
+    // with what it was given (library-free kernels, or GPTQ_E_WORKSPACE for a released layer).
+    if (gptq_layer_route_for(layer, M) == GPTQ_ROUTE_STRIPE_GEMM) return layer->kind == 1 ? a256((size_t)M * layer->K * 2) : 0;
     const size_t unpack = (layer->released && M > 1) ? layer_unpacked_bytes(*layer) : 0;   // (M == 1 always runs on the image)
     if (M >= LAYER_PREFILL_MIN_M && (M > LAYER_STRIPE_MM_MAX_M || !layer->stripe)) return unpack + gptq_prefill_workspace_bytes(M, layer->K, layer->N, layer->nsets);
     return unpack + (layer->kind == 1 && M > 1 ? a256((size_t)M * layer->K * 2) : 0);
@@ -1216,39 +1236,8 @@ int gptq_layer_route_for(const gptq_layer_t *layer, int M) {
     return gptq_layer_route_for_shape(M, layer->K, layer->N, layer->bits, layer->groupsize, layer->nsets, layer->kind, layer->stripe != nullptr);
 }
 
-static int layer_forward_impl(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, size_t workspace_bytes,
-                              void *scratch, size_t scratch_bytes, gptq_stream_t stream, const StripePrefetch *pf);
-
 int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, size_t workspace_bytes,
                        void *scratch, size_t scratch_bytes, gptq_stream_t stream) {
-    return layer_forward_impl(layer, x, ldx, y, ldy, M, workspace, workspace_bytes, scratch, scratch_bytes, stream, nullptr);
-}
-
-// The decode chain knows which layer runs next: at M = 1 the launch of `layer` also touches the first head_kib KiB of every stripe of
-// `next` (capped by what two wave loads per wave of this launch cover), into the L2 of the XCD that will read them (stripe_kernel.inc, PF).
-// Anything the tail prefetch does not apply to (M > 1, no image on either side, a route other than the stripe decode kernel) behaves
-// exactly like gptq_layer_forward.
-int gptq_layer_forward_next(const gptq_layer_t *layer, const gptq_layer_t *next, int head_kib, const void *x, int64_t ldx, void *y, int64_t ldy, int M,
-                            void *workspace, size_t workspace_bytes, void *scratch, size_t scratch_bytes, gptq_stream_t stream) {
-    StripePrefetch pf{};
-    if (layer && next && M == 1 && head_kib > 0 && layer->stripe && next->stripe && (next->N / 16) % 8 == 0 && (layer->N / 16) % 8 == 0) {
-        const size_t toff = stripe_tab_offset(next->K, next->N, next->bits, next->nsets);
-        const uint32_t nstripes = (uint32_t)(next->N / 16), stripe_bytes = (uint32_t)(toff / nstripes);
-        const uint64_t capacity_kib = 2ull * (uint64_t)(layer->N / 16) * STRIPE_NW;   // two 1-KiB loads per wave of this launch
-        uint32_t lg = 0;
-        while ((2u << lg) <= (uint32_t)head_kib && (2u << lg) * 1024u <= stripe_bytes && (uint64_t)nstripes * (2u << lg) <= capacity_kib) lg++;
-        if ((1u << lg) * 1024u <= stripe_bytes && (uint64_t)nstripes * (1u << lg) <= capacity_kib * 2) {
-            pf.weights = (const char *)next->stripe;
-            pf.nstripes = nstripes;
-            pf.stripe_bytes = stripe_bytes;
-            pf.log2_head_kib = lg;
-        }
-    }
-    return layer_forward_impl(layer, x, ldx, y, ldy, M, workspace, workspace_bytes, scratch, scratch_bytes, stream, pf.weights ? &pf : nullptr);
-}
-
-static int layer_forward_impl(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, size_t workspace_bytes,
-                              void *scratch, size_t scratch_bytes, gptq_stream_t stream, const StripePrefetch *pf) {
     if (!layer) return GPTQ_E_NULL;
     const gptq_layer &L = *layer;
     if (M < 0 || ldx < L.K || ldy < L.N) return GPTQ_E_SHAPE;
@@ -1262,8 +1251,7 @@ static int layer_forward_impl(const gptq_layer_t *layer, const void *x, int64_t 
     // ---- 1. decode and small batches on the stripe16 image ----
     if (L.stripe && L.kind == 0) {
         if (M <= rows_max) {
-            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, nullptr, 0,
-                                         false, pf);
+            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream);
             if (rc != GPTQ_E_VARIANT) return rc;
         }
         if (M > 4 && M <= std::max(LAYER_STRIPE_MM_MAX_M, g_stripe_gemm_max_rows.load())) {   // ... 128 rows: 16-row tiles; above: the fused tile GEMM
@@ -1274,8 +1262,7 @@ static int layer_forward_impl(const gptq_layer_t *layer, const void *x, int64_t 
     }
     if (L.stripe && L.kind == 1) {
         if (M == 1) {   // the decode kernel gathers x through the permutation itself
-            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, 1, K, N, bits, gs, ns, nullptr, 0.f, L.perm16, stream, nullptr, 0,
-                                         false, pf);
+            const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, 1, K, N, bits, gs, ns, nullptr, 0.f, L.perm16, stream);
             if (rc != GPTQ_E_VARIANT) return rc;
         } else if (M <= std::max(LAYER_STRIPE_MM_MAX_M, g_stripe_gemm_max_rows.load()) && scratch && aligned(scratch, 16) && scratch_bytes >= (size_t)M * K * 2) {
             // batches: ONE gather of x, then the trivial-g_idx kernels on the image of the group-sorted rows

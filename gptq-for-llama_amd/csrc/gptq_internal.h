@@ -105,13 +105,6 @@ int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int 
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 
 // ---- stripe16: no-split-K GEMV on a load-time repacked copy (stripe.hip) ----
-// tail prefetch of the NEXT op's stripe heads by an M = 1 decode launch (stripe_kernel.inc, PF): weights == NULL: none
-struct StripePrefetch {
-    const char *weights;        // next op's R [nstripes][stripe_bytes]
-    uint32_t nstripes, stripe_bytes;
-    uint32_t log2_head_kib;     // KiB per stripe to touch = 1 << log2_head_kib (<= stripe_bytes / 1024)
-    uint32_t reserved;
-};
 struct StripeParams {
     const half_t *x;
     int64_t ldx, ldy;      // row strides of x / y (elements); M = 1: unused
@@ -122,10 +115,9 @@ struct StripeParams {
     const half_t *norm_w;  // non-NULL: RMS-normalise x while it is staged (M == 1)
     float norm_eps;
     const uint16_t *xperm; // non-NULL: x (and norm_w) gathered through this permutation (M == 1); uint16: K <= 24576 on this path
-    float *y32;            // non-NULL: store the fp32 sums here instead of fp16 y (no bias): partial of a K-sharded layer (M == 1)
+    float *y32;            // non-NULL: store the fp32 sums [M][NS][N] here instead of fp16 y (no bias): partial of a K-sharded layer (M <= 4)
     int M, K, N, G, NS, gq_shift, bits;
-    StripePrefetch pf;     // M == 1: see above
-    uint32_t *progress;    // non-NULL: the decode kernel adds 1 here when it starts (pacing of the run-ahead prefetcher, prefetch.hip)
+    uint32_t *progress;    // non-NULL: the decode kernel adds 1 here when it starts (debug hook gptq_set_progress_counter)
 };
 int stripe_gq_shift(int K, int N, int bits, int groupsize);            // log2(groupsize / (4 KPW)), -1 one group, -2 ineligible
 size_t stripe_tab_offset(int K, int N, int bits, int nsets);
@@ -133,7 +125,7 @@ size_t stripe_total_bytes(int K, int N, int bits, int groupsize, int nsets);
 int stripe_repack_launch(const uint32_t *qw0, const half_t *sc0, const int32_t *qz0, const uint32_t *qw1, const half_t *sc1,
                          const int32_t *qz1, void *out, int K, int N, int bits, int groupsize, hipStream_t s);
 int stripe_gemv_dispatch(const StripeParams &p, hipStream_t s);
-uint32_t *stripe_progress_counter();   // prefetch.hip: gptq_set_progress_counter (NULL by default)
+uint32_t *stripe_progress_counter();   // capi.hip: gptq_set_progress_counter (NULL by default)
 // inverse of stripe_repack_launch for ONE set (bits 2 / 4 / 8): qweight [K/32*bits][N], scales [G][N], qzeros [G][N/32*bits]
 int stripe_unpack_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, int set, uint32_t *qw, half_t *sc, int32_t *qz,
                          hipStream_t s);

@@ -22,7 +22,7 @@ del _mod, _names, _n
 
 
 def release_checkpoint(model):
-    """Memory mode for a whole model (extension; GPTQ_RELEASE_CHECKPOINT=1 applies it when the decode engine is first built): every
+    """Memory mode for a whole model (extension; applied when the decode engine is first built unless GPTQ_RELEASE_CHECKPOINT=0): every
     QuantLinear / QuantLlamaMLP whose decode path runs on its stripe16 image frees qweight / scales / qzeros and keeps that ONE copy
     of the packed weights -- the footprint the reference quotes (README.md:23-29: 4891 MiB for 7B 4-bit g128) instead of two
     copies.  ``state_dict()`` is unchanged (tensors reproduced bit-exactly from the images).  Returns (released, kept) counts."""

@@ -115,9 +115,7 @@ _SIGNATURES = {
     'gptq_layer_scratch_bytes': [c_void_p, c_int],
     'gptq_layer_forward': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p],
     'gptq_set_progress_counter': [c_void_p],
-    'gptq_prefetch_describe': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    'gptq_prefetch_launch': [c_void_p, c_int, c_int, c_void_p, ctypes.c_uint32, c_int, c_int, c_int, c_int, c_int, ctypes.c_uint32, c_void_p, c_void_p],
-    'gptq_layer_forward_next': [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p],
+    'gptq_stripe_matmul_partial_f32': [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'gptq_stripe_matvec_partial_f32': [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
 }
 

@@ -188,28 +188,11 @@ class DecodeEngine:
             attn, mlp = layer.self_attn, layer.mlp
             if not isinstance(attn, fused_attn.QuantLlamaAttention) or not isinstance(mlp, fused_mlp.QuantLlamaMLP):
                 raise RuntimeError('DecodeEngine needs make_quant_attn / make_fused_mlp applied first')
-            if getattr(mlp, '_released', None) is not None:     # memory mode: the pair's image is the only copy of gate / up
-                gpack = self._released_pack(mlp._released, mlp.bits, mlp.groupsize, mlp.infeatures, mlp.intermediate_size, None)
-                upack = dict(gpack)
-            else:
-                gpack = self._pack_raw(mlp.gate_proj_qweight, mlp.gate_proj_scales, mlp.gate_proj_qzeros, mlp.gate_proj_g_idx,
-                                       mlp.bits, mlp.groupsize, mlp.infeatures, mlp.intermediate_size)
-                upack = self._pack_raw(mlp.up_proj_qweight, mlp.up_proj_scales, mlp.up_proj_qzeros, mlp.up_proj_g_idx, mlp.bits,
-                                       mlp.groupsize, mlp.infeatures, mlp.intermediate_size)
+            gpack, upack = self._pack_pair(mlp)
             self.layers.append(dict(
                 ln1=layer.input_layernorm.weight, ln2=layer.post_attention_layernorm.weight,
                 qkv=self._pack(attn.qkv_proj), o=self._pack(attn.o_proj), down=self._pack(mlp.down_proj),
                 gate=gpack, up=upack, theta=float(attn.rope_theta)))
-            L = self.layers[-1]   # gate and up share their input, hence (normally) their act-order permutation: checked ONCE here
-            g, u = L['gate'], L['up']
-            if getattr(mlp, '_released', None) is not None:
-                g['pair_sorted'], g['st2'], g['st'] = False, mlp._released.stripe, None
-                continue
-            g['pair_sorted'] = (g['srt'] is not None and u['srt'] is not None and bool(torch.equal(g['srt'][1], u['srt'][1])))
-            g['st2'] = None     # gate and up in ONE stripe16 image (silu(gate) * up in the kernel epilogue)
-            if g['bits'] in (2, 3, 4, 8) and ((g['gi'] is None and u['gi'] is None) or g['pair_sorted']):
-                a, b = (g['srt'][0], u['srt'][0]) if g['pair_sorted'] else (g['qw'], u['qw'])
-                g['st2'] = quant_linear.stripe_copy(a, g['sc'], g['qz'], g['bits'], g['gs'], up=(b, u['sc'], u['qz']))
         H, I = self.hidden, cfg.intermediate_size
         f16 = dict(dtype=torch.float16, device=dev)
         self.ids = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -231,27 +214,61 @@ class DecodeEngine:
         self.ws = _native.workspace(dev)
         self.graph = None
 
-    def _pack_raw(self, qweight, scales, qzeros, g_idx, bits, groupsize, K, N, bias=None):
+    # -- weights: the engine reads the SAME derived copy as the modules -------------------------------------------------------
+    # Every linear is taken from quant/layer.py prepared() with exactly the arguments the module's own forward uses, so the eager
+    # path (prefill, anything the hook declines) and the engine share ONE PreparedLayer: one stripe16 image per layer next to the
+    # checkpoint buffers -- not the three or four copies of round 3 (module image + the engine's own stripe_copy of every linear +
+    # single-set images of gate and up next to the pair's).
+    def _from_prepared(self, pl, qweight, scales, qzeros, g_idx, bits, gs, K, N, bias):
         gi = None
-        if g_idx is not None and not quant_linear.g_idx_is_trivial(g_idx, K, groupsize):
+        if pl.kind != 0 and g_idx is not None and qweight is not None:
             gi = quant_linear._int32c(g_idx[:K])
-        qw = quant_linear._int32c(qweight)
-        srt = quant_linear.act_order_sorted(qw, gi, K, groupsize, bits) if (gi is not None and bits in (2, 4, 8)) else None
-        qz = quant_linear._int32c(qzeros)
-        # stripe16 image (csrc/stripe.hip) of the layer, or of its group-sorted rows for an act-order layer: the decode kernel
-        st = quant_linear.stripe_copy(srt[0] if srt is not None else qw, scales, qz, bits, groupsize) if (gi is None or srt is not None) else None
-        return dict(qw=qw, sc=scales, qz=qz, gi=gi, bits=bits, gs=groupsize, K=K, N=N, bias=bias, srt=srt, st=st)
+        st = pl.stripe
+        srt = None
+        if st is None and gi is not None and bits in (2, 4, 8):      # no image (GPTQ_STRIPE=0, odd shapes): the sorted-copy kernels
+            srt = quant_linear.act_order_sorted(quant_linear._int32c(qweight), gi, K, gs, bits)
+        released = qweight is None or qweight.shape[0] == 0
+        return dict(qw=None if released else quant_linear._int32c(qweight), sc=None if released else scales,
+                    qz=None if released else quant_linear._int32c(qzeros), gi=gi, bits=bits, gs=gs, K=K, N=N, bias=bias, srt=srt, st=st,
+                    perm=pl.perm16 if st is not None else None, _keep=pl)
 
-    @staticmethod
-    def _released_pack(pl, bits, groupsize, K, N, bias):
-        """a module in memory mode (release_checkpoint): its PreparedLayer's image is all there is -- and all the decode kernels need"""
-        return dict(qw=None, sc=None, qz=None, gi=None, bits=bits, gs=groupsize, K=K, N=N, bias=bias, srt=None, st=pl.stripe, _keep=pl)
+    def _pack_raw(self, qweight, scales, qzeros, g_idx, bits, groupsize, K, N, bias=None):
+        from .layer import prepared
+        gs = groupsize if groupsize != -1 else K
+        pl = prepared(((qweight, scales, qzeros, g_idx),), bias, bits, gs, K, N, sort=quant_linear.ACT_ORDER_SORT)
+        return self._from_prepared(pl, qweight, scales, qzeros, g_idx, bits, gs, K, N, bias)
 
     def _pack(self, ql):
-        if getattr(ql, '_released', None) is not None:
-            return self._released_pack(ql._released, ql.bits, ql.groupsize, ql.infeatures, ql.outfeatures, ql.bias)
-        return self._pack_raw(ql.qweight, ql.scales, ql.qzeros, ql.g_idx, ql.bits, ql.groupsize, ql.infeatures, ql.outfeatures,
-                              ql.bias)
+        if getattr(ql, '_released', None) is not None:   # memory mode: the PreparedLayer's image is all there is -- and all the decode kernels need
+            return self._from_prepared(ql._released, None, None, None, None, ql.bits, ql.groupsize, ql.infeatures, ql.outfeatures, ql.bias)
+        return self._pack_raw(ql.qweight, ql.scales, ql.qzeros, ql.g_idx, ql.bits, ql.groupsize, ql.infeatures, ql.outfeatures, ql.bias)
+
+    def _pack_pair(self, mlp):
+        """gate and up of a QuantLlamaMLP: ONE PreparedLayer of the pair (the one mlp.hip_llama_mlp uses) -- its image holds both sets,
+        of the group-sorted rows when the two share an act-order permutation."""
+        from .layer import prepared
+        K, N, bits = mlp.infeatures, mlp.intermediate_size, mlp.bits
+        gs = mlp.groupsize if mlp.groupsize != -1 else K
+        if getattr(mlp, '_released', None) is not None:
+            pl = mlp._released
+            g = self._from_prepared(pl, None, None, None, None, bits, gs, K, N, None)
+            u = dict(g)
+        else:
+            gate = (mlp.gate_proj_qweight, mlp.gate_proj_scales, mlp.gate_proj_qzeros, mlp.gate_proj_g_idx)
+            up = (mlp.up_proj_qweight, mlp.up_proj_scales, mlp.up_proj_qzeros, mlp.up_proj_g_idx)
+            pl = prepared((gate, up), None, bits, gs, K, N, sort=quant_linear.ACT_ORDER_SORT)
+            g = self._from_prepared(pl, *gate, bits, gs, K, N, None)
+            u = self._from_prepared(pl, *up, bits, gs, K, N, None)
+        g['st2'], g['perm2'] = pl.stripe, (pl.perm16 if pl.stripe is not None else None)
+        g['st'] = u['st'] = None          # the pair's image is not a single-set image
+        g['perm'] = u['perm'] = None
+        g['pair_sorted'] = False
+        if g['st2'] is None and g['gi'] is not None and u['gi'] is not None and bits in (2, 4, 8):
+            # no image: gate and up share their input, hence (normally) their act-order permutation -- checked ONCE here
+            for w in (g, u):
+                w['srt'] = quant_linear.act_order_sorted(w['qw'], w['gi'], K, gs, bits)
+            g['pair_sorted'] = g['srt'] is not None and u['srt'] is not None and bool(torch.equal(g['srt'][1], u['srt'][1]))
+        return g, u
 
     # -- launches ------------------------------------------------------------------------------
     def _gemv(self, x, w, y, s, residual=None):
@@ -260,8 +277,7 @@ class DecodeEngine:
         b = residual if residual is not None else w['bias']
         ptr = self.native.ptr
         if w['st'] is not None:       # stripe16: no K split, no workspace (act-order: x gathered through perm in the kernel)
-            quant_linear.stripe_matvec(x, w['st'], y, w['K'], w['N'], w['bits'], w['gs'], bias=b,
-                                       perm=w['srt'][1] if w['srt'] is not None else None)
+            quant_linear.stripe_matvec(x, w['st'], y, w['K'], w['N'], w['bits'], w['gs'], bias=b, perm=w['perm'])
             return
         if w['srt'] is not None:      # act-order layer: group-sorted copy + fused x gather
             qs, perm = w['srt']
@@ -283,8 +299,7 @@ class DecodeEngine:
         """y = QuantLinear(rmsnorm(x)): one launch when the fused kernel serves the shape, else two."""
         ptr = self.native.ptr
         if self.fuse_norm and w['st'] is not None:      # RMSNorm fused into the staging of x (every workgroup sees all of x)
-            quant_linear.stripe_matvec(x, w['st'], y, w['K'], w['N'], w['bits'], w['gs'], bias=w['bias'], norm_weight=nw, eps=self.eps,
-                                       perm=w['srt'][1] if w['srt'] is not None else None)
+            quant_linear.stripe_matvec(x, w['st'], y, w['K'], w['N'], w['bits'], w['gs'], bias=w['bias'], norm_weight=nw, eps=self.eps, perm=w['perm'])
             return
         if self.fuse_norm and w['bias'] is None and w['srt'] is not None:      # act-order: norm + gather + GEMV in one launch
             qs, perm = w['srt']
@@ -307,7 +322,7 @@ class DecodeEngine:
     def _norm_mlp(self, x, nw, g, u, c, s):
         ptr = self.native.ptr
         if g.get('st2') is not None:
-            perm = g['srt'][1] if g.get('pair_sorted') else None
+            perm = g['perm2']
             if self.fuse_norm:
                 quant_linear.stripe_matvec(x, g['st2'], c, g['K'], g['N'], g['bits'], g['gs'], nsets=2, norm_weight=nw, eps=self.eps, perm=perm)
             else:

@@ -32,7 +32,11 @@ import weakref
 import torch
 
 ENABLED = os.environ.get('GPTQ_DECODE_ENGINE', '1') != '0'
-RELEASE_CHECKPOINT = os.environ.get('GPTQ_RELEASE_CHECKPOINT', '0') == '1'
+# Memory mode is the DEFAULT since round 4: when the engine is first built every eligible module (trivial g_idx, 2 / 4 / 8 bits, an image)
+# frees qweight / scales / qzeros and runs on its stripe16 image alone -- ONE copy of the packed weights, the footprint the reference
+# publishes (README.md:23-29).  state_dict() / load_state_dict() / .to() / copy.deepcopy see the original tensors (reproduced bit-exactly
+# from the image; a move or copy restores them first).  GPTQ_RELEASE_CHECKPOINT=0 keeps both copies (e.g. to read module.qweight).
+RELEASE_CHECKPOINT = os.environ.get('GPTQ_RELEASE_CHECKPOINT', '1') != '0'
 
 
 class _State:

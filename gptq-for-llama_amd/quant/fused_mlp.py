@@ -85,10 +85,12 @@ class QuantLlamaMLP(nn.Module):
             return True
         if not self.gate_proj_qweight.is_cuda:
             return False
+        from . import quant_linear
         from .layer import prepared
         pl = prepared(((self.gate_proj_qweight, self.gate_proj_scales, self.gate_proj_qzeros, self.gate_proj_g_idx),
                        (self.up_proj_qweight, self.up_proj_scales, self.up_proj_qzeros, self.up_proj_g_idx)), None, self.bits,
-                      self.groupsize if self.groupsize != -1 else self.infeatures, self.infeatures, self.intermediate_size)
+                      self.groupsize if self.groupsize != -1 else self.infeatures, self.infeatures, self.intermediate_size,
+                      sort=quant_linear.ACT_ORDER_SORT)
         if not pl.release():
             return False
         self._released = pl
@@ -105,6 +107,14 @@ class QuantLlamaMLP(nn.Module):
             for i, p in enumerate(('gate_proj_', 'up_proj_')):
                 qw, sc, qz = pl.unpack(i)
                 setattr(self, p + 'qweight', qw), setattr(self, p + 'scales', sc), setattr(self, p + 'qzeros', qz)
+
+    def _apply(self, fn, *args, **kwargs):        # see QuantLinear._apply: a released pair comes back before it moves / is copied
+        self.restore_checkpoint()
+        return super()._apply(fn, *args, **kwargs)
+
+    def __getstate__(self):
+        self.restore_checkpoint()
+        return super().__getstate__() if hasattr(super(), '__getstate__') else self.__dict__
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         super()._save_to_state_dict(destination, prefix, keep_vars)

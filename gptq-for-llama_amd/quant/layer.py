@@ -47,7 +47,8 @@ class PreparedLayer:
         self.device = dev
         # everything the handle borrows except the registry key (sets[0][0]: a strong reference to the key would keep the entry alive
         # for ever); the caller of forward() holds that tensor anyway
-        self._keep = [t for s in sets for t in s[1:]] + [s[0] for s in sets[1:]] + [bias]
+        self._keep = [t for s in sets for t in s[1:]] + [s[0] for s in sets[1:]]
+        self._bias = bias        # read by the handle for as long as it lives (also after release())
         ptr = _native.ptr
         s0, s1 = sets[0], (sets[1] if len(sets) > 1 else (None, None, None, None))
         stream = _native.stream_ptr(dev)
@@ -92,8 +93,7 @@ class PreparedLayer:
         layers that need the checkpoint layout: act-order, 3-bit, no image."""
         if self.lib.gptq_layer_release_checkpoint(self.handle) != 0:
             return False
-        bias = self._keep[-1] if self._keep else None      # the handle still reads the bias
-        self._keep = [bias]
+        self._keep = []          # incl. a converted copy of the key tensor prepared() may have parked here; the bias lives in self._bias
         self.released = True
         return True
 

@@ -25,8 +25,9 @@ class P2PAllReduce:
 
     def __init__(self, n_max, group=None, device=None):
         import torch.distributed as dist
-        if os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0') != '0':
-            raise RuntimeError('P2PAllReduce: HSA_ENABLE_IPC_MODE_LEGACY must be 0 (dmabuf IPC) in the environment of the process start')
+        if os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') != '0':     # absent counts as wrong: the runtime's default is the legacy mode
+            raise RuntimeError('P2PAllReduce: HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) must be in the environment when the process starts '
+                               '(found %r); the peer mappings cannot be opened otherwise' % os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))
         self.lib = _native.lib()
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)

@@ -146,6 +146,8 @@ def perm_u16(perm):
     K <= 24576 on that path).  None stays None."""
     if perm is None:
         return None
+    if perm.dtype == torch.int16:      # already narrowed (PreparedLayer.perm16)
+        return perm
     p16 = _U16.get(perm)
     if p16 is None:
         p16 = perm.to(torch.int16)          # bit pattern of the uint16 value: every index is below 32768
@@ -474,7 +476,8 @@ class QuantLinear(nn.Module):
             return True
         if not self.qweight.is_cuda:
             return False
-        pl = prepared(((self.qweight, self.scales, self.qzeros, self.g_idx),), self.bias, self.bits, self.groupsize, self.infeatures, self.outfeatures)
+        pl = prepared(((self.qweight, self.scales, self.qzeros, self.g_idx),), self.bias, self.bits, self.groupsize, self.infeatures, self.outfeatures,
+                      sort=ACT_ORDER_SORT)     # the SAME registry entry forward() uses (a different `sort` would build a second image)
         if not pl.release():
             return False
         self._released = pl
@@ -489,6 +492,16 @@ class QuantLinear(nn.Module):
         if self._released is not None:
             pl, self._released = self._released, None
             self.qweight, self.scales, self.qzeros = pl.unpack(0)
+
+    # a released module holds a device image and a C handle that neither move nor pickle: anything that moves / casts / copies the
+    # module (.to(), .cpu(), .half(), copy.deepcopy, pickling) first brings the checkpoint buffers back
+    def _apply(self, fn, *args, **kwargs):
+        self.restore_checkpoint()
+        return super()._apply(fn, *args, **kwargs)
+
+    def __getstate__(self):
+        self.restore_checkpoint()
+        return super().__getstate__() if hasattr(super(), '__getstate__') else self.__dict__
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         super()._save_to_state_dict(destination, prefix, keep_vars)
@@ -507,6 +520,7 @@ class QuantLinear(nn.Module):
         (quant/quant_linear.py:325-371) -- incl. the division by the fp16-rounded scale, the
         unmasked OR and ``zeros - 1`` -- vectorised on the host, or on the GPU
         (``gptq_pack_f32``) when the layer lives there."""
+        self._released = None      # a repacked module starts over on fresh buffers
         self.g_idx = g_idx.clone() if g_idx is not None else self.g_idx
         W = linear.weight.data
         if linear.bias is not None:

@@ -96,11 +96,13 @@ def _default_matmul(x2, s):
 
 
 def _default_partial(x2, s):
-    """fp32 partial [M, N] of a K-shard: the stripe16 kernel stores its fp32 sums unrounded at M == 1
-    (gptq_stripe_matvec_partial_f32); other shapes go through the fp16 kernels (one extra rounding per shard)."""
+    """fp32 partial [M, N] of a K-shard: the stripe16 decode kernel stores its fp32 sums unrounded for up to four rows
+    (gptq_stripe_matvec_partial_f32 at M == 1, gptq_stripe_matmul_partial_f32 for 2..4 rows -- an act-order shard gathers x[:, perm]
+    first); larger batches go through the fp16 kernels (one extra rounding per shard)."""
     from . import _native
     from .quant_linear import _as_rows, _int32c, act_order_sorted, perm_u16, stripe_copy
-    if x2.shape[0] == 1 and s.bits in (2, 3, 4, 8) and x2.is_cuda:
+    M = x2.shape[0]
+    if 1 <= M <= 4 and s.bits in (2, 3, 4, 8) and x2.is_cuda:
         K, N = s.qweight.shape[0] * 32 // s.bits, s.qweight.shape[1]
         gs = s.groupsize if s.groupsize != -1 else K
         qw, perm = _int32c(s.qweight), None
@@ -109,13 +111,21 @@ def _default_partial(x2, s):
             qw, perm = (srt if srt is not None else (None, None))
         st = stripe_copy(qw, s.scales, _int32c(s.qzeros), s.bits, gs) if qw is not None else None
         if st is not None:
-            x = _as_rows(x2)
-            with torch.cuda.device(x.device):
-                part = torch.empty((1, N), dtype=torch.float32, device=x.device)
-                rc = _native.lib().gptq_stripe_matvec_partial_f32(x.data_ptr(), st.data_ptr(), st.numel(), part.data_ptr(), K, N, s.bits, gs, 1,
-                                                                  _native.ptr(perm_u16(perm)), _native.stream_ptr(x.device))
-            _native.check(rc, 'gptq_stripe_matvec_partial_f32')
-            return part
+            lib = _native.lib()
+            with torch.cuda.device(x2.device):
+                part = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+                if M == 1:
+                    x = _as_rows(x2)
+                    rc = lib.gptq_stripe_matvec_partial_f32(x.data_ptr(), st.data_ptr(), st.numel(), part.data_ptr(), K, N, s.bits, gs, 1,
+                                                            _native.ptr(perm_u16(perm)), _native.stream_ptr(x.device))
+                else:
+                    x = _as_rows(x2 if perm is None else x2[:, perm.long()])
+                    rc = lib.gptq_stripe_matmul_partial_f32(x.data_ptr(), x.stride(0), st.data_ptr(), st.numel(), part.data_ptr(), M, K, N, s.bits, gs, 1,
+                                                            _native.stream_ptr(x.device))
+            if rc == 0:
+                return part
+            if rc != -6:    # GPTQ_E_VARIANT: the row groups do not fit (K too long for four rows of x in LDS) -> the fp16 kernels below
+                _native.check(rc, 'gptq_stripe_matmul_partial_f32')
     return matmul248(x2, s.qweight, s.scales, s.qzeros, s.g_idx, s.bits, s.maxq).float()
 
 

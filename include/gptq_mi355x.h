@@ -99,6 +99,9 @@ int gptq_prefill_plan_count(void);
 /* Development aid: when non-NULL, the decode kernels write per-wave s_memtime checkpoints
  * ([block][wave][8] uint64) into this device buffer.  Returns the previous pointer. */
 void *gptq_set_debug_buffer(void *device_buffer);
+/* debug hook: device uint32 that every stripe16 decode launch (M = 1) increments (one relaxed device-scope add) when it starts; NULL
+ * (default) = no tick.  Used by tools/warmlab.hip to pace a run-ahead prefetcher on a second stream (measured, loses: DESIGN 3.6). */
+int gptq_set_progress_counter(void *device_u32);
 
 /*
  * y = x . deq(B) (+ bias)  -- reference matmul248() + matmul_248_kernel + the bias add in
@@ -342,6 +345,11 @@ int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size
  * complete sums). */
 int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t stripes_bytes, float *y_partial, int K, int N, int bits,
                                    int groupsize, int nsets, const uint16_t *perm, gptq_stream_t stream);
+/* The same for 1 <= M <= 4 rows of x (row stride ldx): y_partial is fp32 [M][nsets][N] -- the row groups of the decode kernel cost the
+ * weight stream of one row, so a K-shard of a small decode batch keeps the one-rounding-after-the-reduce order of M = 1 (trivial g_idx
+ * only: gather x[:, perm] first for a group-sorted act-order image). */
+int gptq_stripe_matmul_partial_f32(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, float *y_partial, int M, int K, int N,
+                                   int bits, int groupsize, int nsets, gptq_stream_t stream);
 /* Batches on the same image (csrc/stripe_mm.inc).  1 <= M <= 128 (to 256 in passes of 128): 16-row MFMA tiles (v_mfma_f32_16x16x32_f16) on exactly
  * dequantised q - z, fp32 group scales; either one launch (a stripe x whole K per workgroup, x streamed through LDS) or K slices
  * (128 columns x one slice per workgroup) that meet through fp32 partial tiles in `workspace` and a reduce kernel (summed in
@@ -356,31 +364,6 @@ int gptq_stripe_matvec_partial_f32(const void *x, const void *stripes, size_t st
  * quant/quant_linear.py:103-137, :415-419; nsets = 2: quant/fused_mlp.py:128-168 (no bias). */
 int gptq_stripe_matmul_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
                            int K, int N, int bits, int groupsize, int nsets, void *workspace, size_t workspace_bytes, gptq_stream_t stream);
-
-/* ---- run-ahead weight prefetcher for the batch-1 decode chain (csrc/prefetch.hip; round 4) ---------------------------------------
- * New functionality; the reference has no counterpart (its decode step is a chain of Triton launches, quant/quant_linear.py:263-269
- * called per module).  A decode pass is a chain of DEPENDENT launches and HBM idles across every boundary between them; the weights
- * do not depend on the chain, so a second stream may pull them into the Infinity Cache / the consuming XCD's L2 ahead of time.
- *   gptq_prefetch_describe   fills one plan entry from a stripe16 image (host-side arithmetic only; GPTQ_E_VARIANT: no image layout for
- *                            the shape, or N / 16 not a multiple of the 8 XCDs)
- *   gptq_set_progress_counter  device uint32 that every stripe decode launch increments (one relaxed device-scope add by one lane)
- *                            when it starts; NULL (default) = no tick.  Process-wide; set it before capturing a graph.
- *   gptq_prefetch_launch     ONE persistent launch that walks plan[first, last): entry j is touched once
- *                            *progress - progress_base + lead >= j (progress == NULL: unpaced), head_kib KiB per stripe (0 = all of
- *                            it) + the stripe's table, with LDS-DMA loads whose data nobody reads.  8 * blocks_per_xcd workgroups of
- *                            4 waves, `depth` (4 / 8 / 16 / 32) KiB in flight per wave.  It never blocks the chain: every wait is
- *                            bounded by spin_limit polls, after which the workgroup exits (and adds 1 to *status if given).
- * The plan (array of gptq_prefetch_op_t) lives in device memory; the entries' pointers are device pointers. */
-typedef struct gptq_prefetch_op {
-    const void *weights;          /* R  [nstripes][stripe_bytes]        */
-    const void *table;            /* tab [nstripes][table_stripe_bytes]  */
-    uint32_t nstripes, stripe_bytes, table_stripe_bytes, reserved;
-} gptq_prefetch_op_t;
-int gptq_set_progress_counter(void *device_u32);
-int gptq_prefetch_describe(const void *stripes, int K, int N, int bits, int groupsize, int nsets, gptq_prefetch_op_t *op);
-int gptq_prefetch_launch(const gptq_prefetch_op_t *plan_device, int first, int last, const void *progress_device, uint32_t progress_base, int lead,
-                         int head_kib, int blocks_per_xcd, int depth, int affinity, uint32_t spin_limit, void *status_device,
-                         gptq_stream_t stream);
 
 /* ---- one-shot all-reduce for the row-sharded layout (BASELINE config 5; csrc/p2p.hip) ------------------------------
  * New functionality (the reference has no collective: llama.py:328-382 is layer placement).  The fp32 partials of a
@@ -444,13 +427,6 @@ size_t gptq_layer_workspace_bytes(void);
 size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M);
 int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace,
                        size_t workspace_bytes, void *scratch, size_t scratch_bytes, gptq_stream_t stream);
-/* gptq_layer_forward for a caller that knows the chain (a decode step: qkv -> o -> gate/up -> down -> next layer's qkv ...): at M = 1
- * the launch of `layer` also pulls the first head_kib KiB (rounded down to a power of two, capped by what the launch can cover with two
- * wave loads per wave) of every stripe of `next` into the L2 of the XCD that will read it, behind its own weight stream, so that the
- * HBM pipe stays busy through the launch's reduce / store tail and `next` starts on resident bytes.  Pure performance hint: results are
- * those of gptq_layer_forward; next == NULL, head_kib == 0, M > 1 or layers without a stripe16 image fall through to it. */
-int gptq_layer_forward_next(const gptq_layer_t *layer, const gptq_layer_t *next, int head_kib, const void *x, int64_t ldx, void *y, int64_t ldy, int M,
-                            void *workspace, size_t workspace_bytes, void *scratch, size_t scratch_bytes, gptq_stream_t stream);
 /* The M -> kernel table of gptq_layer_forward as a host-only query (no launch, no GPU needed): the kernel family a batch of M rows takes,
  * assuming the caller passes gptq_layer_scratch_bytes() of scratch.  It replaces what the reference's Autotuner decides at run time
  * (quant/custom_autotune.py:76-102) by something a caller can read.  A kernel may still decline at launch (LDS limits) and hand the

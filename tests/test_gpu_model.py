@@ -313,7 +313,12 @@ def test_decode_engine_act_order_checkpoint():
     ids = torch.randint(0, HD128['vocab_size'], (1, 8), device=DEV, generator=gen)
     expect = run_steps(q, ids, 1)
     eng = D.DecodeEngine(q, t_max=64).capture()
-    assert all(L['gate'].get('pair_sorted') and L['qkv']['srt'] is not None and L['o']['srt'] is not None for L in eng.layers)
+    # every linear runs on the image of its group-sorted rows + the narrowed permutation -- the modules' own PreparedLayer, not a second copy
+    assert all(L['gate']['st2'] is not None and L['gate']['perm2'] is not None and L['qkv']['st'] is not None and L['qkv']['perm'] is not None and
+               L['o']['perm'] is not None and L['down']['perm'] is not None for L in eng.layers)
+    import quant.layer
+    a0 = q.model.layers[0].self_attn
+    assert eng.layers[0]['qkv']['_keep'] is quant.layer._LAYERS.get(a0.qkv_proj.qweight)[1]
     got = np.stack([eng.decode(ids[0, i]).float().cpu().numpy()[0] for i in range(ids.shape[1])])[:, None, :]
     within('engine_act_order', np.abs(got - expect).max() / np.abs(expect).max(), ENGINE_TOL)
 

@@ -700,7 +700,8 @@ def decode_tokens_per_s(dev, tokens=64):
     out['drop_in_generate'] = benchmark_generate(model)
     st = getattr(model, '_gptq_engine_state', None)
     if st is not None:         # the hook's engine (its own 1 GB K/V cache + graph) would sit next to the one measured below: one engine at a time
-        quant.engine_hook.flush_decode_engine(model)
+        from quant.engine_hook import flush_decode_engine
+        flush_decode_engine(model)
         st.engine, st.sig = None, None
     torch.cuda.empty_cache()
     done = sum(1 for m in model.modules() if getattr(m, '_released', None) is not None)

@@ -501,9 +501,10 @@ def small_batch_leg(dev):
 
 
 def prompt_leg(dev):
-    """A single request's prompt (reported only): batches of 256 / 512 / 1024 rows through gptq_layer_forward on the LLaMA-7B shapes --
-    the fused-dequantise tile GEMM on the stripe16 image (csrc/stripe_mm.inc stripe_gemm_kernel, the product for 129 .. 1024 rows)
-    against the dense route (dequantise per call + gemm8 / hipBLASLt) on the same prepared layer; us per call from a hipGraph of 8
+    """A single request's prompt (reported only): batches of 256 .. 3072 rows through gptq_layer_forward on the LLaMA-7B shapes -- the
+    fused-dequantise tile GEMM on the stripe16 image (csrc/stripe_mm.inc stripe_gemm_kernel, the product for 129 .. 2048 rows), above
+    that dequantise per call + the own tile GEMM (csrc/gemm8.hip) -- against the dense route forced, and against hipBLASLt (reported
+    ceiling: since round 4 the default route never reaches the library for K % 128 == 0) on the same prepared layer; us per call from a hipGraph of 8
     calls, TFLOP/s = 2 M N K / t (reference kernel for every M: quant_linear.py:72-137, fused_mlp.py:84-168)."""
     from quant import _native, layer as QLayer
     lib = _native.lib()
@@ -532,15 +533,21 @@ def prompt_leg(dev):
         sets = tuple((w.qweight, w.scales, w.qzeros, None) for w in (PackedSet(K, N, dev, gen), PackedSet(K, N, dev, gen))[:2 if pair else 1])
         pl = QLayer.PreparedLayer(sets, None, BITS, GS, K, N)
         row = {}
-        for M in (256, 512, 1024):
+        for M in (256, 512, 1024, 2048, 3072):
             x = torch.randn((M, K), device=dev, generator=gen).half()
             y = torch.empty((M, N), dtype=torch.float16, device=dev)
             prev = lib.gptq_set_stripe_gemm_max_rows(0)
-            t_dense = timed(lambda: pl.forward(x, y))
+            t_dense = timed(lambda: pl.forward(x, y))              # dequantise per call + the own tile GEMM (csrc/gemm8.hip)
+            prev_route = lib.gptq_set_prefill_route(0)
+            t_lib = timed(lambda: pl.forward(x, y))                # dequantise per call + hipBLASLt: the reported ceiling, off the default route
+            lib.gptq_set_prefill_route(prev_route)
             lib.gptq_set_stripe_gemm_max_rows(prev)
-            t = timed(lambda: pl.forward(x, y))
+            route = lib.gptq_layer_route_for(pl.handle, M)
+            t = timed(lambda: pl.forward(x, y))                    # the product's own choice
             fl = (4.0 if pair else 2.0) * M * N * K
-            row['M%d' % M] = {'us': round(t, 1), 'TFLOPs': round(fl / t / 1e6, 1), 'dense_route_us': round(t_dense, 1), 'vs_dense_route': round(t_dense / t, 2)}
+            row['M%d' % M] = {'us': round(t, 1), 'TFLOPs': round(fl / t / 1e6, 1), 'route': {3: 'fused tile GEMM on the image', 4: 'dequantise + gemm8', 5: 'library'}.get(route, route),
+                              'dense_route_us': round(t_dense, 1), 'vs_dense_route': round(t_dense / t, 2), 'library_route_us': round(t_lib, 1),
+                              'vs_library_route': round(t_lib / t, 2)}
         out['shapes'][('gate_up_silu_2x%dx%d' if pair else '%dx%d') % (K, N)] = row
         del pl, sets
     return out
@@ -566,7 +573,10 @@ def config4_leg(dev):
 
     out = {}
     for label, bits, gs, act in [('w3_nogroup', 3, -1, False), ('w4_g128_act_order', 4, 128, True)]:
-        out[label] = {}
+        out[label] = {'parity': 'unpinned (the reference raises NotImplementedError for bits == 3, quant_linear.py:308-309: no reference output exists; '
+                               'checked against the oracle\'s own 3-bit restatement and the float64 product at these sizes, tests/test_gpu_parity.py '
+                               'test_config4_full_size_batch1)' if bits == 3 else
+                               'pinned (golden fwd_w4g128_act_* from the reference kernel; these sizes vs the oracle in test_config4_full_size_batch1)'}
         for K, N in [(HIDDEN, HIDDEN), (HIDDEN, 3 * HIDDEN), (INTER, HIDDEN), (HIDDEN, INTER)]:
             G = 1 if gs == -1 else K // gs
             nb = 4 * (K * bits // 32) * N + 4 * G * (N * bits // 32) + 2 * G * N + 2 * K + 2 * N + (4 * K if act else 0)

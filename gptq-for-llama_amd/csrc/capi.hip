@@ -523,6 +523,16 @@ int gptq_rmsnorm_f16(const void *x, int64_t ldx, const void *weight, void *y, in
     return rmsnorm_launch((const half_t *)x, ldx, (const half_t *)weight, (half_t *)y, ldy, M, N, eps, (hipStream_t)stream);
 }
 
+int gptq_dense_matvec_f16(const void *x, const void *weight, int64_t ldw, const void *bias, void *y, int N, int K, const void *norm_weight,
+                          float norm_eps, gptq_stream_t stream) {
+    if (!x || !weight || !y) return GPTQ_E_NULL;
+    if (N <= 0 || K <= 0 || K % 8 != 0 || ldw < K) return GPTQ_E_SHAPE;
+    if (!aligned(x, 16) || !aligned(weight, 16) || ldw % 8 != 0 || !aligned(y, 2) || (norm_weight && !aligned(norm_weight, 16)) || (bias && !aligned(bias, 2)))
+        return GPTQ_E_ALIGN;
+    return dense_gemv_launch((const half_t *)x, (const half_t *)weight, ldw, (const half_t *)bias, (half_t *)y, N, K, (const half_t *)norm_weight, norm_eps,
+                             (hipStream_t)stream);
+}
+
 int gptq_rope_f16(void *qk, int64_t row_stride, const int64_t *position_ids, int64_t pos_batch_stride, int bsz, int seq,
                   int heads, int head_dim, float base, gptq_stream_t stream) {
     if (!qk || !position_ids) return GPTQ_E_NULL;
@@ -596,24 +606,26 @@ int gptq_dequant_ld_f16(const int32_t *qweight, const void *scales, const int32_
 }
 
 // ---------------------------------------------------------------------------------------------- prefill route
-// route 1 (default) = the hand-written GEMM of gemm8.hip on the transposed dequantised weight; route 0 = hipBLASLt on the
-// dequantised weight (the reported ceiling; also the fallback for shapes gemm8 does not serve: K % 128 != 0 ...).
+// route 1 (default) = own kernels only: the hand-written GEMM of gemm8.hip on the transposed dequantised weight for every dense
+// product it can run (K % 128 == 0); route 0 = hipBLASLt on the dequantised weight (the reported ceiling); the library is otherwise
+// reached only by shapes gemm8 does not serve (K % 128 != 0).
 static std::atomic<int> g_prefill_route{1};
 std::atomic<int> g_stripe_mm_pass_rows{128};     // rows per pass of the 16-row MFMA tiles: 128, or 64 (round 2's schedule: A/B runs)
-// batches of 129 .. this many rows run the fused tile GEMM on the stripe16 image (0: never).  Measured crossover against the dense route
-// (tools/bench_mid_prefill.py, profiles/r3g_mid_m/mid_prefill.txt): 1.03-1.70x up to 1024 rows, 0.85-0.95x at 2048
-std::atomic<int> g_stripe_gemm_max_rows{1024};
+// batches of 129 .. this many rows run the fused tile GEMM on the stripe16 image (0: never).  Measured against the dense route with each
+// engine forced (tools/bench_mid_prefill.py ALL_ROUTES=1, profiles/r4e_routes/routes_1k_4k.txt): the image route is the faster OWN kernel
+// up to 2048 rows on every LLaMA-7B shape (1536 rows: 70 / 194 / 193 / 171 us against 94 / 213 / 194 / 215 for gemm8), gemm8 above
+// (3072 rows: 126 / 330 / 311 / 268 against 126 / 335 / 339 / 306); against hipBLASLt the own kernels sit at 0.83-1.47x between 1025 and
+// 4095 rows (median 0.96).
+std::atomic<int> g_stripe_gemm_max_rows{2048};
 namespace {
-// The tile GEMM works in 256 x 256 (pair: 256 x 128) output tiles, one per CU at a time: below one full round of tiles (or a
-// couple of thousand rows) a launch costs a whole tile's latency however small the batch, and the library's smaller tiles win
-// (profiles/r3b_gemm8/gemm8_run1.txt: 0.39-0.60x at M = 256 / 1024, 0.95-1.16x at M = 4096, 0.99-1.06x at M = 65 536).
-// route 1 = own kernel where it is at least on par, route 2 = own kernel wherever it can run (tests, A/B), route 0 = library only.
-inline bool gemm8_wanted(int M, int N, bool pair) {
-    const int r = g_prefill_route.load();
-    if (r == 2) return true;
-    if (r != 1) return false;
-    const long tiles = (long)((M + 255) / 256) * ((N + (pair ? 127 : 255)) / (pair ? 128 : 256));
-    return M >= 2048 && tiles >= 256;
+// Round 3 handed dense products below one full round of 256 x 256 tiles (and below 2048 rows) to hipBLASLt; since round 4 the product
+// path is hand-written end to end: route 1 and 2 are the same (own kernel wherever it can run), route 0 = library only.  What the
+// tile GEMM loses on a partial round of tiles (0.6-0.7x the library at 1025 rows) is only paid by layers WITHOUT a stripe16 image
+// (2-bit batches above 128 rows, groups smaller than a row block, irregular act-order, GPTQ_STRIPE=0): everything else runs the fused
+// tile GEMM on the image up to gptq_set_stripe_gemm_max_rows().
+bool gemm8_wanted(int M, int N, bool pair) {
+    (void)M; (void)N; (void)pair;
+    return g_prefill_route.load() != 0;
 }
 constexpr size_t PREFILL_LIB_WS = (size_t)76 << 20;      // what the library may use for itself (split / stream-K algorithms)
 constexpr int PREFILL_CHUNK_M = 8192;                    // rows of the transient FP32 [rows, 2N] gate | up product

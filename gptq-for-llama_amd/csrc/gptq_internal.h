@@ -98,6 +98,9 @@ int dense_gemm_plan_count();   // plans currently cached (bounded LRU)
 int dense_gemm_set_enabled(int on);   // test hook: 0 = behave as if hipBLASLt were absent; returns the previous value
 int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, const half_t *bias, void *y, int64_t ldy, int M, int K, int N,
                    void *ws, size_t ws_bytes, hipStream_t s, bool trans_w = false, bool out_f32 = false);
+// dense_gemv.hip: y[N] = W[N][K] . x (one row of x, dense fp16 weight stored [out, in]; optional RMSNorm of x in front, optional bias)
+int dense_gemv_launch(const half_t *x, const half_t *W, int64_t ldw, const half_t *bias, half_t *y, int N, int K, const half_t *norm_w, float eps,
+                      hipStream_t s);
 int silu_mul_launch(const half_t *g, int64_t ldg, const half_t *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
 int silu_mul_f32_launch(const float *g, int64_t ldg, const float *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
 int gather_cols_launch(const half_t *x, int64_t ldx, const int32_t *perm, half_t *xg, int64_t ldg, int M, int K, hipStream_t s);   // xg = x[:, perm]

@@ -50,6 +50,7 @@ _SIGNATURES = {
     'gptq_transpose_matmul248_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'gptq_rmsnorm_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p],
+    'gptq_dense_matvec_f16': [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p],
     'gptq_rope_f16': [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p],
     'gptq_pack_f32': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                       c_void_p, c_void_p, c_void_p],

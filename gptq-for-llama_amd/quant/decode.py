@@ -160,6 +160,7 @@ def benchmark_generate(model, prompt_len=16, new_tokens=128, seed=0):
 # The position lives in device memory and is advanced inside the graph.
 # ----------------------------------------------------------------------------------------------
 ROPE_TABLE = os.environ.get('GPTQ_ROPE_TABLE', '1') != '0'
+LM_HEAD_KERNEL = os.environ.get('GPTQ_LM_HEAD_KERNEL', '1') != '0'   # 0: final norm + torch.matmul (hipBLASLt) as in rounds 1-3 (A/B runs)
 
 
 class DecodeEngine:
@@ -405,9 +406,25 @@ class DecodeEngine:
             self._gemv(self.ab, L['o'], self.x2, s, residual=self.x)        # x2 = x + o_proj(attn)
             self._norm_mlp(self.x2, L['ln2'], L['gate'], L['up'], self.cb, s)
             self._gemv(self.cb, L['down'], self.x, s, residual=self.x2)     # x = x2 + down(silu(gate) * up)
+        self._lm_head(s)
+        self.pos.add_(1)
+
+    def _lm_head(self, s):
+        """logits = lm_head(rmsnorm(x)): the model's final norm and its dense fp16 LM head in ONE hand-written launch (gptq_dense_matvec_f16,
+        csrc/dense_gemv.hip); a head the kernel does not take (odd strides, dtypes) goes through the stand-alone norm + torch.matmul."""
+        W = self.lm_head
+        if W.dtype == torch.float16 and W.dim() == 2 and W.stride(1) == 1 and W.stride(0) % 8 == 0 and W.shape[1] % 8 == 0 and LM_HEAD_KERNEL:
+            nw = self.final_norm if self.fuse_norm else None
+            if nw is None:
+                self._norm(self.x, self.final_norm, self.h, s)
+            src = self.x if nw is not None else self.h
+            rc = self.lib.gptq_dense_matvec_f16(src.data_ptr(), W.data_ptr(), W.stride(0), None, self.logits.data_ptr(), W.shape[0], W.shape[1],
+                                                self.native.ptr(nw), self.eps, s)
+            if rc != -6:
+                self.native.check(rc, 'gptq_dense_matvec_f16')
+                return
         self._norm(self.x, self.final_norm, self.h, s)
         torch.matmul(self.h, self.lm_head.t(), out=self.logits)
-        self.pos.add_(1)
 
     def reset(self):
         self.pos.zero_()

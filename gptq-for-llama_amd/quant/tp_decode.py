@@ -136,9 +136,17 @@ class TPDecodeEngine:
             quant_linear.stripe_matvec(self.x2, L['mlp'], c, H, L['Il'], bits, L['gs_mlp'], nsets=2, norm_weight=L['ln2'], eps=self.eps)
             self._partial(c, L['down'], L['Il'], H, bits, L['gs_d'], s)
             self._exchange(self.x, self.x2)                                      # x = x2 + down(silu(gate) * up)
-        rc = lib.gptq_rmsnorm_f16(self.x.data_ptr(), H, self.final_norm.data_ptr(), self.h.data_ptr(), H, 1, H, self.eps, s)
-        self.native.check(rc, 'gptq_rmsnorm_f16')
-        torch.matmul(self.h, self.lm_head.t(), out=self.logits)
+        W = self.lm_head      # replicated dense fp16 head: final norm + matvec in one hand-written launch (csrc/dense_gemv.hip)
+        rc = -6
+        if W.dtype == torch.float16 and W.stride(1) == 1 and W.stride(0) % 8 == 0 and W.shape[1] % 8 == 0:
+            rc = lib.gptq_dense_matvec_f16(self.x.data_ptr(), W.data_ptr(), W.stride(0), None, self.logits.data_ptr(), W.shape[0], W.shape[1],
+                                           self.final_norm.data_ptr(), self.eps, s)
+        if rc == -6:
+            rc = lib.gptq_rmsnorm_f16(self.x.data_ptr(), H, self.final_norm.data_ptr(), self.h.data_ptr(), H, 1, H, self.eps, s)
+            self.native.check(rc, 'gptq_rmsnorm_f16')
+            torch.matmul(self.h, self.lm_head.t(), out=self.logits)
+        else:
+            self.native.check(rc, 'gptq_dense_matvec_f16')
         self.pos.add_(1)
 
     def reset(self):

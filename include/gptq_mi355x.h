@@ -76,9 +76,9 @@ int gptq_set_split_k(int split_k);
  * kernel with packed B in LDS (4-bit, groupsize % 64 == 0; measured 2-4 % slower).  Returns the previous value. */
 int gptq_set_gemm_kernel(int version);
 /* Prefill route behind gptq_prefill_matmul_f16 / _fused_mlp_f16 / _transpose_matmul248_f16 (tests / A-B measurements):
- * 1 (default) = the hand-written LDS-DMA + MFMA tile GEMM of csrc/gemm8.hip on the dequantised weight wherever it is at least
- * on par (M >= 2048 and one full round of 256 x 256 tiles), hipBLASLt below that; 2 = the tile GEMM wherever it can run
- * (K % 128 == 0); 0 = hipBLASLt only (the reported ceiling).  Returns the previous value. */
+ * 1 (default) = the hand-written LDS-DMA + MFMA tile GEMM of csrc/gemm8.hip on the dequantised weight wherever it can run
+ * (K % 128 == 0: every LLaMA shape) -- since round 4 the default route never reaches hipBLASLt for such shapes; 2 = the same (kept for
+ * callers of earlier rounds); 0 = hipBLASLt only (the reported ceiling).  Returns the previous value. */
 int gptq_set_prefill_route(int route);
 /* Rows per pass of the 16-row MFMA tiles on the stripe16 image (gptq_stripe_matmul_f16, the 5..128-row route of gptq_layer_forward):
  * 128 (default: 65..128 rows in ONE pass over the weights) or 64 (round 2's schedule; A-B runs).  Returns the previous value. */
@@ -159,6 +159,13 @@ int gptq_transpose_matmul248_f16(const void *dy, int64_t lddy, const int32_t *qw
 int gptq_rmsnorm_f16(const void *x, int64_t ldx, const void *weight, void *y, int64_t ldy, int M,
                      int N, float eps, gptq_stream_t stream);
 
+/* y[N] = W[N][K] . x (+ bias) for ONE row of x and a dense fp16 weight stored [out, in] (row stride ldw): the LM head of a decode
+ * step -- the ordinary nn.Linear the reference's model ends in (llama_inference.py:119-127 -> HF generate), 262 MB per token for LLaMA-7B.
+ * HBM-bound, hand-written (csrc/dense_gemv.hip): rows streamed non-temporally, x staged once per workgroup, fp32 accumulation.
+ * norm_weight != NULL: x is RMS-normalised first (rms_norm_fwd_fused, quant/triton_norm.py:22-39, rounded to fp16 like the stand-alone
+ * launch) -- the model's final norm folded into the same launch.  K % 8 == 0, K <= 65536. */
+int gptq_dense_matvec_f16(const void *x, const void *weight, int64_t ldw, const void *bias, void *y, int N, int K, const void *norm_weight,
+                          float norm_eps, gptq_stream_t stream);
 /*
  * In-place rotate-half RoPE on the q and k slices of a fused qkv activation -- reference
  * triton_rotate_half_ + rotate_half_kernel (quant/fused_attn.py:61-93, :8-58).
@@ -358,7 +365,7 @@ int gptq_stripe_matmul_partial_f32(const void *x, int64_t ldx, const void *strip
  * reference's own dequantisation, quant_linear.py:128); GPTQ_E_VARIANT when there is no image (callers fall back to gptq_matmul248_f16).  The workspace
  * (gptq_query(GPTQ_Q_STRIPE_MM_WORKSPACE_BYTES), 256-byte aligned) is pure scratch for the partial tiles: no initialisation, no state
  * between launches; do not share it between launches that may overlap, nor with the zero-invariant split-K workspace of the
- * rowwave kernels.  129 <= M <= gptq_set_stripe_gemm_max_rows() (default 1024; groups of at least a row block, bits 3 / 4 / 8): ONE launch of
+ * rowwave kernels.  129 <= M <= gptq_set_stripe_gemm_max_rows() (default 2048; groups of at least a row block, bits 3 / 4 / 8): ONE launch of
  * the 2-D tiled fused-dequantise GEMM (stripe_gemm_kernel: 128 x 128 tiles, weights stay packed, x through LDS) -- no workspace use,
  * no per-call dequantise pass.  Reference semantics:
  * quant/quant_linear.py:103-137, :415-419; nsets = 2: quant/fused_mlp.py:128-168 (no bias). */

@@ -1601,3 +1601,42 @@ def test_stripe_matmul_partial_f32_matches_the_fp16_kernel_before_rounding(M, ns
         return
     assert torch.equal(want, y)
     assert lib.gptq_stripe_matmul_partial_f32(x.data_ptr(), K, st.data_ptr(), st.numel(), part.data_ptr(), 5, K, N, 4, 128, nsets, s) == -6
+
+
+# ---------------------------------------------------------------------------------------
+# the LM head of a decode step: dense fp16 matvec (csrc/dense_gemv.hip) against a float64 product of the same fp16 operands
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,K', [(32000, 4096), (32001, 4096), (1000, 11008), (50, 256), (3, 8)])
+@pytest.mark.parametrize('norm', [False, True])
+def test_dense_matvec_lm_head(N, K, norm):
+    rng = np.random.default_rng(N + K)
+    W = (rng.standard_normal((N, K)) * 0.02).astype(np.float16)
+    x = rng.standard_normal((1, K)).astype(np.float16)
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float16) if N == 50 else None
+    lib = _native.lib()
+    Wd, xd, nd = dev(W), dev(x), dev(nw)
+    y = torch.empty((1, N), dtype=torch.float16, device=DEV)
+    rc = lib.gptq_dense_matvec_f16(xd.data_ptr(), Wd.data_ptr(), K, _native.ptr(None if bias is None else dev(bias)), y.data_ptr(), N, K,
+                                   nd.data_ptr() if norm else None, 1e-6, torch.cuda.current_stream().cuda_stream)
+    _native.check(rc, 'gptq_dense_matvec_f16')
+    torch.cuda.synchronize()
+    xe = oracle.rmsnorm(x, nw, 1e-6) if norm else x          # the reference norm's own fp16-rounded output (triton_norm.py:22-39)
+    exact = xe.astype(np.float64) @ W.astype(np.float64).T
+    if bias is not None:
+        exact = exact.astype(np.float16).astype(np.float64) + bias.astype(np.float64)
+    assert rel_err(y.cpu().numpy(), exact) < TOL, rel_err(y.cpu().numpy(), exact)
+    y2 = torch.empty_like(y)
+    lib.gptq_dense_matvec_f16(xd.data_ptr(), Wd.data_ptr(), K, _native.ptr(None if bias is None else dev(bias)), y2.data_ptr(), N, K,
+                              nd.data_ptr() if norm else None, 1e-6, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)                                # no atomics: bit-reproducible
+
+
+def test_dense_matvec_rejects_bad_arguments():
+    lib = _native.lib()
+    a = torch.zeros(64, dtype=torch.float16, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.gptq_dense_matvec_f16(None, a.data_ptr(), 8, None, a.data_ptr(), 4, 8, None, 0.0, s) == -4        # GPTQ_E_NULL
+    assert lib.gptq_dense_matvec_f16(a.data_ptr(), a.data_ptr(), 8, None, a.data_ptr(), 4, 12, None, 0.0, s) != 0  # K % 8
+    assert lib.gptq_dense_matvec_f16(a.data_ptr(), a.data_ptr(), 4, None, a.data_ptr(), 4, 8, None, 0.0, s) != 0   # ldw < K

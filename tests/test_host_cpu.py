@@ -294,9 +294,9 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert lib.gptq_query(5) == 64 << 20
     assert mm(ws=None) == -4 and mm(y=None) == -4 and mm(x=None) == -4
     assert mm(ws=260) == -3 and mm(ldx=252) == -3
-    assert mm(M=1025) == -6 and mm(bits=5) == -1                       # 129 .. 1024 rows: the fused tile GEMM (gptq_set_stripe_gemm_max_rows)
+    assert mm(M=2049) == -6 and mm(bits=5) == -1                       # 129 .. 2048 rows: the fused tile GEMM (gptq_set_stripe_gemm_max_rows)
     prev = lib.gptq_set_stripe_gemm_max_rows(0)
-    assert prev == 1024 and mm(M=257) == -6                            # without it: passes of 128 rows up to 256
+    assert prev == 2048 and mm(M=257) == -6                            # without it: passes of 128 rows up to 256
     assert lib.gptq_set_stripe_gemm_max_rows(prev) == 0 and lib.gptq_set_stripe_gemm_max_rows(-1) == -6
     assert lib.gptq_set_stripe_mm_pass_rows(96) == -6                  # rows per pass of the 16-row tiles: 64 or 128
     assert lib.gptq_set_stripe_mm_pass_rows(64) == 128 and lib.gptq_set_stripe_mm_pass_rows(128) == 64
@@ -357,9 +357,8 @@ def test_tp_decode_shard_slicing_is_exact_on_cpu():
 
 
 def test_prefill_route_selection_is_host_logic(monkeypatch):
-    """which engine a dense product takes is host logic in the C library (gptq_prefill_route_for): under 'auto' the tile GEMM of
-    csrc/gemm8.hip from one full round of 256 x 256 tiles (pair: 256 x 128) and 2048 rows on, hipBLASLt below; 'library' never,
-    'own' wherever K % 128 == 0.  A refused library (GPTQ_E_LIBRARY) warns once and lets the caller continue, other codes raise."""
+    """which engine a dense product takes is host logic in the C library (gptq_prefill_route_for): under 'auto' (and 'own') the tile GEMM of
+    csrc/gemm8.hip wherever K % 128 == 0 -- the default route never reaches hipBLASLt for such shapes (VERDICT r3 #4) --, 'library' never.  A refused library (GPTQ_E_LIBRARY) warns once and lets the caller continue, other codes raise."""
     import warnings
     from quant import quant_linear as QL
     lib = _native.lib()
@@ -367,7 +366,7 @@ def test_prefill_route_selection_is_host_logic(monkeypatch):
     try:
         rf = lib.gptq_prefill_route_for
         assert rf(65536, 4096, 4096, 1, 0) == 1 and rf(4096, 4096, 4096, 1, 0) == 1 and rf(4096, 4096, 11008, 2, 0) == 1
-        assert rf(1024, 4096, 12288, 1, 0) == 0 and rf(256, 4096, 4096, 1, 0) == 0 and rf(2048, 4096, 4096, 1, 0) == 0     # 128 tiles: not a full round
+        assert rf(1024, 4096, 12288, 1, 0) == 1 and rf(256, 4096, 4096, 1, 0) == 1 and rf(2048, 4096, 4096, 1, 0) == 1     # round 4: own kernel below a full round of tiles too
         assert rf(65536, 4000 // 32 * 32 + 32, 4096, 1, 0) == 0                                                     # K % 128 != 0 -> library
         assert rf(65536, 4096, 4096, 1, 1) == 1 and rf(65536, 4096, 4128, 1, 1) == 0                               # backward: the reduction runs over N
         assert rf(0, 4096, 4096, 1, 0) == -2
@@ -499,27 +498,27 @@ def test_layer_route_table_is_host_logic():
     for K, N, ns in [(4096, 4096, 1), (4096, 12288, 1), (11008, 4096, 1), (4096, 11008, 2)]:
         assert route(1, K, N, nsets=ns) == DEC and route(4, K, N, nsets=ns) == DEC
         assert route(16, K, N, nsets=ns) == TILES and route(128, K, N, nsets=ns) == TILES
-        assert route(129, K, N, nsets=ns) == SGEMM and route(1024, K, N, nsets=ns) == SGEMM      # a single prompt: weights stay packed
-        assert route(1025, K, N, nsets=ns) == LIBR                                                # below one round of 256 x 256 tiles
+        assert route(129, K, N, nsets=ns) == SGEMM and route(2048, K, N, nsets=ns) == SGEMM      # a prompt of up to 2048 tokens: weights stay packed
+        assert route(2049, K, N, nsets=ns) == OWN and route(4095, K, N, nsets=ns) == OWN          # above: dequantise per call + the own tile GEMM
         assert route(65536, K, N, nsets=ns) == OWN                                                # BASELINE config 3
+        for M in (1, 5, 64, 129, 1025, 1536, 2048, 3072, 4095, 65536):
+            assert route(M, K, N, nsets=ns) != LIBR and route(M, K, N, nsets=ns, image=0) != LIBR  # the library is off the default route (K % 128 == 0)
     assert route(8, 4096, 4096) == DEC and route(8, 4096, 12288) == TILES        # row groups only while one round of workgroups covers N
     assert route(8, 11008, 4096) == TILES                                       # eight rows of x do not fit LDS at K = 11008
-    assert route(2048, 4096, 4096) == LIBR and route(2048, 4096, 12288) == OWN   # 128 vs 384 tiles of 256 x 256
-    assert route(2048, 4096, 11008, nsets=2) == OWN                              # the pair: 256 x 128 tiles
+    assert route(300, 4000 // 128 * 128 + 32, 4096, image=0) == LIBR             # K % 128 != 0: no own dense kernel -> the library
     # act-order: regular (group-sorted image + gather) like trivial; irregular: no image
     assert route(1, 4096, 4096, kind=1) == DEC and route(64, 4096, 4096, kind=1) == TILES and route(300, 4096, 4096, kind=1) == SGEMM
-    assert route(1, 4096, 4096, kind=2) == CKPT and route(64, 4096, 4096, kind=2) == CKPT and route(65, 4096, 4096, kind=2) == LIBR
+    assert route(1, 4096, 4096, kind=2) == CKPT and route(64, 4096, 4096, kind=2) == CKPT and route(65, 4096, 4096, kind=2) == OWN
     # groups smaller than a row block have tiles (prescale mode) but no fused GEMM; 2-bit likewise; no image at all
-    assert route(100, 4096, 4096, gs=32) == TILES and route(300, 4096, 4096, gs=32) == LIBR
-    assert route(300, 4096, 4096, bits=2) == LIBR and route(300, 4096, 4096, bits=8) == SGEMM and route(300, 4096, 4096, bits=3, gs=4096) == SGEMM
-    assert route(1, 4096, 4096, image=0) == CKPT and route(64, 4096, 4096, image=0) == CKPT and route(1000, 4096, 4096, image=0) == LIBR and route(4096, 4096, 4096, image=0) == OWN
+    assert route(100, 4096, 4096, gs=32) == TILES and route(300, 4096, 4096, gs=32) == OWN
+    assert route(300, 4096, 4096, bits=2) == OWN and route(300, 4096, 4096, bits=8) == SGEMM and route(300, 4096, 4096, bits=3, gs=4096) == SGEMM
+    assert route(1, 4096, 4096, image=0) == CKPT and route(64, 4096, 4096, image=0) == CKPT and route(1000, 4096, 4096, image=0) == OWN and route(4096, 4096, 4096, image=0) == OWN
     # the switches move the table
     prev = lib.gptq_set_stripe_gemm_max_rows(0)
-    assert route(300, 4096, 4096) == LIBR
+    assert prev == 2048 and route(300, 4096, 4096) == OWN
     lib.gptq_set_stripe_gemm_max_rows(prev)
-    prev = lib.gptq_set_prefill_route(2)
-    assert route(1025, 4096, 4096) == OWN
-    lib.gptq_set_prefill_route(0)
+    prev = lib.gptq_set_prefill_route(0)
+    assert route(3000, 4096, 4096) == LIBR
     assert route(65536, 4096, 4096) == LIBR
     lib.gptq_set_prefill_route(prev)
     assert route(0, 4096, 4096) == -2 and route(1, 4096, 4096, bits=5) == -1 and lib.gptq_layer_route_for(None, 1) == -4

@@ -17,6 +17,8 @@ dev = torch.device('cuda:0')
 lib = _native.lib()
 gen = torch.Generator(device=dev)
 gen.manual_seed(5)
+DEFAULT_ROWS = lib.gptq_set_stripe_gemm_max_rows(1024)
+lib.gptq_set_stripe_gemm_max_rows(DEFAULT_ROWS)
 MS = [int(m) for m in os.environ.get('MS', '129,256,512,1024,1536,2048,4096').split(',')]
 
 
@@ -55,15 +57,24 @@ for (K, N, pair) in [(4096, 4096, False), (4096, 12288, False), (4096, 11008, Fa
         x = torch.randn((M, K), device=dev, generator=gen).half()
         out = torch.empty((M, N), dtype=torch.float16, device=dev)
         res = {}
-        for name, rows in (('dense', 0), ('image', 1 << 20)):
+        # dense route = dequantise per call + a dense GEMM: `library` hipBLASLt (gptq_set_prefill_route(0): the reported ceiling), `gemm8` the
+        # hand-written tile GEMM forced for every M (route 2), `auto` what the default switch picks; `image` = the fused tile GEMM on the stripe16 image
+        for name, rows, route in (('library', 0, 0), ('gemm8', 0, 2), ('dense', 0, 1), ('image', 1 << 20, 1)):
+            if name in ('library', 'gemm8') and not os.environ.get('ALL_ROUTES'):
+                continue
             lib.gptq_set_stripe_gemm_max_rows(rows)
+            lib.gptq_set_prefill_route(route)
             t = timeit(lambda: pl.forward(x, out))
             res[name] = (t, out.float().clone())
-        lib.gptq_set_stripe_gemm_max_rows(1024)
+        lib.gptq_set_stripe_gemm_max_rows(DEFAULT_ROWS)
+        lib.gptq_set_prefill_route(1)
         fl = (4.0 if pair else 2.0) * M * N * K
         d = float((res['dense'][1] - res['image'][1]).abs().max() / res['dense'][1].abs().max())
-        print('%s %5dx%-5d M=%-5d dense route %8.1f us %7.1f TF | tile GEMM on the image %8.1f us %7.1f TF | image / dense %.2fx | max rel diff %.1e'
+        extra = ''
+        if 'library' in res:
+            extra = ' | library %8.1f us %7.1f TF | gemm8 forced %8.1f us %7.1f TF' % (res['library'][0], fl / res['library'][0] / 1e6, res['gemm8'][0], fl / res['gemm8'][0] / 1e6)
+        print('%s %5dx%-5d M=%-5d dense route %8.1f us %7.1f TF | tile GEMM on the image %8.1f us %7.1f TF | image / dense %.2fx | max rel diff %.1e%s'
               % ('pair' if pair else '    ', K, N, M, res['dense'][0], fl / res['dense'][0] / 1e6, res['image'][0], fl / res['image'][0] / 1e6,
-                 res['dense'][0] / res['image'][0], d), flush=True)
+                 res['dense'][0] / res['image'][0], d, extra), flush=True)
     del pl, sets
     torch.cuda.empty_cache()

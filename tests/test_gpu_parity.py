@@ -227,14 +227,14 @@ def test_dequantize_into_a_strided_view_and_silu_mul():
 @pytest.mark.parametrize('bits,gs,act,M,K,N', [(4, 128, False, 4096, 4096, 4096), (4, 128, True, 2100, 1024, 4096), (3, -1, False, 700, 512, 320),
                                                (2, 64, False, 300, 1024, 512), (8, 128, False, 8192, 512, 4096)])
 def test_prefill_routes_vs_oracle(route, bits, gs, act, M, K, N, monkeypatch):
-    """the built-in dispatch above the streaming kernels under every setting of GPTQ_PREFILL: 'auto' = the tile GEMM of csrc/gemm8.hip
-    from one full round of its tiles on, hipBLASLt below (default); 'library' = hipBLASLt for every dense product; 'own' = the tile
-    GEMM wherever it can run (K % 128 == 0); against the CPU oracle on sampled rows."""
+    """the built-in dispatch above the streaming kernels under every setting of GPTQ_PREFILL: 'auto' (default) and 'own' = the tile GEMM of
+    csrc/gemm8.hip wherever it can run (K % 128 == 0; round 3's 'auto' still used hipBLASLt below one full round of tiles); 'library' =
+    hipBLASLt for every dense product (the reported ceiling); against the CPU oracle on sampled rows."""
     monkeypatch.setattr(QL, 'PREFILL_ROUTE', route)
     lib = _native.lib()
     QL._apply_prefill_route()
-    if route != 'library' and K % 128 == 0 and (route == 'own' or M >= 2048):
-        assert lib.gptq_prefill_route_for(M, K, N, 1, 0) == (1 if (route == 'own' or -(-M // 256) * -(-N // 256) >= 256) else 0)
+    if route != 'library' and K % 128 == 0:
+        assert lib.gptq_prefill_route_for(M, K, N, 1, 0) == 1         # round 4: 'auto' never hands a K % 128 == 0 product to the library
     if route == 'library':
         assert lib.gptq_prefill_route_for(M, K, N, 1, 0) == 0
     L = make_random_layer(bits, gs, K, N, act_order=act, seed=M + K + bits)
@@ -280,9 +280,9 @@ def test_prefill_falls_back_to_the_own_kernels_without_the_library(monkeypatch):
     fused MLP (inside gptq_layer_forward) and backward (one Python warning), same results."""
     lib = _native.lib()
     monkeypatch.setattr(QL, '_library_warned', False)
-    K, N, M = 512, 288, 300          # a shape the tile GEMM leaves to the library under 'auto' (less than one round of tiles)
-    L = make_random_layer(4, 128, K, N, seed=9)
-    U = make_random_layer(4, 128, K, N, seed=10)
+    K, N, M = 480, 288, 300          # K % 128 != 0: the one kind of shape the default route still hands to the library (round 4)
+    L = make_random_layer(4, 32, K, N, seed=9)
+    U = make_random_layer(4, 32, K, N, seed=10)
     rng = np.random.default_rng(9)
     x = rng.standard_normal((M, K)).astype(np.float16)
     assert lib.gptq_prefill_route_for(M, K, N, 1, 0) == 0
@@ -291,7 +291,7 @@ def test_prefill_falls_back_to_the_own_kernels_without_the_library(monkeypatch):
         check_forward(x, L)                         # gptq_layer_forward falls through to the C ABI's own kernels (one line on stderr)
         gate = tuple(dev(L[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
         up = tuple(dev(U[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
-        c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 128).cpu().numpy()
+        c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, 32).cpu().numpy()
         ref = oracle.fused_mlp(x, (L['qweight'], L['scales'], L['qzeros'], L['g_idx']), (U['qweight'], U['scales'], U['qzeros'], U['g_idx']), 4)
         assert rel_err(c, ref) < TOL                # (library-free route: the round-1 tile GEMM in PAIR mode, SiLU on the fp32 sums as well)
         dy = rng.standard_normal((M, N)).astype(np.float16)
@@ -1640,3 +1640,40 @@ def test_dense_matvec_rejects_bad_arguments():
     assert lib.gptq_dense_matvec_f16(None, a.data_ptr(), 8, None, a.data_ptr(), 4, 8, None, 0.0, s) == -4        # GPTQ_E_NULL
     assert lib.gptq_dense_matvec_f16(a.data_ptr(), a.data_ptr(), 8, None, a.data_ptr(), 4, 12, None, 0.0, s) != 0  # K % 8
     assert lib.gptq_dense_matvec_f16(a.data_ptr(), a.data_ptr(), 4, None, a.data_ptr(), 4, 8, None, 0.0, s) != 0   # ldw < K
+
+
+# ---------------------------------------------------------------------------------------
+# round 4: several stripes per workgroup on the same staged x (stripe_mm3_kernel C = 2 / 3: 5 .. 32 rows on shapes with 2-3 rounds of stripes)
+# and K slices of the 128-row fused tile GEMM (65 .. 128 rows on multi-round / long-K shapes) -- against the oracle on sampled rows
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize('bits', [3, 4, 8])
+@pytest.mark.parametrize('K,N', [(4096, 12288), (4096, 11008), (4096, 8192), (11008, 4096), (4096, 8224)])
+@pytest.mark.parametrize('M', [5, 16, 17, 32, 65, 100, 128])
+def test_small_batches_on_multi_round_shapes(bits, K, N, M):
+    """every schedule of gptq_stripe_matmul_f16 that round 4 added or re-routed: C adjacent stripes per workgroup (N = 8192: 2, 11008 / 12288: 3;
+    8224 = 514 stripes = 171 x 3 + 1: a ragged last workgroup), the sliced tile GEMM from 65 rows on; bias in the epilogue; bit-reproducible"""
+    if bits == 8 and K == 11008:
+        pytest.skip('8-bit row block = 64 k: covered by the 4096-k shapes')
+    L = make_random_layer(bits, 128, K, N, seed=bits * 1000 + N + M)
+    rng = np.random.default_rng(M + K)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    b = rng.standard_normal(N).astype(np.float16)
+    xd, out = dev(x), torch.empty((M, N), dtype=torch.float16, device=DEV)
+    st = QL.stripe_copy(dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), bits, 128)
+    assert st is not None
+    assert QL.stripe_matmul(xd, st, out, K, N, bits, 128, bias=dev(b))
+    torch.cuda.synchronize()
+    y = out.cpu().numpy()
+    rows = np.unique(np.concatenate([[0, M - 1, M // 2], rng.integers(0, M, 5)]))
+    ref = exact_forward(x[rows], L, b)
+    assert np.isfinite(y.astype(np.float32)).all()
+    assert rel_err(y[rows], ref) < TOL, rel_err(y[rows], ref)
+    out2 = torch.empty_like(out)
+    assert QL.stripe_matmul(xd, st, out2, K, N, bits, 128, bias=dev(b))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)                              # partial tiles are summed in slice order: no atomics anywhere
+    # every row agrees with the M = 1 decode kernel on the same image (size-independent property; catches a wrong row / column map at once)
+    one = torch.empty((1, N), dtype=torch.float16, device=DEV)
+    for m in (0, M - 1):
+        assert QL.stripe_matvec(xd[m:m + 1], st, one, K, N, bits, 128, bias=dev(b))
+        assert rel_err(y[m:m + 1], one.cpu().numpy()) < TOL

@@ -1676,4 +1676,5 @@ def test_small_batches_on_multi_round_shapes(bits, K, N, M):
     one = torch.empty((1, N), dtype=torch.float16, device=DEV)
     for m in (0, M - 1):
         assert QL.stripe_matvec(xd[m:m + 1], st, one, K, N, bits, 128, bias=dev(b))
-        assert rel_err(y[m:m + 1], one.cpu().numpy()) < TOL
+        # two independently rounded fp16 results (bias: two roundings each): ONE fp16 spacing at the top of the range is already 1e-3 of max|y|
+        assert rel_err(y[m:m + 1], one.cpu().numpy()) < 2 * TOL

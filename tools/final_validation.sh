@@ -1,19 +1,19 @@
 # one gpurun call: tests, smoke, bench, rocprofv3 kernel stats, PMC traffic, PMC counters of the prefill tile GEMM, decode engine profile
 set -x
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r3f}; mkdir -p $O
+O=gpurun_out/${1:-r4j}; mkdir -p $O
 # a sick box (seen once: 'Memory access fault by GPU' in the first torch op of every process) must not burn the GPU budget: smoke first, stop if it fails
 timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 grep -q 'smoke ok' $O/smoke.txt || { echo 'SMOKE FAILED -- stopping'; exit 3; }
 if [ -z "$SKIP_TESTS" ]; then
-timeout 600 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -6 $O/pytest_gpu.txt
+timeout 900 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -6 $O/pytest_gpu.txt
 timeout 900 python bench.py > $O/bench.json.txt 2> $O/bench.err; tail -c 400 $O/bench.json.txt
 fi
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 if [ -z "$SKIP_TESTS" ]; then
-timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/prof -- python $R/bench.py --steps 5 --warmup 1 --no-decode --no-cpu-baseline --no-per-shape --no-prefill --no-config4 --no-small-batch > $R/$O/prof_bench.txt 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $R/$O/pmc -- python $R/bench.py --steps 2 --warmup 1 --eager --no-decode --no-cpu-baseline --no-per-shape --no-prefill --no-config4 --no-small-batch > $R/$O/pmc_bench.txt 2>&1
+GPTQ_BENCH_NO_TP1=1 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/prof -- python $R/bench.py --steps 5 --warmup 1 --no-decode --no-cpu-baseline --no-per-shape --no-prefill --no-config4 --no-small-batch > $R/$O/prof_bench.txt 2>&1
+GPTQ_BENCH_NO_TP1=1 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d $R/$O/pmc -- python $R/bench.py --steps 2 --warmup 1 --eager --no-decode --no-cpu-baseline --no-per-shape --no-prefill --no-config4 --no-small-batch > $R/$O/pmc_bench.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/prof_engine -- python $R/tools/profile_engine.py > $R/$O/prof_engine.txt 2>&1
 fi
 timeout 200 rocprofv3 --kernel-trace --stats -f csv -d $R/$O/prof_gemm -- python $R/tools/run_prefill_once.py 16384 > $R/$O/prof_gemm.txt 2>&1

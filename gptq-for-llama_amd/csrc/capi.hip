@@ -1027,7 +1027,7 @@ struct gptq_layer {
     size_t stripe_bytes;
     int32_t *perm32;               // kind == 1: sorted position -> original k
     uint16_t *perm16;
-    int32_t *qw_sorted[2];         // kind == 1: group-sorted qweight copies
+    int32_t *invperm32;            // kind == 1: original k -> sorted position (rebuilds the checkpoint rows out of the image)
     bool released;                 // the caller freed the checkpoint buffers: qw / sc / qz are gone, the image is the only copy
 };
 
@@ -1088,7 +1088,7 @@ size_t gptq_layer_image_bytes(int K, int N, int bits, int groupsize, int nsets, 
     if (kind == 2 || (kind == 1 && !sorted_supported(K, bits, groupsize))) return 0;
     const size_t st = stripe_total_bytes(K, N, bits, groupsize, nsets);
     size_t b = a256(st);
-    if (kind == 1) b += a256((size_t)K * 4) + a256((size_t)K * 2) + (size_t)nsets * a256((size_t)(K / 32 * bits) * N * 4);
+    if (kind == 1) b += 2 * a256((size_t)K * 4) + a256((size_t)K * 2);   // perm32, invperm32, perm16 (round 4: no group-sorted qweight copy any more)
     return b;
 }
 
@@ -1140,25 +1140,25 @@ int gptq_layer_prepare(gptq_layer_t **out, const int32_t *qweight, const void *s
         char *p = (char *)image;
         void *stripe = st_bytes ? p : nullptr;
         p += a256(st_bytes);
-        const uint32_t *src[2] = {(const uint32_t *)qweight, (const uint32_t *)qweight_up};
         if (kind == 1) {
             L->perm32 = (int32_t *)p; p += a256((size_t)K * 4);
+            L->invperm32 = (int32_t *)p; p += a256((size_t)K * 4);
             L->perm16 = (uint16_t *)p; p += a256((size_t)K * 2);
             std::vector<uint16_t> p16(K);
-            for (int k = 0; k < K; k++) p16[k] = (uint16_t)perm[k];
+            std::vector<int32_t> inv(K);
+            for (int k = 0; k < K; k++) { p16[k] = (uint16_t)perm[k]; inv[perm[k]] = k; }
             hipError_t e = hipMemcpyAsync(L->perm32, perm.data(), (size_t)K * 4, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(L->invperm32, inv.data(), (size_t)K * 4, hipMemcpyHostToDevice, s);
             if (e == hipSuccess) e = hipMemcpyAsync(L->perm16, p16.data(), (size_t)K * 2, hipMemcpyHostToDevice, s);
             if (e == hipSuccess) e = hipStreamSynchronize(s);   // the host vectors go out of scope
             if (e != hipSuccess) { delete L; return (int)e; }
-            for (int i = 0; i < nsets; i++) {
-                L->qw_sorted[i] = (int32_t *)p; p += a256((size_t)(K / 32 * bits) * N * 4);
-                if (int rc = act_order_repack_launch(src[i], L->perm32, K, N, bits, (uint32_t *)L->qw_sorted[i], s)) { delete L; return rc; }
-                src[i] = (const uint32_t *)L->qw_sorted[i];
-            }
         }
-        if (stripe) {
-            if (int rc = stripe_repack_launch(src[0], (const half_t *)scales, qzeros, nsets == 2 ? src[1] : nullptr, (const half_t *)scales_up, qzeros_up,
-                                              stripe, K, N, bits, groupsize, s)) { delete L; return rc; }
+        if (stripe) {   // (kind 1: the rows are gathered through the permutation while the image is written -- no sorted copy of qweight)
+            if (int rc = stripe_repack_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, nsets == 2 ? (const uint32_t *)qweight_up : nullptr,
+                                              (const half_t *)scales_up, qzeros_up, stripe, K, N, bits, groupsize, s, kind == 1 ? L->perm32 : nullptr)) {
+                delete L;
+                return rc;
+            }
             L->stripe = stripe; L->stripe_bytes = st_bytes;
         }
     } else if (need && image) {
@@ -1191,17 +1191,18 @@ static size_t layer_unpacked_bytes(const gptq_layer &L) {
 }
 int gptq_layer_release_checkpoint(gptq_layer_t *layer) {
     if (!layer) return GPTQ_E_NULL;
-    if (layer->kind != 0 || !layer->stripe || (layer->bits != 2 && layer->bits != 4 && layer->bits != 8)) return GPTQ_E_VARIANT;
+    if (layer->kind == 2 || !layer->stripe || (layer->bits != 2 && layer->bits != 4 && layer->bits != 8)) return GPTQ_E_VARIANT;
     layer->released = true;
-    for (int i = 0; i < 2; i++) layer->qw[i] = nullptr, layer->sc[i] = nullptr, layer->qz[i] = nullptr, layer->gi[i] = nullptr;
+    // (a regular act-order layer keeps borrowing g_idx -- K ints; qweight / scales / qzeros come back out of the image on demand)
+    for (int i = 0; i < 2; i++) layer->qw[i] = nullptr, layer->sc[i] = nullptr, layer->qz[i] = nullptr;
     return GPTQ_OK;
 }
 /* the checkpoint buffers of weight set `set` reproduced from the image (bit-exact): for state_dict() of a released layer */
 int gptq_layer_unpack_checkpoint(const gptq_layer_t *layer, int set, int32_t *qweight, void *scales, int32_t *qzeros, gptq_stream_t stream) {
     if (!layer || !qweight || !scales || !qzeros) return GPTQ_E_NULL;
-    if (!layer->stripe || layer->kind != 0) return GPTQ_E_VARIANT;
+    if (!layer->stripe || layer->kind == 2) return GPTQ_E_VARIANT;
     return stripe_unpack_launch(layer->stripe, layer->K, layer->N, layer->bits, layer->groupsize, layer->nsets, set, (uint32_t *)qweight, (half_t *)scales,
-                                qzeros, (hipStream_t)stream);
+                                qzeros, (hipStream_t)stream, layer->kind == 1 ? layer->invperm32 : nullptr);
 }
 
 /* persistent workspace every forward takes: [split-K words, zero on first use and left zero][scratch of the 16-row MFMA tiles] */
@@ -1300,7 +1301,9 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
             int32_t *qw_i = (int32_t *)p; p += a256((size_t)(K / 32 * bits) * N * 4);
             void *sc_i = p; p += a256(G * N * 2);
             int32_t *qz_i = (int32_t *)p; p += a256(G * (size_t)(N / 32 * bits) * 4);
-            if (int rc = stripe_unpack_launch(L.stripe, K, N, bits, gs, ns, i, (uint32_t *)qw_i, (half_t *)sc_i, qz_i, (hipStream_t)stream)) return rc;
+            if (int rc = stripe_unpack_launch(L.stripe, K, N, bits, gs, ns, i, (uint32_t *)qw_i, (half_t *)sc_i, qz_i, (hipStream_t)stream,
+                                              L.kind == 1 ? L.invperm32 : nullptr))
+                return rc;
             Lr.qw[i] = qw_i; Lr.sc[i] = sc_i; Lr.qz[i] = qz_i;
         }
         scratch = p;
@@ -1331,26 +1334,8 @@ static int layer_forward_checkpoint(const gptq_layer &L, const void *x, int64_t 
         q.fused2 = true;
         q.qw[1] = L.qw[1]; q.sc[1] = L.sc[1]; q.qz[1] = L.qz[1]; q.gi[1] = L.gi[1];
     }
-    if (L.kind == 1 && L.qw_sorted[0]) {   // group-sorted copy: trivial-g_idx kernels on x[perm]
-        q.qw[0] = L.qw_sorted[0]; q.gi[0] = nullptr;
-        if (ns == 2) { q.qw[1] = L.qw_sorted[1]; q.gi[1] = nullptr; }
-        if (M == 1 && bits == 4) {            // rowwave GEMV with the gather fused
-            q.xperm = L.perm32;
-            if (int rc = validate(q)) return rc;
-            if (fast_eligible(q, 8)) {
-                const int rc = run_rowwave(q, (hipStream_t)stream);
-                if (rc != GPTQ_E_VARIANT) return rc;
-            }
-            q.xperm = nullptr;
-        }
-        if (scratch && aligned(scratch, 16) && scratch_bytes >= (size_t)M * K * 2) {
-            if (int rc = gather_cols_launch((const half_t *)x, ldx, L.perm32, (half_t *)scratch, K, M, K, (hipStream_t)stream)) return rc;
-            q.x = scratch; q.ldx = K;
-        } else {   // no room for the gathered x: the generic g_idx kernels on the original rows
-            q.qw[0] = L.qw[0]; q.gi[0] = L.gi[0];
-            if (ns == 2) { q.qw[1] = L.qw[1]; q.gi[1] = L.gi[1]; }
-        }
-    }
+    // (a regular act-order layer that gets here -- no scratch for the gather, a kernel declined -- runs the generic g_idx kernels on the
+    // checkpoint rows: round 3's group-sorted qweight copy, one more qweight per layer kept for this corner, is gone)
     if (int rc = validate(q)) return rc;
     return run_auto(q, (hipStream_t)stream);
 }

@@ -125,13 +125,15 @@ struct StripeParams {
 int stripe_gq_shift(int K, int N, int bits, int groupsize);            // log2(groupsize / (4 KPW)), -1 one group, -2 ineligible
 size_t stripe_tab_offset(int K, int N, int bits, int nsets);
 size_t stripe_total_bytes(int K, int N, int bits, int groupsize, int nsets);
+// perm != NULL (bits 2 / 4 / 8): the image of the GROUP-SORTED rows of a regular act-order layer, gathered straight from the checkpoint layout
 int stripe_repack_launch(const uint32_t *qw0, const half_t *sc0, const int32_t *qz0, const uint32_t *qw1, const half_t *sc1,
-                         const int32_t *qz1, void *out, int K, int N, int bits, int groupsize, hipStream_t s);
+                         const int32_t *qz1, void *out, int K, int N, int bits, int groupsize, hipStream_t s, const int32_t *perm = nullptr);
 int stripe_gemv_dispatch(const StripeParams &p, hipStream_t s);
 uint32_t *stripe_progress_counter();   // capi.hip: gptq_set_progress_counter (NULL by default)
 // inverse of stripe_repack_launch for ONE set (bits 2 / 4 / 8): qweight [K/32*bits][N], scales [G][N], qzeros [G][N/32*bits]
+// (invperm != NULL: the image holds group-sorted rows; the ORIGINAL row order comes back)
 int stripe_unpack_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, int set, uint32_t *qw, half_t *sc, int32_t *qz,
-                         hipStream_t s);
+                         hipStream_t s, const int32_t *invperm = nullptr);
 
 int gptq_block_launch(const float *W, int64_t ldw, const float *Hinv, int64_t ldh, int rows, int i1, int count, int groupsize, int maxq,
                       const float *scale, const float *zero, int64_t ldg, float *Q, int64_t ldq, float *Err, int64_t lde, float *loss_rows,

@@ -43,8 +43,12 @@ namespace gptq {
 
 namespace {
 
+// perm != NULL (round 4): the image of the GROUP-SORTED rows of an act-order layer straight from the checkpoint layout -- packed row r of
+// the sorted matrix holds k' = F r .. F r + F - 1, whose source is field perm[k'] % F of checkpoint row perm[k'] / F (what
+// act_order_repack_kernel writes into a full sorted copy; that copy, one more qweight per layer, is no longer needed)
 __global__ void __launch_bounds__(256) stripe_repack_kernel(const uint32_t *__restrict__ qw0, const uint32_t *__restrict__ qw1,
-                                                            uint32_t *__restrict__ R, int N, int nrb, int NS, int bits) {
+                                                            uint32_t *__restrict__ R, int N, int nrb, int NS, int bits,
+                                                            const int32_t *__restrict__ perm) {
     // one thread per output word; consecutive threads -> consecutive j (rows), then lanes (columns): 64-byte reads
     const size_t total = (size_t)(N / 16) * nrb * NS * 256;
     const int F = 32 / bits;
@@ -56,7 +60,16 @@ __global__ void __launch_bounds__(256) stripe_repack_kernel(const uint32_t *__re
         const int rb = (int)(b % nrb);
         const int stripe = (int)(b / nrb);
         const int row = rb * 16 + 4 * (l >> 4) + j, col = 16 * stripe + (l & 15);
-        const uint32_t w = (set ? qw1 : qw0)[(size_t)row * N + col];
+        uint32_t w;
+        if (perm) {
+            w = 0;
+            for (int f = 0; f < F; f++) {
+                const int k = perm[row * F + f];
+                w |= (((set ? qw1 : qw0)[(size_t)(k / F) * N + col] >> (bits * (k % F))) & fm) << (bits * f);
+            }
+        } else {
+            w = (set ? qw1 : qw0)[(size_t)row * N + col];
+        }
         uint32_t o = 0;
         for (int p = 0; p < F; p++) o |= ((w >> (bits * stripe_k_of_pos(p, F))) & fm) << (bits * p);
         R[i] = o;
@@ -115,17 +128,31 @@ __global__ void __launch_bounds__(256) stripe_table_kernel(const half_t *__restr
 // (qweight, scales, qzeros) -- oracle.stripe16_unpack states it, tests hold both directions bit-exact -- so a model that has
 // released its checkpoint buffers (GPTQ_RELEASE_CHECKPOINT, DESIGN.md "memory") can still produce its state_dict and feed the
 // per-call dequantise pass of the prefill route.
+// invperm != NULL: the image holds the group-sorted rows (see stripe_repack_kernel); field f of checkpoint row r is value k' = invperm[F r + f]
+// of the sorted matrix, i.e. field position pos(k' % F) of the image word of packed row k' / F
 __global__ void __launch_bounds__(256) stripe_unpack_kernel(const uint32_t *__restrict__ R, uint32_t *__restrict__ qw, int N, int nrb, int NS, int set,
-                                                            int bits, size_t total) {
+                                                            int bits, size_t total, const int32_t *__restrict__ invperm) {
     const int F = 32 / bits;
     const uint32_t fm = (1u << bits) - 1u;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int col = (int)(i % N), row = (int)(i / N);
-        const int stripe = col >> 4, c = col & 15, rb = row >> 4, rr = row & 15;
-        const int l = (rr >> 2) * 16 + c, j = rr & 3;
-        const uint32_t o = R[((((size_t)stripe * nrb + rb) * NS + set) * 64 + l) * 4 + j];
+        const int stripe = col >> 4, c = col & 15;
+        auto image_word = [&](int srow) {
+            const int rb = srow >> 4, rr = srow & 15;
+            const int l = (rr >> 2) * 16 + c, j = rr & 3;
+            return R[((((size_t)stripe * nrb + rb) * NS + set) * 64 + l) * 4 + j];
+        };
         uint32_t w = 0;
-        for (int p = 0; p < F; p++) w |= ((o >> (bits * p)) & fm) << (bits * stripe_k_of_pos(p, F));
+        if (invperm) {
+            for (int f = 0; f < F; f++) {
+                const int ks = invperm[row * F + f], kk = ks % F;
+                const int pos = (kk & 1) ? (kk - 1) / 2 + F / 2 : kk / 2;        // inverse of stripe_k_of_pos
+                w |= ((image_word(ks / F) >> (bits * pos)) & fm) << (bits * f);
+            }
+        } else {
+            const uint32_t o = image_word(row);
+            for (int p = 0; p < F; p++) w |= ((o >> (bits * p)) & fm) << (bits * stripe_k_of_pos(p, F));
+        }
         qw[i] = w;
     }
 }
@@ -153,14 +180,14 @@ __global__ void __launch_bounds__(256) stripe_untable_kernel(const uint32_t *__r
 }  // namespace
 
 int stripe_unpack_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, int set, uint32_t *qw, half_t *sc, int32_t *qz,
-                         hipStream_t s) {
+                         hipStream_t s, const int32_t *invperm) {
     if (bits != 2 && bits != 4 && bits != 8) return GPTQ_E_VARIANT;
     if (stripe_gq_shift(K, N, bits, groupsize) == -2 || set < 0 || set >= nsets || N % (32 / bits) != 0) return GPTQ_E_VARIANT;
     const int G = groupsize >= K ? 1 : K / groupsize;
     const uint32_t *R = (const uint32_t *)image;
     const uint32_t *tab = (const uint32_t *)((const char *)image + stripe_tab_offset(K, N, bits, nsets));
     const size_t words = (size_t)(K / 32 * bits) * N;
-    hipLaunchKernelGGL(stripe_unpack_kernel, dim3(2048), dim3(256), 0, s, R, qw, N, K / (16 * (32 / bits)), nsets, set, bits, words);
+    hipLaunchKernelGGL(stripe_unpack_kernel, dim3(2048), dim3(256), 0, s, R, qw, N, K / (16 * (32 / bits)), nsets, set, bits, words, invperm);
     if (bits == 2) hipLaunchKernelGGL(stripe_untable_kernel<2>, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
     else if (bits == 4) hipLaunchKernelGGL(stripe_untable_kernel<4>, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
     else hipLaunchKernelGGL(stripe_untable_kernel<8>, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
@@ -190,13 +217,14 @@ size_t stripe_total_bytes(int K, int N, int bits, int groupsize, int nsets) {
 }
 
 int stripe_repack_launch(const uint32_t *qw0, const half_t *sc0, const int32_t *qz0, const uint32_t *qw1, const half_t *sc1, const int32_t *qz1,
-                         void *out, int K, int N, int bits, int groupsize, hipStream_t s) {
+                         void *out, int K, int N, int bits, int groupsize, hipStream_t s, const int32_t *perm) {
+    if (perm && bits == 3) return GPTQ_E_VARIANT;   // (no group-sorted image for the 96-bit blocks of 3-bit rows)
     const int NS = qw1 ? 2 : 1;
     const int G = groupsize >= K ? 1 : K / groupsize;
     uint32_t *R = (uint32_t *)out;
     uint32_t *tab = (uint32_t *)((char *)out + stripe_tab_offset(K, N, bits, NS));
     if (bits == 3) hipLaunchKernelGGL(stripe_repack3_kernel, dim3(2048), dim3(256), 0, s, qw0, qw1, R, N, K / 128, NS);
-    else hipLaunchKernelGGL(stripe_repack_kernel, dim3(2048), dim3(256), 0, s, qw0, qw1, R, N, K / (16 * (32 / bits)), NS, bits);
+    else hipLaunchKernelGGL(stripe_repack_kernel, dim3(2048), dim3(256), 0, s, qw0, qw1, R, N, K / (16 * (32 / bits)), NS, bits, perm);
     if (bits == 3) hipLaunchKernelGGL(stripe_table_kernel<3>, dim3(512), dim3(256), 0, s, sc0, qz0, sc1, qz1, tab, N, G, NS);
     else if (bits == 2) hipLaunchKernelGGL(stripe_table_kernel<2>, dim3(512), dim3(256), 0, s, sc0, qz0, sc1, qz1, tab, N, G, NS);
     else if (bits == 4) hipLaunchKernelGGL(stripe_table_kernel<4>, dim3(512), dim3(256), 0, s, sc0, qz0, sc1, qz1, tab, N, G, NS);

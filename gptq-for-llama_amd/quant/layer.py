@@ -49,6 +49,7 @@ class PreparedLayer:
         # for ever); the caller of forward() holds that tensor anyway
         self._keep = [t for s in sets for t in s[1:]] + [s[0] for s in sets[1:]]
         self._bias = bias        # read by the handle for as long as it lives (also after release())
+        self._gidx = [s[3] for s in sets if s[3] is not None]   # ... and so is g_idx of an act-order layer (K ints: kept, not released)
         ptr = _native.ptr
         s0, s1 = sets[0], (sets[1] if len(sets) > 1 else (None, None, None, None))
         stream = _native.stream_ptr(dev)
@@ -88,9 +89,10 @@ class PreparedLayer:
                 pass
 
     def release(self):
-        """memory mode (gptq_layer_release_checkpoint): the handle stops reading the checkpoint buffers -- the stripe16 image is a
-        bijection of them -- and this object lets go of its references, so the caller can free them.  False (nothing changed) for
-        layers that need the checkpoint layout: act-order, 3-bit, no image."""
+        """memory mode (gptq_layer_release_checkpoint): the handle stops reading qweight / scales / qzeros -- the stripe16 image (of the
+        group-sorted rows + both permutations for a regular act-order layer, round 4) is a bijection of them -- and this object lets go of its
+        references, so the caller can free them; g_idx stays borrowed.  False (nothing changed) for layers that need the checkpoint layout:
+        irregular act-order, 3-bit, no image."""
         if self.lib.gptq_layer_release_checkpoint(self.handle) != 0:
             return False
         self._keep = []          # incl. a converted copy of the key tensor prepared() may have parked here; the bias lives in self._bias

@@ -653,6 +653,45 @@ def test_release_checkpoint_memory_mode():
         assert torch.equal(v, sd0[k]), k
 
 
+def test_release_checkpoint_act_order_model():
+    """round 4: memory mode for an --act-order checkpoint.  The image of a regular act-order layer holds the group-sorted rows, the
+    permutation and its inverse -- a bijection of qweight / scales / qzeros (g_idx stays with the module) -- so those buffers are freed like
+    a trivial layer's: prefill (tiles on the image after one gather; the dense route on buffers rebuilt from the image) and engine decode are
+    bit-identical before and after, state_dict() returns the original tensors bit for bit, and no layer keeps a second copy."""
+    import quant
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=23, fused=True, act_order=True, **HOOK_CFG)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator(device=DEV).manual_seed(9)
+    ids9, ids200 = torch.randint(0, 512, (1, 9), device=DEV, generator=g), torch.randint(0, 512, (1, 200), device=DEV, generator=g)
+    model._gptq_engine_disabled = True          # "before" = the plain module chain on both copies
+
+    def probe():
+        with torch.no_grad():
+            return model(ids9).logits.clone(), model(ids200).logits.clone()
+    before = probe()
+    eager = run_steps(model, ids9, 1)
+    model._gptq_engine_disabled = False
+    done, kept = quant.release_checkpoint(model)
+    assert (done, kept) == (4 * HOOK_CFG['num_hidden_layers'], 0)
+    lins = [m for m in model.modules() if isinstance(m, quant.QuantLinear)]
+    assert all(m.qweight.numel() == 0 and m.g_idx.numel() >= m.infeatures and m._released.kind == 1 for m in lins)   # (fused qkv: g_idx of length 3 K like the reference, fused_attn.py:177-188)
+    model._gptq_engine_disabled = True
+    after = probe()
+    model._gptq_engine_disabled = False
+    for x, y in zip(before, after):
+        assert torch.equal(x, y)
+    eng = D.DecodeEngine(model, t_max=64).capture()        # the engine on the released model: images + permutations only
+    got = np.stack([eng.decode(ids9[0, i]).float().cpu().numpy()[0] for i in range(ids9.shape[1])])[:, None, :]
+    within('engine_act_order_released', np.abs(got - eager).max() / np.abs(eager).max(), ENGINE_TOL)
+    sd1 = model.state_dict()
+    for k in sd0:
+        assert sd1[k].shape == sd0[k].shape and torch.equal(sd1[k], sd0[k]), k
+    quant.restore_checkpoint(model)
+    assert all(m.qweight.numel() > 0 and m._released is None for m in lins)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+
+
 # ---------------------------------------------------------------------------------------
 # BASELINE config 5 at the model level: tensor-parallel decode (quant/tp_decode.py), two ranks sharing the one GPU of the test box,
 # the exchanges through the one-shot all-reduce captured in each rank's hipGraph

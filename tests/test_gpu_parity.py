@@ -1483,7 +1483,7 @@ def test_prepared_layer_abi_direct(bits, gs, K, N, act, pair):
             assert rel_err(y, exact_forward(x, A, bias)) < TOL, M          # bias: two roundings -> float64 bar
         return y
     ys = {M: check(M) for M in (1, 3, 8, 17, 64, 100, 300)}
-    if kind == 0 and nbytes and bits != 3:
+    if nbytes and bits != 3:       # trivial AND (round 4) regular act-order layers: the image -- of the group-sorted rows + both permutations -- is a bijection
         assert lib.gptq_layer_release_checkpoint(h) == 0
         keep = [t.clone() for t in a[:3]]
         for t in a[:3] + (b[:3] if pair else []):
@@ -1496,6 +1496,11 @@ def test_prepared_layer_abi_direct(bits, gs, K, N, act, pair):
         assert lib.gptq_layer_unpack_checkpoint(h, 0, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), s) == 0
         torch.cuda.synchronize()
         assert torch.equal(qw, keep[0]) and torch.equal(sc, keep[1]) and torch.equal(qz, keep[2])
+        if pair:
+            keep_b = [dev(B[k]) for k in ('qweight', 'scales', 'qzeros')]
+            assert lib.gptq_layer_unpack_checkpoint(h, 1, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), s) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(qw, keep_b[0]) and torch.equal(sc, keep_b[1]) and torch.equal(qz, keep_b[2])
     else:
         assert lib.gptq_layer_release_checkpoint(h) == -6 or not nbytes
     lib.gptq_layer_destroy(h)

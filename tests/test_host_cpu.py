@@ -400,8 +400,8 @@ def test_prepared_layer_abi_host_logic():
     st1, st2 = lib.gptq_stripe_bytes(K, N, 4, 128, 1), lib.gptq_stripe_bytes(K, N, 4, 128, 2)
     assert st1 > 0 and lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 0) == a256(st1) and lib.gptq_layer_image_bytes(K, N, 4, 128, 2, 0) == a256(st2)
     qw = (K // 8) * N * 4
-    assert lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 1) == a256(st1) + a256(4 * K) + a256(2 * K) + a256(qw)          # + perm32, perm16, sorted rows
-    assert lib.gptq_layer_image_bytes(K, N, 4, 128, 2, 1) == a256(st2) + a256(4 * K) + a256(2 * K) + 2 * a256(qw)
+    assert lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 1) == a256(st1) + 2 * a256(4 * K) + a256(2 * K)          # + perm32, invperm32, perm16 (round 4: no sorted rows)
+    assert lib.gptq_layer_image_bytes(K, N, 4, 128, 2, 1) == a256(st2) + 2 * a256(4 * K) + a256(2 * K)
     assert lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 2) == 0                   # irregular g_idx: no derived copies
     assert lib.gptq_layer_image_bytes(K, N, 3, 128, 1, 1) == 0                   # 3-bit act-order: generic kernels
     assert lib.gptq_layer_image_bytes(96, 64, 4, 32, 1, 0) == 0                  # K not a multiple of the row block: no stripe image

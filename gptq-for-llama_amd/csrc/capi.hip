@@ -1191,7 +1191,7 @@ static size_t layer_unpacked_bytes(const gptq_layer &L) {
 }
 int gptq_layer_release_checkpoint(gptq_layer_t *layer) {
     if (!layer) return GPTQ_E_NULL;
-    if (layer->kind == 2 || !layer->stripe || (layer->bits != 2 && layer->bits != 4 && layer->bits != 8)) return GPTQ_E_VARIANT;
+    if (layer->kind == 2 || !layer->stripe || (layer->bits == 3 && layer->kind != 0)) return GPTQ_E_VARIANT;   // (no group-sorted image for 3-bit rows)
     layer->released = true;
     // (a regular act-order layer keeps borrowing g_idx -- K ints; qweight / scales / qzeros come back out of the image on demand)
     for (int i = 0; i < 2; i++) layer->qw[i] = nullptr, layer->sc[i] = nullptr, layer->qz[i] = nullptr;

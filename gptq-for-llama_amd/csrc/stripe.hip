@@ -177,15 +177,67 @@ __global__ void __launch_bounds__(256) stripe_untable_kernel(const uint32_t *__r
     }
 }
 
+// ---- 3-bit inverse (round 4): the lane's three image words of a 32-k block -> its 32 fields -> the reference's 96-bit block (rows 3 b .. 3 b + 2
+// of qweight, value j at bits [3 j, 3 j + 3) of the little-endian stream); the zero stream along N likewise
+GPTQ_DEV void put3(uint32_t (&c3)[3], int j, uint32_t v) {
+    const int bit = 3 * j, wi = bit >> 5, off = bit & 31;
+    c3[wi] |= v << off;
+    if (off > 29) c3[wi + 1] |= v >> (32 - off);
+}
+__global__ void __launch_bounds__(256) stripe_unpack3_kernel(const uint32_t *__restrict__ R, uint32_t *__restrict__ qw, int N, int nrb, int NS, int set,
+                                                             size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % N), blk = (int)(i / N);
+        const int stripe = col >> 4, c = col & 15, rb = blk >> 2, l = (blk & 3) * 16 + c;
+        const uint32_t *o = R + ((((size_t)stripe * nrb + rb) * NS + set) * 64 + l) * 3;
+        uint32_t c3[3] = {0u, 0u, 0u}, q30 = 0, q31 = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t w = o[j];
+            q30 |= ((w >> 15) & 1u) << j;
+            q31 |= ((w >> 31) & 1u) << j;
+#pragma unroll
+            for (int pp = 0; pp < 5; pp++) {
+                put3(c3, 10 * j + 2 * pp, (w >> (3 * pp)) & 7u);
+                put3(c3, 10 * j + 2 * pp + 1, (w >> (16 + 3 * pp)) & 7u);
+            }
+        }
+        put3(c3, 30, q30);
+        put3(c3, 31, q31);
+#pragma unroll
+        for (int j = 0; j < 3; j++) qw[((size_t)blk * 3 + j) * N + col] = c3[j];
+    }
+}
+__global__ void __launch_bounds__(256) stripe_untable3_kernel(const uint32_t *__restrict__ tab, half_t *__restrict__ sc, uint32_t *__restrict__ qz, int N,
+                                                              int G, int NS, int set) {
+    const size_t total = (size_t)G * (N / 32);   // one thread per 96-bit block of the zero stream = 32 columns of one group
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int wb = (int)(i % (N / 32)), g = (int)(i / (N / 32));
+        uint32_t c3[3] = {0u, 0u, 0u};
+        for (int j = 0; j < 32; j++) {
+            const int n = wb * 32 + j;
+            const half2_t e = as_half2(tab[(((size_t)(n >> 4) * NS + set) * G + g) * 16 + (n & 15)]);
+            sc[(size_t)g * N + n] = e[0];
+            put3(c3, j, ((uint32_t)(int)(float)e[1] - 1u) & 7u);   // the table holds zero + 1 (not re-masked: 8 for a stored 7)
+        }
+        for (int j = 0; j < 3; j++) qz[((size_t)g * (N / 32) + wb) * 3 + j] = c3[j];
+    }
+}
+
 }  // namespace
 
 int stripe_unpack_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, int set, uint32_t *qw, half_t *sc, int32_t *qz,
                          hipStream_t s, const int32_t *invperm) {
-    if (bits != 2 && bits != 4 && bits != 8) return GPTQ_E_VARIANT;
-    if (stripe_gq_shift(K, N, bits, groupsize) == -2 || set < 0 || set >= nsets || N % (32 / bits) != 0) return GPTQ_E_VARIANT;
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_VARIANT;
+    if (stripe_gq_shift(K, N, bits, groupsize) == -2 || set < 0 || set >= nsets || N % 32 != 0 || (bits == 3 && invperm)) return GPTQ_E_VARIANT;
     const int G = groupsize >= K ? 1 : K / groupsize;
     const uint32_t *R = (const uint32_t *)image;
     const uint32_t *tab = (const uint32_t *)((const char *)image + stripe_tab_offset(K, N, bits, nsets));
+    if (bits == 3) {
+        hipLaunchKernelGGL(stripe_unpack3_kernel, dim3(2048), dim3(256), 0, s, R, qw, N, K / 128, nsets, set, (size_t)(K / 32) * N);
+        hipLaunchKernelGGL(stripe_untable3_kernel, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
+        return (int)hipGetLastError();
+    }
     const size_t words = (size_t)(K / 32 * bits) * N;
     hipLaunchKernelGGL(stripe_unpack_kernel, dim3(2048), dim3(256), 0, s, R, qw, N, K / (16 * (32 / bits)), nsets, set, bits, words, invperm);
     if (bits == 2) hipLaunchKernelGGL(stripe_untable_kernel<2>, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);

@@ -1483,7 +1483,7 @@ def test_prepared_layer_abi_direct(bits, gs, K, N, act, pair):
             assert rel_err(y, exact_forward(x, A, bias)) < TOL, M          # bias: two roundings -> float64 bar
         return y
     ys = {M: check(M) for M in (1, 3, 8, 17, 64, 100, 300)}
-    if nbytes and bits != 3:       # trivial AND (round 4) regular act-order layers: the image -- of the group-sorted rows + both permutations -- is a bijection
+    if nbytes:       # trivial AND (round 4) regular act-order layers -- the image of the group-sorted rows + both permutations --, 3-bit included: a bijection
         assert lib.gptq_layer_release_checkpoint(h) == 0
         keep = [t.clone() for t in a[:3]]
         for t in a[:3] + (b[:3] if pair else []):

@@ -1068,7 +1068,11 @@ int fetch_g_idx(const int32_t *g_idx, int K, hipStream_t s, std::vector<int32_t>
     return (int)e;
 }
 
-bool sorted_supported(int K, int bits, int groupsize) { return (bits == 2 || bits == 4 || bits == 8) && groupsize % (32 / bits) == 0 && K % groupsize == 0 && K <= 65535; }
+// (3-bit: the fields of the 96-bit blocks are gathered one by one while the image is written; a group must not split a 32-k block)
+bool sorted_supported(int K, int bits, int groupsize) {
+    const int unit = bits == 3 ? 32 : 32 / bits;
+    return groupsize % unit == 0 && K % groupsize == 0 && K <= 65535;
+}
 
 }  // namespace
 
@@ -1191,7 +1195,7 @@ static size_t layer_unpacked_bytes(const gptq_layer &L) {
 }
 int gptq_layer_release_checkpoint(gptq_layer_t *layer) {
     if (!layer) return GPTQ_E_NULL;
-    if (layer->kind == 2 || !layer->stripe || (layer->bits == 3 && layer->kind != 0)) return GPTQ_E_VARIANT;   // (no group-sorted image for 3-bit rows)
+    if (layer->kind == 2 || !layer->stripe) return GPTQ_E_VARIANT;
     layer->released = true;
     // (a regular act-order layer keeps borrowing g_idx -- K ints; qweight / scales / qzeros come back out of the image on demand)
     for (int i = 0; i < 2; i++) layer->qw[i] = nullptr, layer->sc[i] = nullptr, layer->qz[i] = nullptr;

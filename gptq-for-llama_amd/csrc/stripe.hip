@@ -79,8 +79,21 @@ __global__ void __launch_bounds__(256) stripe_repack_kernel(const uint32_t *__re
 // 3-bit: a lane's 32 k = three words.  Word j holds k = 10 j .. 10 j + 9 as five 3-bit fields per half-word (even k low, odd k
 // high: pair p = bits [3p+2:3p] of both halves) and bit j of k 30 / k 31 in its spare bits 15 / 31.  Source: the reference's
 // 96-bit blocks (rows 3 b .. 3 b + 2 of qweight hold the 32 k of block b, fields straddling the word boundaries).
+GPTQ_DEV void put3(uint32_t (&c3)[3], int j, uint32_t v) {
+    const int bit = 3 * j, wi = bit >> 5, off = bit & 31;
+    c3[wi] |= v << off;
+    if (off > 29) c3[wi + 1] |= v >> (32 - off);
+}
+GPTQ_DEV uint32_t field3_at(const uint32_t *__restrict__ qw, int N, int col, int k) {   // 3-bit field k of one column in the 96-bit block layout
+    const int bit = 3 * (k & 31), wi = bit >> 5, off = bit & 31;
+    const uint32_t *src = qw + ((size_t)(k >> 5) * 3 + wi) * N + col;
+    uint32_t v = src[0] >> off;
+    if (off > 29) v |= src[N] << (32 - off);
+    return v & 7u;
+}
+// perm != NULL: the group-sorted rows of an act-order layer, gathered field by field (k' = 32 blk + j comes from checkpoint k = perm[k'])
 __global__ void __launch_bounds__(256) stripe_repack3_kernel(const uint32_t *__restrict__ qw0, const uint32_t *__restrict__ qw1,
-                                                             uint32_t *__restrict__ R, int N, int nrb, int NS) {
+                                                             uint32_t *__restrict__ R, int N, int nrb, int NS, const int32_t *__restrict__ perm) {
     const size_t total = (size_t)(N / 16) * nrb * NS * 64;   // one thread per (stripe, row block, set, lane): three output words
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int l = (int)(i & 63);
@@ -89,8 +102,15 @@ __global__ void __launch_bounds__(256) stripe_repack3_kernel(const uint32_t *__r
         const int rb = (int)(b % nrb);
         const int stripe = (int)(b / nrb);
         const int blk = rb * 4 + (l >> 4), col = 16 * stripe + (l & 15);
-        const uint32_t *src = (set ? qw1 : qw0) + (size_t)blk * 3 * N + col;
-        const uint32_t c3[3] = {src[0], src[N], src[2 * (size_t)N]};
+        const uint32_t *qw = set ? qw1 : qw0;
+        uint32_t c3[3];
+        if (perm) {
+            c3[0] = c3[1] = c3[2] = 0u;
+            for (int j = 0; j < 32; j++) put3(c3, j, field3_at(qw, N, col, perm[blk * 32 + j]));
+        } else {
+            const uint32_t *src = qw + (size_t)blk * 3 * N + col;
+            c3[0] = src[0], c3[1] = src[N], c3[2] = src[2 * (size_t)N];
+        }
         const uint32_t q30 = (uint32_t)field_of_block<3>(c3, 30), q31 = (uint32_t)field_of_block<3>(c3, 31);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -179,31 +199,26 @@ __global__ void __launch_bounds__(256) stripe_untable_kernel(const uint32_t *__r
 
 // ---- 3-bit inverse (round 4): the lane's three image words of a 32-k block -> its 32 fields -> the reference's 96-bit block (rows 3 b .. 3 b + 2
 // of qweight, value j at bits [3 j, 3 j + 3) of the little-endian stream); the zero stream along N likewise
-GPTQ_DEV void put3(uint32_t (&c3)[3], int j, uint32_t v) {
-    const int bit = 3 * j, wi = bit >> 5, off = bit & 31;
-    c3[wi] |= v << off;
-    if (off > 29) c3[wi + 1] |= v >> (32 - off);
+GPTQ_DEV uint32_t image3_field(const uint32_t *__restrict__ o, int j) {   // field j (0..31) of a lane's three image words
+    if (j >= 30) {
+        const int sh = j == 30 ? 15 : 31;
+        return ((o[0] >> sh) & 1u) | (((o[1] >> sh) & 1u) << 1) | (((o[2] >> sh) & 1u) << 2);
+    }
+    const int p = j % 10;
+    return (o[j / 10] >> (3 * (p >> 1) + 16 * (p & 1))) & 7u;
 }
+// invperm != NULL: the image holds the group-sorted rows; checkpoint k sits at sorted position invperm[k]
 __global__ void __launch_bounds__(256) stripe_unpack3_kernel(const uint32_t *__restrict__ R, uint32_t *__restrict__ qw, int N, int nrb, int NS, int set,
-                                                             size_t total) {
+                                                             size_t total, const int32_t *__restrict__ invperm) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int col = (int)(i % N), blk = (int)(i / N);
-        const int stripe = col >> 4, c = col & 15, rb = blk >> 2, l = (blk & 3) * 16 + c;
-        const uint32_t *o = R + ((((size_t)stripe * nrb + rb) * NS + set) * 64 + l) * 3;
-        uint32_t c3[3] = {0u, 0u, 0u}, q30 = 0, q31 = 0;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint32_t w = o[j];
-            q30 |= ((w >> 15) & 1u) << j;
-            q31 |= ((w >> 31) & 1u) << j;
-#pragma unroll
-            for (int pp = 0; pp < 5; pp++) {
-                put3(c3, 10 * j + 2 * pp, (w >> (3 * pp)) & 7u);
-                put3(c3, 10 * j + 2 * pp + 1, (w >> (16 + 3 * pp)) & 7u);
-            }
+        const int stripe = col >> 4, c = col & 15;
+        uint32_t c3[3] = {0u, 0u, 0u};
+        for (int j = 0; j < 32; j++) {
+            const int k = invperm ? invperm[blk * 32 + j] : blk * 32 + j;
+            const int b = k >> 5, l = (b & 3) * 16 + c;
+            put3(c3, j, image3_field(R + ((((size_t)stripe * nrb + (b >> 2)) * NS + set) * 64 + l) * 3, k & 31));
         }
-        put3(c3, 30, q30);
-        put3(c3, 31, q31);
 #pragma unroll
         for (int j = 0; j < 3; j++) qw[((size_t)blk * 3 + j) * N + col] = c3[j];
     }
@@ -229,12 +244,12 @@ __global__ void __launch_bounds__(256) stripe_untable3_kernel(const uint32_t *__
 int stripe_unpack_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, int set, uint32_t *qw, half_t *sc, int32_t *qz,
                          hipStream_t s, const int32_t *invperm) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_VARIANT;
-    if (stripe_gq_shift(K, N, bits, groupsize) == -2 || set < 0 || set >= nsets || N % 32 != 0 || (bits == 3 && invperm)) return GPTQ_E_VARIANT;
+    if (stripe_gq_shift(K, N, bits, groupsize) == -2 || set < 0 || set >= nsets || N % 32 != 0) return GPTQ_E_VARIANT;
     const int G = groupsize >= K ? 1 : K / groupsize;
     const uint32_t *R = (const uint32_t *)image;
     const uint32_t *tab = (const uint32_t *)((const char *)image + stripe_tab_offset(K, N, bits, nsets));
     if (bits == 3) {
-        hipLaunchKernelGGL(stripe_unpack3_kernel, dim3(2048), dim3(256), 0, s, R, qw, N, K / 128, nsets, set, (size_t)(K / 32) * N);
+        hipLaunchKernelGGL(stripe_unpack3_kernel, dim3(2048), dim3(256), 0, s, R, qw, N, K / 128, nsets, set, (size_t)(K / 32) * N, invperm);
         hipLaunchKernelGGL(stripe_untable3_kernel, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
         return (int)hipGetLastError();
     }
@@ -270,12 +285,11 @@ size_t stripe_total_bytes(int K, int N, int bits, int groupsize, int nsets) {
 
 int stripe_repack_launch(const uint32_t *qw0, const half_t *sc0, const int32_t *qz0, const uint32_t *qw1, const half_t *sc1, const int32_t *qz1,
                          void *out, int K, int N, int bits, int groupsize, hipStream_t s, const int32_t *perm) {
-    if (perm && bits == 3) return GPTQ_E_VARIANT;   // (no group-sorted image for the 96-bit blocks of 3-bit rows)
     const int NS = qw1 ? 2 : 1;
     const int G = groupsize >= K ? 1 : K / groupsize;
     uint32_t *R = (uint32_t *)out;
     uint32_t *tab = (uint32_t *)((char *)out + stripe_tab_offset(K, N, bits, NS));
-    if (bits == 3) hipLaunchKernelGGL(stripe_repack3_kernel, dim3(2048), dim3(256), 0, s, qw0, qw1, R, N, K / 128, NS);
+    if (bits == 3) hipLaunchKernelGGL(stripe_repack3_kernel, dim3(2048), dim3(256), 0, s, qw0, qw1, R, N, K / 128, NS, perm);
     else hipLaunchKernelGGL(stripe_repack_kernel, dim3(2048), dim3(256), 0, s, qw0, qw1, R, N, K / (16 * (32 / bits)), NS, bits, perm);
     if (bits == 3) hipLaunchKernelGGL(stripe_table_kernel<3>, dim3(512), dim3(256), 0, s, sc0, qz0, sc1, qz1, tab, N, G, NS);
     else if (bits == 2) hipLaunchKernelGGL(stripe_table_kernel<2>, dim3(512), dim3(256), 0, s, sc0, qz0, sc1, qz1, tab, N, G, NS);

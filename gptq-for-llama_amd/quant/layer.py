@@ -92,7 +92,7 @@ class PreparedLayer:
         """memory mode (gptq_layer_release_checkpoint): the handle stops reading qweight / scales / qzeros -- the stripe16 image (of the
         group-sorted rows + both permutations for a regular act-order layer, round 4) is a bijection of them -- and this object lets go of its
         references, so the caller can free them; g_idx stays borrowed.  False (nothing changed) for layers that need the checkpoint layout:
-        irregular act-order, 3-bit, no image."""
+        irregular act-order, no image."""
         if self.lib.gptq_layer_release_checkpoint(self.handle) != 0:
             return False
         self._keep = []          # incl. a converted copy of the key tensor prepared() may have parked here; the bias lives in self._bias

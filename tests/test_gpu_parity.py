@@ -436,8 +436,9 @@ def test_act_order_sorted_fast_path(bits, gs, M):
     assert rel_err(y, y_generic) < TOL
 
 
-@pytest.mark.parametrize('bits,gs,K,N', [(4, 128, 4096, 512), (4, 32, 1024, 160), (8, 64, 1024, 96), (2, 128, 1024, 64), (4, 128, 11008, 256)])
-@pytest.mark.parametrize('M', [2, 4, 7, 16, 50, 100])
+@pytest.mark.parametrize('bits,gs,K,N', [(4, 128, 4096, 512), (4, 32, 1024, 160), (8, 64, 1024, 96), (2, 128, 1024, 64), (4, 128, 11008, 256),
+                                         (3, 128, 4096, 512), (3, 32, 1152, 160)])
+@pytest.mark.parametrize('M', [1, 2, 4, 7, 16, 50, 100])
 def test_act_order_batches_through_stripe_kernels(bits, gs, K, N, M):
     """batches of an act-order layer: one gather x[:, perm], then the stripe16 decode / MFMA-tile kernels on the image of the
     group-sorted rows -- against the oracle on the ORIGINAL checkpoint buffers, and run twice"""
@@ -1084,26 +1085,29 @@ def test_stripe_fused_rmsnorm(K, N, gs, NS):
     assert rel_err(out.cpu().numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize('K,N,gs', [(4096, 4096, 128), (1024, 288, 32), (2176, 64, 64)])
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 4096, 128), (4, 1024, 288, 32), (4, 2176, 64, 64), (3, 4096, 4096, 128), (3, 256, 768, 128), (3, 1152, 288, 32),
+                                         (8, 1024, 96, 64)])
 @pytest.mark.parametrize('norm', [False, True])
-def test_stripe_act_order(K, N, gs, norm):
-    """act-order layer: rows sorted by group at load (gptq_act_order_repack), then striped; x (and the norm weight)
-    gathered through the permutation inside the kernel -- against the oracle on the ORIGINAL g_idx."""
-    L = make_random_layer(4, gs, K, N, act_order=True, seed=K)
+@pytest.mark.parametrize('pair', [False, True])
+def test_stripe_act_order(bits, K, N, gs, norm, pair):
+    """act-order layer (or gate/up pair sharing one permutation): the image holds the rows sorted by group (gathered from the checkpoint layout
+    while it is written); x -- optionally RMS-normalised first -- is gathered through the permutation inside the decode kernel.  Against the
+    oracle on the ORIGINAL g_idx.  3-bit since round 4."""
+    Ls = [make_random_layer(bits, gs, K, N, act_order=True, seed=K + i) for i in range(2 if pair else 1)]
+    for L in Ls[1:]:
+        L['g_idx'] = Ls[0]['g_idx']
     rng = np.random.default_rng(N)
     x = rng.standard_normal((1, K)).astype(np.float16)
-    if not norm:
-        y, ref = check_forward(x, L)             # default dispatch: sorted copy -> stripe image -> XPERM kernel
-        qw = None
-        return
     nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
-    qw, sc, qz, gi = dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx'])
-    srt = QL.act_order_sorted(qw, gi, K, gs, 4)
-    st = QL.stripe_copy(srt[0], sc, qz, 4, gs)
+    sets = tuple(tuple(dev(L[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx')) for L in Ls)
+    pl = quant.layer.prepared(sets, None, bits, gs, K, N)
+    assert pl.kind == 1 and pl.stripe is not None and pl.perm16 is not None
     out = torch.empty((1, N), dtype=torch.float16, device=DEV)
-    QL.stripe_matvec(dev(x), st, out, K, N, 4, gs, norm_weight=dev(nw), eps=1e-6, perm=srt[1])
+    QL.stripe_matvec(dev(x), pl.stripe, out, K, N, bits, gs, nsets=len(Ls), norm_weight=dev(nw) if norm else None, eps=1e-6, perm=pl.perm16)
     torch.cuda.synchronize()
-    ref = oracle.matmul248(oracle.rmsnorm(x, nw, 1e-6), L['qweight'], L['scales'], L['qzeros'], L['g_idx'], 4)
+    xin = oracle.rmsnorm(x, nw, 1e-6) if norm else x
+    ts = [(L['qweight'], L['scales'], L['qzeros'], L['g_idx']) for L in Ls]
+    ref = oracle.fused_mlp(xin, ts[0], ts[1], bits) if pair else oracle.matmul248(xin, *ts[0], bits)
     assert rel_err(out.cpu().numpy(), ref) < TOL
 
 
@@ -1433,7 +1437,8 @@ def test_p2p_allreduce_two_processes_one_gpu(world):
 
 @pytest.mark.parametrize('bits,gs,K,N,act,pair', [(4, 128, 4096, 4096, False, False), (4, 128, 1024, 512, True, False), (4, 128, 4096, 11008, False, True),
                                                  (4, 128, 1024, 288, True, True), (8, 64, 1024, 96, False, False), (3, -1, 512, 320, False, False),
-                                                 (2, 128, 1024, 64, True, False), (4, 32, 416, 288, False, False)])
+                                                 (2, 128, 1024, 64, True, False), (4, 32, 416, 288, False, False), (3, 128, 1024, 288, True, False),
+                                                 (3, 64, 512, 320, True, True)])
 def test_prepared_layer_abi_direct(bits, gs, K, N, act, pair):
     """the product's ONE call site used the way a non-Python consumer uses it: gptq_layer_inspect ->
     gptq_layer_image_bytes -> gptq_layer_prepare -> gptq_layer_forward for M = 1 .. 300 with nothing but raw pointers; act-order layers

@@ -403,7 +403,9 @@ def test_prepared_layer_abi_host_logic():
     assert lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 1) == a256(st1) + 2 * a256(4 * K) + a256(2 * K)          # + perm32, invperm32, perm16 (round 4: no sorted rows)
     assert lib.gptq_layer_image_bytes(K, N, 4, 128, 2, 1) == a256(st2) + 2 * a256(4 * K) + a256(2 * K)
     assert lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 2) == 0                   # irregular g_idx: no derived copies
-    assert lib.gptq_layer_image_bytes(K, N, 3, 128, 1, 1) == 0                   # 3-bit act-order: generic kernels
+    st3 = lib.gptq_stripe_bytes(K, N, 3, 128, 1)
+    assert st3 > 0 and lib.gptq_layer_image_bytes(K, N, 3, 128, 1, 1) == a256(st3) + 2 * a256(4 * K) + a256(2 * K)   # 3-bit act-order too (round 4)
+    assert lib.gptq_layer_image_bytes(K, N, 3, 48, 1, 1) == 0                    # ... unless a group would split a 32-k block
     assert lib.gptq_layer_image_bytes(96, 64, 4, 32, 1, 0) == 0                  # K not a multiple of the row block: no stripe image
     assert lib.gptq_layer_image_bytes(K, N, 4, 128, 3, 0) == 0 and lib.gptq_layer_image_bytes(K, N, 4, 128, 1, 5) == 0
     assert lib.gptq_layer_workspace_bytes() == lib.gptq_query(3) + lib.gptq_query(5)

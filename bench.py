@@ -555,8 +555,9 @@ def prompt_leg(dev):
 
 def config4_leg(dev):
     """BASELINE config 4 (reported only): LLaMA-7B-shaped 3-bit no-group and 4-bit g128 act-order, batch 1, cold weights,
-    through the drop-in matmul248 (3-bit: rowwave3 kernel, an extension -- the reference raises for bits == 3,
-    quant_linear.py:308-309; act-order: rows sorted by group at load + stripe16 kernel with the x gather fused)."""
+    through the drop-in matmul248 (3-bit: its own stripe16 image, dwordx3 per 32 k -- an extension, the reference raises for bits == 3,
+    quant_linear.py:308-309; act-order: image of the rows sorted by group at load + decode kernel with the x gather fused; round 4: 3-bit
+    g128 act-order, the README's `--wbits 3 --groupsize 128 --act-order` flavour, on the same path)."""
     from quant import quant_linear as QL
     gen = torch.Generator(device=dev)
     gen.manual_seed(4)
@@ -572,7 +573,7 @@ def config4_leg(dev):
         return qw, sc, qz, gi
 
     out = {}
-    for label, bits, gs, act in [('w3_nogroup', 3, -1, False), ('w4_g128_act_order', 4, 128, True)]:
+    for label, bits, gs, act in [('w3_nogroup', 3, -1, False), ('w4_g128_act_order', 4, 128, True), ('w3_g128_act_order', 3, 128, True)]:
         out[label] = {'parity': 'unpinned (the reference raises NotImplementedError for bits == 3, quant_linear.py:308-309: no reference output exists; '
                                'checked against the oracle\'s own 3-bit restatement and the float64 product at these sizes, tests/test_gpu_parity.py '
                                'test_config4_full_size_batch1)' if bits == 3 else

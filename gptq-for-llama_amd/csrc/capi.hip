@@ -1186,8 +1186,8 @@ int gptq_layer_stripe_image(const gptq_layer_t *layer, const void **stripe, size
 }
 
 /* Memory mode: the caller is about to FREE the checkpoint buffers (the stripe16 image is a bijection of them: one copy of the packed
- * weights per layer instead of two).  Only for layers whose every decode / small-batch route runs on the image: trivial g_idx, bits
- * 2 / 4 / 8, an image present (else GPTQ_E_VARIANT and nothing changes).  Afterwards the routes that read the checkpoint layout
+ * weights per layer instead of two).  Only for layers whose every decode / small-batch route runs on the image: trivial or regular
+ * act-order g_idx, an image present (else GPTQ_E_VARIANT and nothing changes).  Afterwards the routes that read the checkpoint layout
  * (prefill, fall-backs) first unpack it from the image into `scratch` -- gptq_layer_scratch_bytes() accounts for that. */
 static size_t layer_unpacked_bytes(const gptq_layer &L) {
     const size_t G = L.groupsize >= L.K ? 1 : (size_t)L.K / L.groupsize;

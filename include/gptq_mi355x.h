@@ -426,8 +426,8 @@ int gptq_layer_kind(const gptq_layer_t *layer);
 int gptq_layer_stripe_image(const gptq_layer_t *layer, const void **stripe, size_t *stripe_bytes, const uint16_t **perm16);
 /* Memory mode (reference README.md:23-29 quotes 4891 MiB for 7B 4-bit g128: ONE copy of the packed weights): after this call the
  * caller may free qweight / scales / qzeros -- the stripe16 image is a bijection of them.  Trivial or (round 4) regular act-order g_idx --
- * its image holds the group-sorted rows, the permutation and its inverse; g_idx itself (K ints) stays borrowed --, bits 2 / 4 / 8 (3 bits:
- * trivial g_idx only) and an image (GPTQ_E_VARIANT otherwise, nothing changes).  Routes that read the checkpoint layout (prefill, fall-backs) then rebuild it
+ * its image holds the group-sorted rows, the permutation and its inverse; g_idx itself (K ints) stays borrowed --, any width, and an
+ * image (GPTQ_E_VARIANT otherwise, nothing changes).  Routes that read the checkpoint layout (prefill, fall-backs) then rebuild it
  * from the image into `scratch` per call; gptq_layer_unpack_checkpoint reproduces one weight set bit-exactly (state_dict()). */
 int gptq_layer_release_checkpoint(gptq_layer_t *layer);
 int gptq_layer_unpack_checkpoint(const gptq_layer_t *layer, int set, int32_t *qweight, void *scales, int32_t *qzeros, gptq_stream_t stream);

@@ -1519,11 +1519,11 @@ LLAMA7B_SHAPES = [(4096, 4096), (4096, 11008), (11008, 4096), (4096, 12288)]
 
 
 @pytest.mark.parametrize('K,N', LLAMA7B_SHAPES)
-@pytest.mark.parametrize('variant', ['w3_nogroup', 'w4_g128_act_order'])
+@pytest.mark.parametrize('variant', ['w3_nogroup', 'w4_g128_act_order', 'w3_g128_act_order'])
 def test_config4_full_size_batch1(K, N, variant):
     """3-bit is the layout EXTENSION (the reference raises NotImplementedError, quant_linear.py:308-309: parity unpinned by construction,
     checked against the oracle's own 3-bit restatement AND the float64 product); act-order g_idx as gptq.py:210-216 produces it."""
-    bits, gs, act = (3, -1, False) if variant == 'w3_nogroup' else (4, 128, True)
+    bits, gs, act = {'w3_nogroup': (3, -1, False), 'w4_g128_act_order': (4, 128, True), 'w3_g128_act_order': (3, 128, True)}[variant]
     L = make_random_layer(bits, gs, K, N, act_order=act, seed=K + N + bits)
     x = np.random.default_rng(K + bits).standard_normal((1, K)).astype(np.float16)
     y, ref = check_forward(x, L)

@@ -1658,11 +1658,11 @@ def test_dense_matvec_rejects_bad_arguments():
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize('bits', [3, 4, 8])
 @pytest.mark.parametrize('K,N', [(4096, 12288), (4096, 11008), (4096, 8192), (11008, 4096), (4096, 8224)])
-@pytest.mark.parametrize('M', [5, 16, 17, 32, 33, 48, 65, 100, 128])
+@pytest.mark.parametrize('M', [5, 16, 17, 32, 33, 48, 49, 64, 65, 96, 100, 128])
 def test_small_batches_on_multi_round_shapes(bits, K, N, M):
     """every schedule of gptq_stripe_matmul_f16 that round 4 added or re-routed: C adjacent stripes per workgroup (N = 8192: 2, 11008 / 12288: 3;
-    8224 = 514 stripes = 171 x 3 + 1: a ragged last workgroup), the four-wave instance at 33 .. 48 rows, the sliced tile GEMM from 65 rows on; bias in the
-    epilogue; bit-reproducible"""
+    8224 = 514 stripes = 171 x 3 + 1: a ragged last workgroup), the four-wave instances at 33 .. 64 rows (.. 96 on N = 8192), the sliced tile GEMM from 65
+    rows on elsewhere; bias in the epilogue; bit-reproducible"""
     if bits == 8 and K == 11008:
         pytest.skip('8-bit row block = 64 k: covered by the 4096-k shapes')
     L = make_random_layer(bits, 128, K, N, seed=bits * 1000 + N + M)

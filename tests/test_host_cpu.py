@@ -35,6 +35,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.gptq_strerror(0) == b'ok'
 
 
+def test_no_constant_tables_in_the_built_kernels():
+    """build guard (round 4): a `constexpr` array indexed with a run-time value becomes a table in .rodata (`__const.<function>.<name>`) that the
+    kernel reads with a global load -- and the s_waitcnt vmcnt(0) behind that load also waits for every weight block in flight.  That cost the
+    2- and 3-bit decode kernels 6-13 % (stripe_unpack.inc pair_off, found in the disassembly).  No code object of the library may carry such a
+    table; write selects / arithmetic instead."""
+    path = _native.lib()._name
+    blob = open(path, 'rb').read()
+    assert blob.count(b'__const.') == 0, 'a constant table was emitted into %s: look for __const.* in the disassembly of the new kernel' % path
+
+
 def test_argument_validation_needs_no_gpu():
     lib = _native.lib()
     one = 16

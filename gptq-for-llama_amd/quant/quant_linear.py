@@ -471,8 +471,8 @@ class QuantLinear(nn.Module):
         decode kernels read is a bijection of qweight / scales / qzeros, so those buffers are freed (they become empty
         placeholders) and forward() goes straight to the prepared handle.  ``state_dict()`` still returns the original tensors
         (reproduced bit-exactly from the image), ``load_state_dict`` restores the buffers first.  Inference only.  Returns False
-        -- and changes nothing -- for layers that need the checkpoint layout (irregular act-order g_idx, 3-bit act-order, K not served by the
-        image).  Round 4: regular act-order layers (the image carries the permutation and its inverse; g_idx stays) and 3-bit layers release too."""
+        -- and changes nothing -- for layers that need the checkpoint layout (irregular act-order g_idx, K not served by the image).  Round 4: regular act-order layers (the image carries the permutation and its inverse; g_idx stays) and 3-bit layers, act-order
+        or not, release too."""
         if self._released is not None:
             return True
         if not self.qweight.is_cuda:

@@ -656,13 +656,15 @@ def test_release_checkpoint_memory_mode():
         assert torch.equal(v, sd0[k]), k
 
 
-def test_release_checkpoint_act_order_model():
-    """round 4: memory mode for an --act-order checkpoint.  The image of a regular act-order layer holds the group-sorted rows, the
+@pytest.mark.parametrize('bits', [4, 3])
+def test_release_checkpoint_act_order_model(bits):
+    """round 4: memory mode for an --act-order checkpoint (4-bit, and 3-bit: the layout extension).  The image of a regular act-order layer holds the group-sorted rows, the
     permutation and its inverse -- a bijection of qweight / scales / qzeros (g_idx stays with the module) -- so those buffers are freed like
     a trivial layer's: prefill (tiles on the image after one gather; the dense route on buffers rebuilt from the image) and engine decode are
     bit-identical before and after, state_dict() returns the original tensors bit for bit, and no layer keeps a second copy."""
     import quant
-    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=23, fused=True, act_order=True, **HOOK_CFG)
+    # (3-bit: a seed whose random two-layer model is well conditioned at 3 bits, see test_decode_engine_act_order_checkpoint)
+    model = D.build_random_llama(DEV, bits=bits, groupsize=128, seed=23 if bits == 4 else 5, fused=True, act_order=True, **HOOK_CFG)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     g = torch.Generator(device=DEV).manual_seed(9)
     ids9, ids200 = torch.randint(0, 512, (1, 9), device=DEV, generator=g), torch.randint(0, 512, (1, 200), device=DEV, generator=g)

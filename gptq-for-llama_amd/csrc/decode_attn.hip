@@ -204,7 +204,6 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     __shared__ __attribute__((aligned(16))) half_t knew[ATT_HD];
     __shared__ __attribute__((aligned(16))) half_t vnew[ATT_HD];
     __shared__ float sc[ATT_TS];
-    __shared__ float red[8];
     __shared__ float accs[4][ATT_HD];
     __shared__ int last_flag;
     const int h = blockIdx.x, s = blockIdx.y, nsplit = gridDim.y;
@@ -298,20 +297,13 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     if (dbg) sx_[1] = stamp_cycles(0);
     __syncthreads();
     if (dbg) st_[4] = stamp_cycles(0);
-    float sv = (tid < ATT_TS) ? sc[tid] : -INFINITY;
-    float m = sv;
-    m = att_wave_max(m);
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float p = (tid < nact) ? __expf(sv - m) : 0.f;
-    float l = p;
-    l = att_wave_sum(l);
-    __syncthreads();
-    if (tid < ATT_TS) sc[tid] = p;
-    if (lane == 0) red[4 + wave] = l;
-    __syncthreads();
-    l = red[4] + red[5] + red[6] + red[7];
+    // softmax statistics WITHOUT another barrier (round 4; there were three more here: max through red[], the probabilities written back over
+    // sc[], their sum through red[]): every wave reads all ATT_TS scores (two per lane), reduces max and sum of exp on its own with DPP /
+    // permlane steps -- four redundant copies of 128 values cost less than one LDS round trip + barrier -- and the P V loop below turns the
+    // scores it needs into probabilities itself (eight v_exp per thread).  Empty slots hold -inf: exp -> 0.
+    const float s0 = sc[lane], s1 = sc[lane + 64];
+    const float m = att_wave_max(fmaxf(s0, s1));
+    const float l = att_wave_sum(__expf(s0 - m) + __expf(s1 - m));
     if (dbg) st_[5] = stamp_cycles(__builtin_bit_cast(uint32_t, l));
 
     float av[8];
@@ -323,7 +315,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
         if (it < nit && tl < nact) {
             half8_t v8 = vpre[it];
             if (tl == tnew) v8 = *(const half8_t *)(vnew + d8 * 8);
-            const float pt = sc[tl];
+            const float pt = __expf(sc[tl] - m);
 #pragma unroll
             for (int j = 0; j < 8; j++) av[j] += pt * (float)v8[j];
         }

@@ -175,7 +175,38 @@ def require_device(t, what):
         raise RuntimeError('%s: tensor is on %s -- the MI355X HIP path has no CPU fallback' % (what, t.device))
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+class _NoGuard:
+    __slots__ = ()
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """``with on_device(x.device):`` -- torch.cuda.device(device) only when it is NOT already the current device (kernels are launched on the
+    current device: the guard is needed for a tensor that lives elsewhere, and costs 3-5 us of host time per call where it is not)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(idx)
+
+
 def stream_ptr(device):
+    """raw handle of the CURRENT stream of `device` (asked per call: `with torch.cuda.stream(...)` must be honoured).  The private torch entry
+    returns the handle without building a torch.cuda.Stream object: the module chain asks ~11 times per decoder layer, and
+    torch.cuda.current_stream() cost 2-4 us each (tools/profile_eager_host.py)."""
+    if _raw_stream is not None:
+        idx = device.index if isinstance(device, torch.device) else device
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 
@@ -190,7 +221,7 @@ def workspace(device, stream=None):
     pointing at the one of its capture stream)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if stream is None:
-        stream = torch.cuda.current_stream(torch.device('cuda', idx)).cuda_stream
+        stream = stream_ptr(idx)
     key = (device.type, idx, int(stream))
     ws = _workspaces.get(key)
     if ws is None:
@@ -211,7 +242,7 @@ def layer_workspace(device, stream=None):
     pointing at the one of its capture stream)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if stream is None:
-        stream = torch.cuda.current_stream(torch.device('cuda', idx)).cuda_stream
+        stream = stream_ptr(idx)
     key = (device.type, idx, int(stream))
     ws = _layer_workspaces.get(key)
     if ws is None:
@@ -232,7 +263,7 @@ def mm_workspace(device, stream=None):
     must stay zero, these tiles are overwritten freely."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if stream is None:
-        stream = torch.cuda.current_stream(torch.device('cuda', idx)).cuda_stream
+        stream = stream_ptr(idx)
     key = (device.type, idx, int(stream))
     ws = _mm_workspaces.get(key)
     if ws is None:

@@ -22,7 +22,7 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
         from . import quant_linear
         from .layer import prepared
         quant_linear._apply_prefill_route()
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             c = torch.empty((M, N), device=x.device, dtype=torch.float16)
             if M == 0:
                 return c
@@ -35,12 +35,12 @@ def fused_gate_up(x, gate, up, bits, groupsize, family=None):
         st = None
         if M <= 1024 and all(gi is None for gi in gis):
             st = stripe_copy(_int32c(gate[0]), gate[1], _int32c(gate[2]), bits, groupsize, up=(_int32c(up[0]), up[1], _int32c(up[2])))
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             c = torch.empty((M, N), device=x.device, dtype=torch.float16)
             if st is not None and stripe_matmul(x2, st, c, K, N, bits, groupsize, nsets=2, strict=False):
                 return c
         raise RuntimeError('fused_gate_up: the stripe16 MFMA kernel does not serve this shape')
-    with torch.cuda.device(x.device):
+    with _native.on_device(x.device):
         c = torch.empty((M, N), device=x.device, dtype=torch.float16)
         if M:
             ws = _native.workspace(x.device)
@@ -134,7 +134,7 @@ class QuantLlamaMLP(nn.Module):
             _native.require_device(x, 'QuantLlamaMLP')
             x2 = _as_rows(x.reshape(-1, x.shape[-1]))
             quant_linear._apply_prefill_route()
-            with torch.cuda.device(x2.device):
+            with _native.on_device(x2.device):
                 c = torch.empty((x2.shape[0], self.intermediate_size), device=x2.device, dtype=torch.float16)
                 if x2.shape[0]:
                     self._released.forward(x2, c)

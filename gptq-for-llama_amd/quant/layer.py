@@ -115,11 +115,12 @@ class PreparedLayer:
         """out[M, N] = layer(x[M, K]) on the current stream of x's device.  x: fp16, unit column stride, 16-byte aligned rows."""
         lib = self.lib
         M = x.shape[0]
-        ws = _native.layer_workspace(x.device)
+        stream = _native.stream_ptr(x.device)            # ONE query per call (the workspace is keyed by it)
+        ws = _native.layer_workspace(x.device, stream)
         need = lib.gptq_layer_scratch_bytes(self.handle, M)
         scratch = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None     # caching allocator: the next layer reuses it
         rc = lib.gptq_layer_forward(self.handle, x.data_ptr(), x.stride(0) if M > 1 else self.K, out.data_ptr(), out.stride(0) if M > 1 else self.N, M,
-                                    ws.data_ptr(), ws.numel(), _native.ptr(scratch), need, _native.stream_ptr(x.device))
+                                    ws.data_ptr(), ws.numel(), _native.ptr(scratch), need, stream)
         _native.check(rc, 'gptq_layer_forward')
         return out
 

@@ -322,7 +322,7 @@ def matmul248(input, qweight, scales, qzeros, g_idx, bits, maxq, bias=None, fami
             raise RuntimeError('matmul248: input has %d features, weight expects %d' % (x.shape[1], K))
         M = x.shape[0]
         _apply_prefill_route()
-        with torch.cuda.device(x.device):
+        with _native.on_device(x.device):
             out = torch.empty((M, N), device=x.device, dtype=torch.float16)
             if M == 0:
                 return out
@@ -571,7 +571,7 @@ class QuantLinear(nn.Module):
             _native.require_device(x2, 'QuantLinear.forward')
             xr = _as_rows(x2)
             _apply_prefill_route()
-            with torch.cuda.device(xr.device):
+            with _native.on_device(xr.device):
                 out = torch.empty((xr.shape[0], self.outfeatures), device=xr.device, dtype=torch.float16)
                 if xr.shape[0]:
                     self._released.forward(xr, out)

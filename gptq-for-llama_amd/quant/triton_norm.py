@@ -21,7 +21,7 @@ def rms_norm(x, weight, eps):
     w = weight if (weight.dtype == torch.float16 and weight.is_contiguous()) else weight.half().contiguous()
     if N * 2 > 65536:
         raise RuntimeError("This layer norm doesn't support feature dim >= 64KB.")
-    with torch.cuda.device(x.device):
+    with _native.on_device(x.device):
         y = torch.empty((M, N), dtype=torch.float16, device=x.device)
         if M:
             rc = _native.lib().gptq_rmsnorm_f16(x2.data_ptr(), x2.stride(0) if M > 1 else N, w.data_ptr(), y.data_ptr(), N,

@@ -696,7 +696,8 @@ def decode_tokens_per_s(dev, tokens=64):
       drop_in_forward  the same protocol through the public surface: model(input_ids[:, i:i+1], past_key_values=cache);
                        one-token forwards are answered by the hipGraph decode engine (quant/engine_hook.py)
       drop_in_generate model.generate(...) as llama_inference.py:119-127 calls it
-      engine_graph     quant.decode.DecodeEngine driven directly (one hipGraph replay per token)"""
+      engine_graph     quant.decode.DecodeEngine driven directly (one hipGraph replay per token)
+      engine_graph_bN  DecodeEngine(batch=N): N sequences per replay, aggregate tokens/s"""
     from quant.decode import build_random_llama, benchmark_decode, benchmark_decode_engine, benchmark_generate
     import quant
     model = build_random_llama(dev)
@@ -709,17 +710,21 @@ def decode_tokens_per_s(dev, tokens=64):
     # (README.md:26, protocol llama.py:426-438)
     out['drop_in_forward'] = benchmark_decode(model, tokens)
     out['drop_in_generate'] = benchmark_generate(model)
-    st = getattr(model, '_gptq_engine_state', None)
-    if st is not None:         # the hook's engine (its own 1 GB K/V cache + graph) would sit next to the one measured below: one engine at a time
-        from quant.engine_hook import flush_decode_engine
-        flush_decode_engine(model)
-        st.engine, st.sig = None, None
+    # round 5: generate on FOUR left-padded prompts -- [4, 1] steps with per-row positions answered by DecodeEngine(batch=4)
+    out['drop_in_generate_b4_left_padded'] = benchmark_generate(model, batch=4, left_pad=True, new_tokens=64)
+    from quant.engine_hook import drop_decode_engines
+    drop_decode_engines(model)     # the hook's engines (1 GB of K/V cache per row + a graph each) would sit next to the ones measured below
     torch.cuda.empty_cache()
     done = sum(1 for m in model.modules() if getattr(m, '_released', None) is not None)
     kept = sum(1 for m in model.modules() if isinstance(m, (quant.QuantLinear, quant.fused_mlp.QuantLlamaMLP)) and getattr(m, '_released', None) is None)
     out['engine_graph'] = dict(benchmark_decode_engine(model, tokens=tokens, graph=True), released_modules=done, kept_modules=kept,
                                reference_published_MiB=4891)
     out['tokens_per_s'] = out['engine_graph']['tokens_per_s']
+    # round 5: decode BATCHES -- B sequences per hipGraph replay (linears at M = B: the decode kernel's row groups / 16-row MFMA tiles with
+    # norm and residual fused, per-row positions in the attention launch, ONE pass over the LM head for all rows); aggregate tokens/s
+    for B in (2, 4, 8, 16):
+        torch.cuda.empty_cache()
+        out['engine_graph_b%d' % B] = benchmark_decode_engine(model, tokens=32, graph=True, batch=B)
     return out
 
 

@@ -533,6 +533,28 @@ int gptq_dense_matvec_f16(const void *x, const void *weight, int64_t ldw, const 
                              (hipStream_t)stream);
 }
 
+/* M <= 16 rows of x against a dense fp16 weight [N][K] in ONE pass over the weight: the LM head of a decode batch */
+int gptq_dense_matmat_f16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const void *bias, void *y, int64_t ldy, int M, int N, int K,
+                          const void *norm_weight, float norm_eps, gptq_stream_t stream) {
+    if (!x || !weight || !y) return GPTQ_E_NULL;
+    if (M < 0 || N <= 0 || K <= 0 || K % 8 != 0 || ldw < K || (M > 1 && (ldx < K || ldy < N))) return GPTQ_E_SHAPE;
+    if (M > 16) return GPTQ_E_VARIANT;
+    if (!aligned(x, 16) || !aligned(weight, 16) || ldw % 8 != 0 || !aligned(y, 2) || (norm_weight && !aligned(norm_weight, 16)) || (bias && !aligned(bias, 2)) ||
+        (M > 1 && ldx % 8 != 0))
+        return GPTQ_E_ALIGN;
+    if (M == 0) return GPTQ_OK;
+    return dense_gemv_launch((const half_t *)x, (const half_t *)weight, ldw, (const half_t *)bias, (half_t *)y, N, K, (const half_t *)norm_weight, norm_eps,
+                             (hipStream_t)stream, M, ldx, ldy);
+}
+
+/* y[m][n] = fp16(y[m][n] + r[m][n]) */
+int gptq_add_rows_f16(void *y, int64_t ldy, const void *r, int64_t ldr, int M, int N, gptq_stream_t stream) {
+    if (!y || !r) return GPTQ_E_NULL;
+    if (M < 0 || N <= 0 || ldy < N || ldr < N) return GPTQ_E_SHAPE;
+    if (M == 0) return GPTQ_OK;
+    return add_rows_launch((half_t *)y, ldy, (const half_t *)r, ldr, M, N, (hipStream_t)stream);
+}
+
 int gptq_rope_f16(void *qk, int64_t row_stride, const int64_t *position_ids, int64_t pos_batch_stride, int bsz, int seq,
                   int heads, int head_dim, float base, gptq_stream_t stream) {
     if (!qk || !position_ids) return GPTQ_E_NULL;
@@ -879,6 +901,27 @@ int gptq_decode_attn_fused_table_f16(const void *qkv, const int64_t *position, v
                                     (float *)workspace, heads, t_max, base, scale, rope_table, (u64_t *)g_debug_buffer.load(), (hipStream_t)stream);
 }
 
+/* round 5: a decode BATCH -- row b has its own position (positions[b]; negative = idle row), qkv row (ldq apart), output row (ldo apart) and
+ * [t_max][heads * head_dim] slice of k_cache / v_cache.  rope_table may be NULL (trig in the kernel). */
+size_t gptq_decode_attn_batch_workspace_bytes(int batch, int heads, int head_dim, int t_max) {
+    if (batch <= 0 || heads <= 0 || head_dim != 128 || t_max <= 0) return 0;
+    return decode_attn_ws_bytes(heads, t_max, batch);
+}
+
+int gptq_decode_attn_batch_f16(const void *qkv, int64_t ldq, const int64_t *positions, void *k_cache, void *v_cache, void *out, int64_t ldo,
+                               void *workspace, size_t workspace_bytes, int batch, int heads, int head_dim, int t_max, float base, float scale,
+                               const float *rope_table, gptq_stream_t stream) {
+    if (!qkv || !k_cache || !v_cache || !positions || !out || !workspace) return GPTQ_E_NULL;
+    if (batch <= 0 || batch > 65535 || heads <= 0 || head_dim != 128 || t_max <= 0 || ldq < 3 * (int64_t)heads * head_dim || ldo < (int64_t)heads * head_dim)
+        return GPTQ_E_SHAPE;
+    if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4) || (rope_table && !aligned(rope_table, 8)) ||
+        ldq % 8 != 0 || ldo % 8 != 0 || !aligned(out, 2))
+        return GPTQ_E_ALIGN;
+    if (workspace_bytes < decode_attn_ws_bytes(heads, t_max, batch)) return GPTQ_E_WORKSPACE;
+    return decode_attn_fused_launch((const half_t *)qkv, positions, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out, (float *)workspace, heads, t_max,
+                                    base, scale, rope_table, (u64_t *)g_debug_buffer.load(), (hipStream_t)stream, batch, ldq, ldo);
+}
+
 // ---- stripe16: no-split-K decode GEMV on a load-time repacked copy (stripe*.hip) ----
 size_t gptq_stripe_bytes(int K, int N, int bits, int groupsize, int nsets) { return stripe_total_bytes(K, N, bits, groupsize, nsets); }
 
@@ -900,7 +943,7 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
 
 static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, float *y32,
                          int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
-                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false) {
+                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false, int64_t ldb = 0) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
@@ -908,7 +951,9 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     const int gemm_max = g_stripe_gemm_max_rows.load();
     const bool gemm_rows = mm_ws && M > 128 && M <= gemm_max;
     if (gq == -2 || (M > (mm_ws ? 256 : 16) && !gemm_rows) || (nsets == 2 && bias) || (y32 && bias)) return GPTQ_E_VARIANT;
-    if (M > 1 && (norm_weight || perm || (y32 && M > 4))) return GPTQ_E_VARIANT;
+    if (M > 1 && (perm || (y32 && (M > 4 || norm_weight)))) return GPTQ_E_VARIANT;
+    if (norm_weight && mm_ws) return GPTQ_E_VARIANT;        // the fused norm lives in the decode kernel only (every row its own rstd)
+    if (ldb != 0 && (!bias || ldb < N || y32)) return GPTQ_E_SHAPE;
     if (stripes_bytes < stripe_total_bytes(K, N, bits, groupsize, nsets)) return GPTQ_E_WORKSPACE;
     if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || !aligned(y32, 4) || (norm_weight && !aligned(norm_weight, 16)) ||
         (perm && !aligned(perm, 16)) || (M > 1 && (ldx % 8 != 0 || ldy < N)))
@@ -923,6 +968,7 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.y = (half_t *)y;
     p.y32 = y32;
     p.bias = (const half_t *)bias;
+    p.ldb = ldb;
     p.norm_w = (const half_t *)norm_weight;
     p.norm_eps = norm_eps;
     p.xperm = perm;
@@ -951,6 +997,7 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
         auto pass = [&](int m0, int rows) {
             p.x = (const half_t *)x + (size_t)m0 * ldx;
             p.y = (half_t *)y + (size_t)m0 * ldy;
+            p.bias = (const half_t *)bias + (size_t)m0 * ldb;
             p.M = rows;
             switch (bits) {
                 case 2: return stripe_mm_dispatch_b2(p, mm_ws, mm_ws_bytes, forced, (hipStream_t)stream);
@@ -1342,6 +1389,79 @@ static int layer_forward_checkpoint(const gptq_layer &L, const void *x, int64_t 
     // checkpoint rows: round 3's group-sorted qweight copy, one more qweight per layer kept for this corner, is gone)
     if (int rc = validate(q)) return rc;
     return run_auto(q, (hipStream_t)stream);
+}
+
+// ---- round 5: the operator of the batched decode engine -- y = residual + layer(rmsnorm(x)) for 1 .. 128 rows ----
+// One decoder layer is four of these (qkv with the input norm, o_proj with the residual, gate/up with the post-attention norm, down_proj
+// with the residual: fused_attn.py:117-161, fused_mlp.py:203-218 between HF's norms and adds).  The decode kernel takes norm AND residual
+// into its launch for up to 4 (8 on one-round shapes) rows; the 16-row tiles take the residual into their epilogue and get the norm from a
+// stand-alone launch into `scratch`; everything else is gptq_layer_forward + an add.
+size_t gptq_layer_decode_scratch_bytes(const gptq_layer_t *layer, int M) {
+    if (!layer || M <= 0) return 0;
+    return a256((size_t)M * layer->K * 2) + gptq_layer_scratch_bytes(layer, M);
+}
+
+int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, const void *norm_weight, float norm_eps,
+                          const void *residual, int64_t ldr, void *workspace, size_t workspace_bytes, void *scratch, size_t scratch_bytes,
+                          gptq_stream_t stream) {
+    if (!layer) return GPTQ_E_NULL;
+    const gptq_layer &L = *layer;
+    if (M < 0 || ldx < L.K || ldy < L.N || (residual && ldr < L.N)) return GPTQ_E_SHAPE;
+    if (M == 0) return GPTQ_OK;
+    if (M > LAYER_STRIPE_MM_MAX_M) return GPTQ_E_VARIANT;
+    if (!x || !y) return GPTQ_E_NULL;
+    if (L.nsets == 2 && residual) return GPTQ_E_VARIANT;            // (the SiLU pair has no residual in a LLaMA block)
+    if (!aligned(x, 16) || ldx % 8 != 0 || !aligned(y, 16) || ldy % 8 != 0 || (norm_weight && !aligned(norm_weight, 16)) ||
+        (residual && (!aligned(residual, 16) || ldr % 8 != 0)))
+        return GPTQ_E_ALIGN;
+    if (!workspace || !aligned(workspace, 256) || workspace_bytes < gptq_layer_workspace_bytes()) return GPTQ_E_WORKSPACE;
+    if (scratch && !aligned(scratch, 256)) return GPTQ_E_ALIGN;
+    void *mm_ws = (char *)workspace + WS_BYTES;
+    const int K = L.K, N = L.N, bits = L.bits, gs = L.groupsize, ns = L.nsets;
+    const int rows_max = N <= 4608 ? 8 : 4;
+    const bool add_fused = !(L.bias && residual);                   // one add slot per launch: bias OR residual
+    const void *add = residual && add_fused ? residual : L.bias;
+    const int64_t ldb = residual && add_fused ? ldr : 0;
+    auto finish = [&](int rc) {                                     // the residual of a launch that carried the bias
+        if (rc == 0 && residual && !add_fused) return add_rows_launch((half_t *)y, ldy, (const half_t *)residual, ldr, M, N, (hipStream_t)stream);
+        return rc;
+    };
+    const bool image = L.stripe != nullptr && L.kind != 2;
+    // 1. everything in the decode kernel's launch
+    if (image && M <= rows_max && (L.kind == 0 || M == 1)) {
+        const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, add, y, ldy, nullptr, M, K, N, bits, gs, ns, norm_weight, norm_eps,
+                                     L.kind == 1 ? L.perm16 : nullptr, stream, nullptr, 0, false, ldb);
+        if (rc != GPTQ_E_VARIANT) return finish(rc);
+    }
+    // 2. the norm on its own, into scratch
+    const void *xin = x;
+    int64_t ldin = ldx;
+    char *sp = (char *)scratch;
+    size_t left = scratch_bytes;
+    if (norm_weight) {
+        const size_t nb = a256((size_t)M * K * 2);
+        if (!scratch || left < nb) return GPTQ_E_WORKSPACE;
+        if ((size_t)K * 2 > 65536) return GPTQ_E_NORM_WIDTH;
+        if (int rc = rmsnorm_launch((const half_t *)x, ldx, (const half_t *)norm_weight, (half_t *)sp, K, M, K, norm_eps, (hipStream_t)stream)) return rc;
+        xin = sp; ldin = K;
+        sp += nb; left -= nb;
+    }
+    if (image && L.kind == 0) {
+        if (M <= rows_max && norm_weight) {   // (the decode kernel declined WITH the norm -- LDS -- but may take the rows without it)
+            const int rc = stripe_matvec(xin, ldin, L.stripe, L.stripe_bytes, add, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, nullptr, 0,
+                                         false, ldb);
+            if (rc != GPTQ_E_VARIANT) return finish(rc);
+        }
+        if (M > 4) {                           // 16-row MFMA tiles, the residual in their epilogue
+            const int rc = stripe_matvec(xin, ldin, L.stripe, L.stripe_bytes, add, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, mm_ws,
+                                         STRIPE_MM_WS_BYTES, true, ldb);
+            if (rc != GPTQ_E_VARIANT) return finish(rc);
+        }
+    }
+    // 3. whatever gptq_layer_forward picks (act-order batches after a gather, layers without an image ...), then the add
+    const int rc = gptq_layer_forward(layer, xin, ldin, y, ldy, M, workspace, workspace_bytes, left ? sp : nullptr, left, stream);
+    if (rc == 0 && residual) return add_rows_launch((half_t *)y, ldy, (const half_t *)residual, ldr, M, N, (hipStream_t)stream);
+    return rc;
 }
 
 // ---- GPTQ solver: the sequential loop of one column block (gptq_solver.hip) ----

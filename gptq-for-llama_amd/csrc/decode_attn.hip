@@ -190,13 +190,28 @@ __global__ void __launch_bounds__(ATT_HD) attn_combine_kernel(const float *__res
 // With more than one active split the partial records are published with system-scope
 // (write-through) stores, drained, and a per-head arrival ticket elects the last split to merge
 // them (MI355X_MICROARCH.md, "Valid forms": sc0 sc1 stores AND loads, flag behind vmcnt(0)).
-// ws = [heads][nsplit][ATT_REC] floats followed by [heads] uint32 tickets (zero between launches).
+// ws = [batch][heads][nsplit][ATT_REC] floats followed by [batch][heads] uint32 tickets (zero between launches).
+// Round 5: blockIdx.z = row of a decode BATCH -- every row has its own position (sequences of different lengths; a left-padded prompt is
+// stored without its pads, see quant/engine_hook.py), its own [t_max][heads * 128] slice of the K / V cache, its own qkv row (stride ldq)
+// and output row (stride ldo).  A negative position marks an idle row: nothing is read or written for it.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__restrict__ qkv, const int64_t *__restrict__ pos_ptr,
                                                                 half_t *__restrict__ kc, half_t *__restrict__ vc,
                                                                 half_t *__restrict__ out, float *__restrict__ ws, int heads, int t_max,
                                                                 float inv_base, float scale, const float2 *__restrict__ rope_tab,
-                                                                u64_t *__restrict__ dbg) {
+                                                                u64_t *__restrict__ dbg, int ldq, int ldo) {
+    {   // this workgroup's row of the batch
+        const int b = blockIdx.z;
+        const size_t hdz = (size_t)heads * ATT_HD;
+        pos_ptr += b;
+        qkv += (size_t)b * ldq;
+        out += (size_t)b * ldo;
+        kc += (size_t)b * t_max * hdz;
+        vc += (size_t)b * t_max * hdz;
+        if (b) dbg = nullptr;   // (development stamps: row 0 only)
+    }
+    float *const ws_tickets = ws + (size_t)gridDim.z * heads * gridDim.y * ATT_REC;
+    ws += (size_t)blockIdx.z * heads * gridDim.y * ATT_REC;
     u64_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64_t sx_[4] = {0, 0, 0, 0};   // development stamps (gptq_set_debug_buffer, tools/timeline_attn.py)
     if (dbg) { st_[0] = stamp_realtime(); st_[1] = stamp_cycles(0); }
@@ -363,7 +378,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned *ticket = (unsigned *)(ws + (size_t)heads * nsplit * ATT_REC) + h;
+    unsigned *ticket = (unsigned *)ws_tickets + (size_t)blockIdx.z * heads + h;
     if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (t == (unsigned)(nsp - 1));
@@ -423,11 +438,11 @@ int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, cons
 }
 
 int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
-                             float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s) {
+                             float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s, int batch, int64_t ldq, int64_t ldo) {
     const int nsplit = (t_max + ATT_TS - 1) / ATT_TS;
     const float inv_base = -2.0f * logf(base) / (float)ATT_HD;
-    hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(heads, nsplit), dim3(256), 0, s, qkv, pos, kc, vc, out, ws, heads, t_max, inv_base,
-                       scale, (const float2 *)rope_table, dbg);
+    hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(heads, nsplit, batch), dim3(256), 0, s, qkv, pos, kc, vc, out, ws, heads, t_max, inv_base,
+                       scale, (const float2 *)rope_table, dbg, (int)ldq, (int)ldo);
     return (int)hipGetLastError();
 }
 
@@ -445,8 +460,8 @@ int rope_table_launch(float *table, int t_max, int head_dim, float base, hipStre
     return (int)hipGetLastError();
 }
 
-size_t decode_attn_ws_bytes(int heads, int t_max) {
-    return (size_t)heads * ((t_max + ATT_TS - 1) / ATT_TS) * ATT_REC * sizeof(float) + (size_t)heads * sizeof(unsigned);
+size_t decode_attn_ws_bytes(int heads, int t_max, int batch) {
+    return (size_t)batch * ((size_t)heads * ((t_max + ATT_TS - 1) / ATT_TS) * ATT_REC * sizeof(float) + (size_t)heads * sizeof(unsigned));
 }
 
 }  // namespace gptq

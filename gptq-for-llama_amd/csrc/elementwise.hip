@@ -504,6 +504,26 @@ int gather_cols_launch(const half_t *x, int64_t ldx, const int32_t *perm, half_t
     return (int)hipGetLastError();
 }
 
+// y[m][n] = fp16(y[m][n] + r[m][n]): the residual add of a decoder layer (HF: hidden = residual + proj(..), one fp16 add) for the routes of a
+// decode batch whose kernel has no residual epilogue.  Thread = 8 consecutive n of one row.
+__global__ void __launch_bounds__(256) add_rows_kernel(half_t *__restrict__ y, int64_t ldy, const half_t *__restrict__ r, int64_t ldr, int N) {
+    const int n8 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (n8 >= N) return;
+    const size_t m = blockIdx.y;
+    half8_t a = *(const half8_t *)(y + m * ldy + n8);
+    const half8_t b = *(const half8_t *)(r + m * ldr + n8);
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = (half_t)((float)a[i] + (float)b[i]);
+    *(half8_t *)(y + m * ldy + n8) = a;
+}
+
+int add_rows_launch(half_t *y, int64_t ldy, const half_t *r, int64_t ldr, int M, int N, hipStream_t s) {
+    if (N % 8 != 0 || ldy % 8 != 0 || ldr % 8 != 0 || ((uintptr_t)y % 16) != 0 || ((uintptr_t)r % 16) != 0) return GPTQ_E_ALIGN;
+    if (M <= 0 || M > 65535) return GPTQ_E_SHAPE;
+    hipLaunchKernelGGL(add_rows_kernel, dim3((N / 8 + 255) / 256, M), dim3(256), 0, s, y, ldy, r, ldr, N);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------- act-order row sort
 // qweight_out row r', field j  <-  the field of k = perm[r' * f + j] in qweight (f = 32 / bits).
 // With perm = stable argsort(g_idx) every packed row of the output holds f consecutive members of

@@ -100,10 +100,11 @@ int dense_gemm_f16(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw, c
                    void *ws, size_t ws_bytes, hipStream_t s, bool trans_w = false, bool out_f32 = false);
 // dense_gemv.hip: y[N] = W[N][K] . x (one row of x, dense fp16 weight stored [out, in]; optional RMSNorm of x in front, optional bias)
 int dense_gemv_launch(const half_t *x, const half_t *W, int64_t ldw, const half_t *bias, half_t *y, int N, int K, const half_t *norm_w, float eps,
-                      hipStream_t s);
+                      hipStream_t s, int M = 1, int64_t ldx = 0, int64_t ldy = 0);   // M <= 16 rows of x share ONE pass over W
 int silu_mul_launch(const half_t *g, int64_t ldg, const half_t *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
 int silu_mul_f32_launch(const float *g, int64_t ldg, const float *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
 int gather_cols_launch(const half_t *x, int64_t ldx, const int32_t *perm, half_t *xg, int64_t ldg, int M, int K, hipStream_t s);   // xg = x[:, perm]
+int add_rows_launch(half_t *y, int64_t ldy, const half_t *r, int64_t ldr, int M, int N, hipStream_t s);   // y = fp16(y + r)
 int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 
@@ -115,7 +116,8 @@ struct StripeParams {
     const uint32_t *tab;   // half2 [N/16][NS][G][16] {scale, zero + 1}
     half_t *y;
     const half_t *bias;
-    const half_t *norm_w;  // non-NULL: RMS-normalise x while it is staged (M == 1)
+    int64_t ldb;           // 0: bias[N] added to every row; != 0: `bias` is a residual [M][ldb] added row by row (decode kernel, 16-row tiles)
+    const half_t *norm_w;  // non-NULL: RMS-normalise x while it is staged (decode kernel, every row its own rstd)
     float norm_eps;
     const uint16_t *xperm; // non-NULL: x (and norm_w) gathered through this permutation (M == 1); uint16: K <= 24576 on this path
     float *y32;            // non-NULL: store the fp32 sums [M][NS][N] here instead of fp16 y (no bias): partial of a K-sharded layer (M <= 4)
@@ -143,9 +145,11 @@ int decode_rope_kv_launch(half_t *qkv, const int64_t *pos, half_t *kc, half_t *v
                           hipStream_t s);
 int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, const int64_t *pos, half_t *out, float *ws, int heads,
                        int t_max, float scale, hipStream_t s);
-size_t decode_attn_ws_bytes(int heads, int t_max);
+size_t decode_attn_ws_bytes(int heads, int t_max, int batch = 1);
+// batch rows: pos[batch], qkv rows ldq apart, out rows ldo apart, kc / vc [batch][t_max][heads * 128], ws of decode_attn_ws_bytes(heads, t_max, batch)
 int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
-                             float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s);
+                             float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s, int batch = 1, int64_t ldq = 0,
+                             int64_t ldo = 0);
 int rope_table_launch(float *table, int t_max, int head_dim, float base, hipStream_t s);
 
 }  // namespace gptq

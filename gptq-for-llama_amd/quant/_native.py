@@ -118,6 +118,15 @@ _SIGNATURES = {
     'gptq_set_progress_counter': [c_void_p],
     'gptq_stripe_matmul_partial_f32': [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'gptq_stripe_matvec_partial_f32': [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    # round 5: the batched decode engine
+    'gptq_dense_matmat_f16': [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_float, c_void_p],
+    'gptq_add_rows_f16': [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p],
+    'gptq_decode_attn_batch_workspace_bytes': [c_int, c_int, c_int, c_int],
+    'gptq_decode_attn_batch_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
+                                   c_float, c_float, c_void_p, c_void_p],
+    'gptq_layer_decode_scratch_bytes': [c_void_p, c_int],
+    'gptq_layer_decode_f16': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_size_t,
+                              c_void_p, c_size_t, c_void_p],
 }
 
 
@@ -152,6 +161,8 @@ def lib():
             L.gptq_layer_image_bytes.restype = c_size_t
             L.gptq_layer_workspace_bytes.restype = c_size_t
             L.gptq_layer_scratch_bytes.restype = c_size_t
+            L.gptq_layer_decode_scratch_bytes.restype = c_size_t
+            L.gptq_decode_attn_batch_workspace_bytes.restype = c_size_t
             L.gptq_layer_destroy.restype = None
             L.gptq_strerror.argtypes = [c_int]
             L.gptq_strerror.restype = ctypes.c_char_p
@@ -194,7 +205,9 @@ _NO_GUARD = _NoGuard()
 def on_device(device):
     """``with on_device(x.device):`` -- torch.cuda.device(device) only when it is NOT already the current device (kernels are launched on the
     current device: the guard is needed for a tensor that lives elsewhere, and costs 3-5 us of host time per call where it is not)."""
-    idx = device.index
+    if not isinstance(device, (torch.device, int)):
+        device = torch.device(device)               # 'cuda:0' style strings (bench.py, tools)
+    idx = device if isinstance(device, int) else device.index
     if idx is None or idx == torch.cuda.current_device():
         return _NO_GUARD
     return torch.cuda.device(idx)
@@ -204,9 +217,14 @@ def stream_ptr(device):
     """raw handle of the CURRENT stream of `device` (asked per call: `with torch.cuda.stream(...)` must be honoured).  The private torch entry
     returns the handle without building a torch.cuda.Stream object: the module chain asks ~11 times per decoder layer, and
     torch.cuda.current_stream() cost 2-4 us each (tools/profile_eager_host.py)."""
+    if not isinstance(device, (torch.device, int)):
+        device = torch.device(device)               # 'cuda:0' style strings (bench.py, tools)
     if _raw_stream is not None:
         idx = device.index if isinstance(device, torch.device) else device
-        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
+        try:
+            return _raw_stream(torch.cuda.current_device() if idx is None else idx)
+        except TypeError:                           # a torch version with another private signature: the public (slower) way
+            pass
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -127,29 +127,38 @@ def benchmark_decode(model, tokens=64, seed=0, engine_hook=True):
             'max_memory_MiB': round(torch.cuda.max_memory_allocated(dev) / 1024 / 1024, 1)}
 
 
-def benchmark_generate(model, prompt_len=16, new_tokens=128, seed=0):
+def benchmark_generate(model, prompt_len=16, new_tokens=128, seed=0, batch=1, left_pad=False):
     """``model.generate(input_ids, do_sample=False, max_new_tokens=...)`` as llama_inference.py:119-127 calls it (greedy here
-    so that runs are comparable), wall time of the decode part: (t(new_tokens) - t(1 new token)) / (new_tokens - 1)."""
+    so that runs are comparable), wall time of the decode part: (t(new_tokens) - t(1 new token)) / (new_tokens - 1).
+    batch > 1: that many prompts at once; left_pad: rows of different lengths, left-padded with an attention mask (what a tokenizer
+    with padding_side='left' hands to generate); tokens_per_s is the aggregate over the rows."""
     dev = next(model.parameters()).device
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
-    ids = torch.randint(0, model.config.vocab_size, (1, prompt_len), device=dev, generator=gen)
+    ids = torch.randint(1, model.config.vocab_size, (batch, prompt_len), device=dev, generator=gen)
+    mask = torch.ones_like(ids)
+    if left_pad:
+        for b in range(batch):
+            n = (3 * b + 2) % max(prompt_len - 1, 1) if b < batch - 1 or batch == 1 else 0
+            ids[b, :n] = 0
+            mask[b, :n] = 0
 
     def run(n):
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         with torch.no_grad():
-            out = model.generate(ids, do_sample=False, max_new_tokens=n, min_new_tokens=n)
+            out = model.generate(ids, attention_mask=mask, do_sample=False, max_new_tokens=n, min_new_tokens=n, pad_token_id=0)
         torch.cuda.synchronize(dev)
         return time.perf_counter() - t0, out
     run(4)                                   # warm-up: engine build + graph capture happen here
     t1, _ = run(1)
     tn, out = run(new_tokens)
-    per_tok = (tn - t1) / (new_tokens - 1)
+    per_step = (tn - t1) / (new_tokens - 1)
     from .engine_hook import engine_steps
-    return {'call': 'model.generate(input_ids[1, %d], do_sample=False, max_new_tokens=%d) (llama_inference.py:119-127)' % (prompt_len, new_tokens),
-            'generated': int(out.shape[1] - prompt_len), 's_per_token': round(per_tok, 6), 'tokens_per_s': round(1.0 / per_tok, 1),
-            'engine_steps_total': engine_steps(model)}
+    return {'call': 'model.generate(input_ids[%d, %d]%s, do_sample=False, max_new_tokens=%d) (llama_inference.py:119-127)' % (
+                batch, prompt_len, ', left-padded attention_mask' if left_pad else '', new_tokens),
+            'generated': int(out.shape[1] - prompt_len), 's_per_token': round(per_step / batch, 6), 's_per_step': round(per_step, 6),
+            'tokens_per_s': round(batch / per_step, 1), 'engine_steps_total': engine_steps(model)}
 
 
 # ----------------------------------------------------------------------------------------------
@@ -163,10 +172,47 @@ ROPE_TABLE = os.environ.get('GPTQ_ROPE_TABLE', '1') != '0'
 LM_HEAD_KERNEL = os.environ.get('GPTQ_LM_HEAD_KERNEL', '1') != '0'   # 0: final norm + torch.matmul (hipBLASLt) as in rounds 1-3 (A/B runs)
 
 
+MAX_BATCH = 16         # rows of a decode batch one engine serves (the LM head kernel and the decode kernel's row groups end there)
+
+
+def lm_head_logits(eng, x, logits, s):
+    """shared by DecodeEngine and TPDecodeEngine: logits[B, rows] = lm_head(rmsnorm(x[B, hidden])) (+ lm_head.bias).  The hand-written
+    launch needs an fp16 [rows, hidden] weight with unit column stride whose shape matches the logits buffer (a resized head would write
+    past it: ADVICE r4) -- anything else, or GPTQ_LM_HEAD_KERNEL=0, takes the stand-alone norm + torch.matmul."""
+    W = eng.lm_head
+    bias = getattr(eng, 'lm_head_bias', None)
+    B = x.shape[0]
+    ok = (LM_HEAD_KERNEL and W.dtype == torch.float16 and W.dim() == 2 and W.stride(1) == 1 and W.stride(0) % 8 == 0 and W.shape[1] % 8 == 0 and
+          W.shape[1] == x.shape[1] and W.shape[0] == logits.shape[-1] and B <= MAX_BATCH and (bias is None or bias.dtype == torch.float16))
+    if ok:
+        nw = eng.final_norm if eng.fuse_norm else None
+        if nw is None:
+            eng._norm_rows(x, eng.final_norm, eng.h, s)
+        src = x if nw is not None else eng.h
+        rc = eng.lib.gptq_dense_matmat_f16(src.data_ptr(), src.stride(0), W.data_ptr(), W.stride(0), eng.native.ptr(bias), logits.data_ptr(),
+                                           logits.stride(0), B, W.shape[0], W.shape[1], eng.native.ptr(nw), eng.eps, s)
+        if rc != -6:
+            eng.native.check(rc, 'gptq_dense_matmat_f16')
+            return
+    eng._norm_rows(x, eng.final_norm, eng.h, s)
+    if bias is not None:
+        torch.addmm(bias, eng.h, W.t(), out=logits)
+    else:
+        torch.matmul(eng.h, W.t(), out=logits)
+
+
 class DecodeEngine:
 
-    def __init__(self, model, t_max=2048, fuse_norm=True, fuse_attn=True):
+    def __init__(self, model, t_max=2048, fuse_norm=True, fuse_attn=True, batch=1):
+        """batch (round 5): rows of a decode BATCH -- B sequences advance by one token per step, every row with its own position and its
+        own slice of the K/V cache (the reference's one kernel serves any batch, quant_linear.py:263-269; HF generate drives it with
+        [B, 1] steps).  The linears run at M = B through gptq_layer_decode_f16 (norm and residual inside the decode kernel's launch up to
+        four rows, 16-row MFMA tiles above), attention through gptq_decode_attn_batch_f16, the LM head through gptq_dense_matmat_f16:
+        still ONE hipGraph replay per step."""
         from . import _native
+        self.batch = int(batch)
+        if not 1 <= self.batch <= MAX_BATCH:
+            raise NotImplementedError('DecodeEngine: batch must be 1 .. %d' % MAX_BATCH)
         self.fuse_norm, self.fuse_attn = bool(fuse_norm), bool(fuse_attn)
         self.native = _native
         self.lib = _native.lib()
@@ -183,6 +229,7 @@ class DecodeEngine:
             raise NotImplementedError('DecodeEngine: head_dim must be 128')
         self.embed = model.model.embed_tokens.weight
         self.lm_head = model.lm_head.weight
+        self.lm_head_bias = getattr(model.lm_head, 'bias', None)
         self.final_norm = model.model.norm.weight
         self.layers = []
         for layer in model.model.layers:
@@ -194,26 +241,39 @@ class DecodeEngine:
                 ln1=layer.input_layernorm.weight, ln2=layer.post_attention_layernorm.weight,
                 qkv=self._pack(attn.qkv_proj), o=self._pack(attn.o_proj), down=self._pack(mlp.down_proj),
                 gate=gpack, up=upack, theta=float(attn.rope_theta)))
-        H, I = self.hidden, cfg.intermediate_size
+        H, I, B = self.hidden, cfg.intermediate_size, self.batch
         f16 = dict(dtype=torch.float16, device=dev)
-        self.ids = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.pos = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.x = torch.zeros((1, H), **f16)
-        self.x2 = torch.zeros((1, H), **f16)
-        self.h = torch.zeros((1, H), **f16)
-        self.qkvb = torch.zeros((1, 3 * H), **f16)
-        self.ab = torch.zeros((1, H), **f16)
-        self.cb = torch.zeros((1, I), **f16)
-        self.logits = torch.zeros((1, cfg.vocab_size), **f16)
-        self.stream_out = torch.zeros(self.t_max + 1, dtype=torch.int64, device=dev)   # greedy mode: token chosen after position p
+        self.ids = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.pos = torch.zeros(B, dtype=torch.int64, device=dev)       # per row: tokens consumed so far = the position of the next one
+        self.x = torch.zeros((B, H), **f16)
+        self.x2 = torch.zeros((B, H), **f16)
+        self.h = torch.zeros((B, H), **f16)
+        self.qkvb = torch.zeros((B, 3 * H), **f16)
+        self.ab = torch.zeros((B, H), **f16)
+        self.cb = torch.zeros((B, I), **f16)
+        # sized from the head itself (a resized / padded lm_head has rows != config.vocab_size: ADVICE r4)
+        self.logits = torch.zeros((B, self.lm_head.shape[0]), **f16)
+        self.stream_out = torch.zeros(self.t_max + 1, dtype=torch.int64, device=dev)   # greedy mode (batch 1): token chosen after position p
         self.greedy_graph = None
         nl = len(self.layers)
-        self.kc = torch.zeros((nl, self.t_max, H), **f16)
-        self.vc = torch.zeros((nl, self.t_max, H), **f16)
-        self.attn_ws = torch.zeros(self.lib.gptq_decode_attn_workspace_bytes(self.heads, self.head_dim, self.t_max),
+        self.kcb = torch.zeros((nl, B, self.t_max, H), **f16)          # [layer][row][t][heads * head_dim]
+        self.vcb = torch.zeros((nl, B, self.t_max, H), **f16)
+        self.kc, self.vc = self.kcb[:, 0], self.vcb[:, 0]              # row 0 = THE cache of a batch-1 engine ([layer][t][H] views)
+        self.attn_ws = torch.zeros(self.lib.gptq_decode_attn_batch_workspace_bytes(B, self.heads, self.head_dim, self.t_max),
                                    dtype=torch.uint8, device=dev)
         self.ws = _native.workspace(dev)
         self.graph = None
+        self.scratch = None
+        if B > 1:
+            need = 0
+            for L in self.layers:
+                for w in (L['qkv'], L['o'], L['gate'], L['down']):
+                    pl = w['_keep']
+                    route = self.lib.gptq_layer_route_for(pl.handle, B)
+                    if route not in (1, 2) and not (pl.kind == 1 and route > 0):     # stripe decode kernel / 16-row tiles on the image
+                        raise NotImplementedError('DecodeEngine(batch=%d): a layer has no stripe16 route for %d rows (route %d)' % (B, B, route))
+                    need = max(need, self.lib.gptq_layer_decode_scratch_bytes(pl.handle, B))
+            self.scratch = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
 
     # -- weights: the engine reads the SAME derived copy as the modules -------------------------------------------------------
     # Every linear is taken from quant/layer.py prepared() with exactly the arguments the module's own forward uses, so the eager
@@ -375,7 +435,51 @@ class DecodeEngine:
             tabs[float(theta)] = t
         return t
 
+    # -- a decode batch: every linear is ONE gptq_layer_decode_f16 (y = residual + layer(rmsnorm(x)), M = batch) ------------------------
+    def _lin(self, w, x, y, s, lws, norm=None, residual=None):
+        pl = w['_keep']
+        ptr = self.native.ptr
+        rc = self.lib.gptq_layer_decode_f16(pl.handle, x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), x.shape[0], ptr(norm), self.eps,
+                                            ptr(residual), residual.stride(0) if residual is not None else 0, lws.data_ptr(), lws.numel(),
+                                            self.scratch.data_ptr(), self.scratch.numel(), s)
+        self.native.check(rc, 'gptq_layer_decode_f16')
+
+    def _step_batch(self):
+        lib = self.lib
+        s = self.native.stream_ptr(self.dev)
+        lws = self.native.layer_workspace(self.dev, s)
+        B, H = self.batch, self.hidden
+        torch.index_select(self.embed, 0, self.ids, out=self.x)
+        scale = 1.0 / float(np.sqrt(self.head_dim))
+        for li, L in enumerate(self.layers):
+            if self.fuse_norm:
+                self._lin(L['qkv'], self.x, self.qkvb, s, lws, norm=L['ln1'])                   # qkv = qkv_proj(rmsnorm(x))
+            else:
+                self._norm_rows(self.x, L['ln1'], self.h, s)
+                self._lin(L['qkv'], self.h, self.qkvb, s, lws)
+            tab = self._rope_table(L['theta'], s)
+            rc = lib.gptq_decode_attn_batch_f16(self.qkvb.data_ptr(), self.qkvb.stride(0), self.pos.data_ptr(), self.kcb[li].data_ptr(),
+                                                self.vcb[li].data_ptr(), self.ab.data_ptr(), self.ab.stride(0), self.attn_ws.data_ptr(),
+                                                self.attn_ws.numel(), B, self.heads, self.head_dim, self.t_max, L['theta'], scale,
+                                                self.native.ptr(tab), s)
+            self.native.check(rc, 'gptq_decode_attn_batch_f16')
+            self._lin(L['o'], self.ab, self.x2, s, lws, residual=self.x)                       # x2 = x + o_proj(attn)
+            if self.fuse_norm:
+                self._lin(L['gate'], self.x2, self.cb, s, lws, norm=L['ln2'])                   # c = silu(gate(h)) * up(h), h = rmsnorm(x2)
+            else:
+                self._norm_rows(self.x2, L['ln2'], self.h, s)
+                self._lin(L['gate'], self.h, self.cb, s, lws)
+            self._lin(L['down'], self.cb, self.x, s, lws, residual=self.x2)                    # x = x2 + down(c)
+        self._lm_head(s)
+        self.pos.add_(1)
+
+    def _norm_rows(self, x, w, y, s):
+        rc = self.lib.gptq_rmsnorm_f16(x.data_ptr(), x.stride(0), w.data_ptr(), y.data_ptr(), y.stride(0), x.shape[0], self.hidden, self.eps, s)
+        self.native.check(rc, 'gptq_rmsnorm_f16')
+
     def _step(self):
+        if self.batch > 1:
+            return self._step_batch()
         lib, ptr = self.lib, self.native.ptr
         s = torch.cuda.current_stream(self.dev).cuda_stream
         H = self.hidden
@@ -410,21 +514,10 @@ class DecodeEngine:
         self.pos.add_(1)
 
     def _lm_head(self, s):
-        """logits = lm_head(rmsnorm(x)): the model's final norm and its dense fp16 LM head in ONE hand-written launch (gptq_dense_matvec_f16,
-        csrc/dense_gemv.hip); a head the kernel does not take (odd strides, dtypes) goes through the stand-alone norm + torch.matmul."""
-        W = self.lm_head
-        if W.dtype == torch.float16 and W.dim() == 2 and W.stride(1) == 1 and W.stride(0) % 8 == 0 and W.shape[1] % 8 == 0 and LM_HEAD_KERNEL:
-            nw = self.final_norm if self.fuse_norm else None
-            if nw is None:
-                self._norm(self.x, self.final_norm, self.h, s)
-            src = self.x if nw is not None else self.h
-            rc = self.lib.gptq_dense_matvec_f16(src.data_ptr(), W.data_ptr(), W.stride(0), None, self.logits.data_ptr(), W.shape[0], W.shape[1],
-                                                self.native.ptr(nw), self.eps, s)
-            if rc != -6:
-                self.native.check(rc, 'gptq_dense_matvec_f16')
-                return
-        self._norm(self.x, self.final_norm, self.h, s)
-        torch.matmul(self.h, self.lm_head.t(), out=self.logits)
+        """logits = lm_head(rmsnorm(x)): the model's final norm and its dense fp16 LM head in ONE hand-written launch (gptq_dense_matmat_f16,
+        csrc/dense_gemv.hip: one pass over the weight for all rows of a batch); a head the kernel does not take (odd strides, dtypes) goes
+        through the stand-alone norm + torch.matmul."""
+        lm_head_logits(self, self.x, self.logits, s)
 
     def reset(self):
         self.pos.zero_()
@@ -465,9 +558,9 @@ class DecodeEngine:
         return self
 
     def decode(self, token):
-        """one token in, logits [1, vocab] out (the static buffer: clone it to keep it)."""
+        """one token per row in ([batch] ids), logits [batch, vocab] out (the static buffer: clone it to keep it)."""
         if torch.is_tensor(token):
-            self.ids.copy_(token.reshape(1))
+            self.ids.copy_(token.reshape(self.batch))
         else:
             self.ids.fill_(int(token))
         with torch.no_grad():
@@ -530,36 +623,43 @@ def engine_generate(model, input_ids, max_new_tokens, eos_token_id=None, engine=
     return torch.cat([input_ids[0], gen.to(input_ids.dtype)]).unsqueeze(0)
 
 
-def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fuse_norm=True, fuse_attn=True, start_pos=0):
-    """the llama.py:385-438 protocol on the DecodeEngine (hipGraph replay per token)."""
+def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fuse_norm=True, fuse_attn=True, start_pos=0, batch=1):
+    """the llama.py:385-438 protocol on the DecodeEngine (hipGraph replay per token).  batch > 1: B sequences advance together, one
+    replay per step; tokens_per_s is the aggregate (B tokens per step)."""
     dev = next(model.parameters()).device
     torch.cuda.synchronize(dev)
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
-    eng = DecodeEngine(model, t_max=t_max, fuse_norm=fuse_norm, fuse_attn=fuse_attn)
+    eng = DecodeEngine(model, t_max=t_max, fuse_norm=fuse_norm, fuse_attn=fuse_attn, batch=batch)
     if graph:
         eng.capture()
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
-    input_ids = torch.randint(0, model.config.vocab_size, (1, tokens), device=dev, generator=gen)
+    input_ids = torch.randint(0, model.config.vocab_size, (batch, tokens), device=dev, generator=gen)
     times = []
     eng.reset()
     if start_pos:      # decode at depth: pretend start_pos tokens are already cached (random K/V rows)
-        eng.kc.normal_(0, 0.5)
-        eng.vc.normal_(0, 0.5)
+        eng.kcb.normal_(0, 0.5)
+        eng.vcb.normal_(0, 0.5)
         eng.pos.fill_(int(start_pos))
     for i in range(tokens):
         torch.cuda.synchronize(dev)
         tick = time.perf_counter()
-        eng.decode(input_ids[0, i])
+        eng.decode(input_ids[:, i])
         torch.cuda.synchronize(dev)
         times.append(time.perf_counter() - tick)
     med = float(np.median(times[2:])) if len(times) > 4 else float(np.median(times))
-    return {'protocol': 'llama.py:385-438 (one token per step, KV cache, sync per step, median)',
-            'mode': 'DecodeEngine, %s' % ('one hipGraph replay per token' if graph else 'eager launches'), 'tokens': tokens,
-            't_max': t_max, 'start_pos': start_pos, 'fused_norm': fuse_norm, 'fused_attention': fuse_attn,
-            # per layer: [norm,] qkv, [rope+append, attention partial, merge | one fused launch], o+residual, [norm,] gate/up, down+residual
-            'launches_per_token': (9 - 2 * int(fuse_norm) - 2 * int(fuse_attn)) * len(eng.layers) + 4, 'median_s_per_token': round(med, 6),
-            'tokens_per_s': round(1.0 / med, 1),
-            # the llama.py:426-438 figure: peak bytes in use by tensors while decoding (model + derived copies + KV cache of t_max + engine buffers)
-            'max_memory_MiB': round(torch.cuda.max_memory_allocated(dev) / 1024 / 1024, 1)}
+    res = {'protocol': 'llama.py:385-438 (one token per step, KV cache, sync per step, median)',
+           'mode': 'DecodeEngine, %s' % ('one hipGraph replay per token' if graph else 'eager launches'), 'tokens': tokens,
+           't_max': t_max, 'start_pos': start_pos, 'fused_norm': fuse_norm, 'fused_attention': fuse_attn,
+           # per layer: [norm,] qkv, [rope+append, attention partial, merge | one fused launch], o+residual, [norm,] gate/up, down+residual
+           'launches_per_token': (9 - 2 * int(fuse_norm) - 2 * int(fuse_attn)) * len(eng.layers) + 4, 'median_s_per_token': round(med, 6),
+           'tokens_per_s': round(batch / med, 1),
+           # the llama.py:426-438 figure: peak bytes in use by tensors while decoding (model + derived copies + KV cache of t_max + engine buffers)
+           'max_memory_MiB': round(torch.cuda.max_memory_allocated(dev) / 1024 / 1024, 1)}
+    if batch > 1:
+        res['batch'] = batch
+        res['mode'] = 'DecodeEngine(batch=%d), %s' % (batch, 'one hipGraph replay per step' if graph else 'eager launches')
+        res['median_s_per_step'] = res.pop('median_s_per_token')
+        res.pop('launches_per_token')
+    return res

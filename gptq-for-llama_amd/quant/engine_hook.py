@@ -21,15 +21,24 @@ the engine holds.  It is brought up to date
     from the cache length, so the cache must be complete).  A caller that starts again at the lagging length (it never saw the
     engine's tokens and re-sends them, e.g. a second ``generate(full_ids, past_key_values=cache)``) gets NOTHING appended: the eager
     forward recomputes those tokens itself, appending them as well would duplicate K/V entries.
-Eligibility is decided once per sequence, on the first untracked step (one host sync): batch 1, one new token, an
-all-ones 2-D attention mask of exactly the cache length + 1 (left padding -> eager) and, when given, position_ids /
-cache_position equal to the cache length.  ``GPTQ_DECODE_ENGINE=0`` disables the hook.
+Eligibility is decided once per sequence, on the first untracked step (one host sync): one new token per row, at most
+``decode.MAX_BATCH`` rows, a 2-D attention mask of exactly the cache length + 1 whose zeros -- if any -- are a LEFT-padding prefix
+of each row, and, when given, position_ids / cache_position that continue the rows.  ``GPTQ_DECODE_ENGINE=0`` disables the hook.
+
+Round 5 -- batches and left padding.  ``model.generate`` on several prompts sends ``[B, 1]`` steps with a left-padded mask and per-row
+``position_ids`` (= tokens of the row so far).  The engine keeps every row as an UNPADDED sequence: row b of its K/V cache holds the
+``T - npad_b`` real tokens of the caller's cache (the pads the prefill computed K/V for are masked out for ever, so they are simply not
+copied), its position is ``T - npad_b`` -- what HF's position_ids say -- and the attention launch runs over exactly that many entries.
+Going back (``_sync_back``) the engine-only tokens of row b are appended at the caller's uniform index, where HF expects them.  One engine
+(graph, static K/V cache) per batch size, at most ``MAX_ENGINES`` alive.
 """
 import os
 import types
 import weakref
 
 import torch
+
+from .decode import MAX_BATCH
 
 ENABLED = os.environ.get('GPTQ_DECODE_ENGINE', '1') != '0'
 # Memory mode is the DEFAULT since round 4: when the engine is first built every eligible module (trivial g_idx, 2 / 4 / 8 bits, an image)
@@ -39,11 +48,18 @@ ENABLED = os.environ.get('GPTQ_DECODE_ENGINE', '1') != '0'
 RELEASE_CHECKPOINT = os.environ.get('GPTQ_RELEASE_CHECKPOINT', '1') != '0'
 
 
+MAX_ENGINES = 4       # engines (one per batch size) kept alive per model; the least recently used one goes first
+
+
 class _State:
-    __slots__ = ('engine', 'sig', 'cache_ref', 'hf_len', 'pos', 'steps')
+    __slots__ = ('engine', 'engines', 'declined', 'sig', 'cache_ref', 'hf_len', 'pos', 'steps', 'npad', 'released')
 
     def __init__(self):
         self.engine, self.sig, self.cache_ref, self.hf_len, self.pos, self.steps = None, None, None, 0, 0, 0
+        self.engines = {}         # batch size -> DecodeEngine (insertion order = recency)
+        self.declined = set()     # batch sizes the model has no engine route for
+        self.npad = None          # per row of the tracked batch: pads of the caller's left-padded cache (host ints)
+        self.released = False
 
 
 def _signature(model):
@@ -78,82 +94,140 @@ def _cache_len(cache):
 
 
 def _sync_back(st, upto=None):
-    """append the tokens only the engine holds -- positions [hf_len, min(upto, pos)) -- to the caller's cache."""
+    """append the tokens only the engine holds -- positions [hf_len, min(upto, pos)) of the caller's (uniform, padded) index -- to the
+    caller's cache; row r of the engine stores them npad[r] entries earlier (it keeps the row without its pads)."""
     cache = st.cache_ref() if st.cache_ref is not None else None
     if cache is None or st.pos <= st.hf_len or st.engine is None:
         return
     eng, a, b = st.engine, st.hf_len, st.pos if upto is None else min(int(upto), st.pos)
     if b <= a:
         return
+    npad = st.npad if st.npad is not None else [0] * eng.batch
     for li in range(len(eng.layers)):
-        k = eng.kc[li, a:b].view(b - a, eng.heads, eng.head_dim).transpose(0, 1).unsqueeze(0)
-        v = eng.vc[li, a:b].view(b - a, eng.heads, eng.head_dim).transpose(0, 1).unsqueeze(0)
+        k = torch.stack([eng.kcb[li, r, a - n:b - n].view(b - a, eng.heads, eng.head_dim).transpose(0, 1) for r, n in enumerate(npad)])
+        v = torch.stack([eng.vcb[li, r, a - n:b - n].view(b - a, eng.heads, eng.head_dim).transpose(0, 1) for r, n in enumerate(npad)])
         cache.update(k.contiguous(), v.contiguous(), li)
     st.hf_len = b
 
 
-def _sync_in(st, cache, T):
-    """copy the caller's cache (T tokens) into the engine's static cache."""
+def _sync_in(st, cache, T, npad=None):
+    """copy the caller's cache (T entries per row, the first npad[r] of row r being pads) into the engine's static cache."""
     from .decode import _cache_layer_kv
     eng = st.engine
+    npad = [0] * eng.batch if npad is None else npad
     if T:
         for li in range(len(eng.layers)):
             k, v = _cache_layer_kv(cache, li)
-            eng.kc[li, :T].copy_(k[0].transpose(0, 1).reshape(T, -1))
-            eng.vc[li, :T].copy_(v[0].transpose(0, 1).reshape(T, -1))
-    eng.pos.fill_(T)
-    st.cache_ref, st.hf_len, st.pos = weakref.ref(cache), T, T
+            for r, n in enumerate(npad):
+                if T - n > 0:
+                    eng.kcb[li, r, :T - n].copy_(k[r, :, n:T].transpose(0, 1).reshape(T - n, -1))
+                    eng.vcb[li, r, :T - n].copy_(v[r, :, n:T].transpose(0, 1).reshape(T - n, -1))
+    eng.pos.copy_(torch.tensor([T - n for n in npad], dtype=torch.int64), non_blocking=False)
+    st.cache_ref, st.hf_len, st.pos, st.npad = weakref.ref(cache), T, T, (npad if any(npad) else None)
 
 
-def _start_position(position_ids, kw):
-    """first position of the incoming tokens when the call says so (cache_position wins), else None.  One host sync."""
-    for t in (kw.get('cache_position'), position_ids):
-        if torch.is_tensor(t) and t.numel():
-            return int(t.reshape(-1)[0])
+def _start_index(st, position_ids, kw):
+    """index in the caller's cache at which the incoming tokens start, when the call says so (cache_position wins; position_ids of row 0
+    are that row's TOKEN count, the cache index lies its left pads further), else None.  One host sync."""
+    cp = kw.get('cache_position')
+    if torch.is_tensor(cp) and cp.numel():
+        return int(cp.reshape(-1)[0])
+    if torch.is_tensor(position_ids) and position_ids.numel():
+        return int(position_ids.reshape(-1)[0]) + (st.npad[0] if st.npad is not None else 0)
     return None
 
 
-def _engine_forward(model, st, input_ids, cache, attention_mask, position_ids, kw):
-    """one token through the DecodeEngine, or None when this call has to go the eager way."""
-    from .decode import DecodeEngine
-    sig = _signature(model)
-    if st.sig != sig or st.engine is None:
-        if not _eligible_model(model):      # (walks all layers: only when the weights changed identity, not once per token)
-            return None
-    elif model.training:
+def _left_pads(attention_mask, T):
+    """pads per row of a [B, T + 1] mask whose zeros form a left prefix of every row (what a tokenizer with padding_side='left' and HF
+    generate produce), or None when the mask is anything else (holes, right padding, a fully masked row).  One host sync."""
+    m = attention_mask != 0
+    npad = (~m).sum(1)
+    form = m == (torch.arange(T + 1, device=m.device)[None, :] >= npad[:, None])
+    flat = torch.cat([npad, form.all().reshape(1).to(npad.dtype)]).tolist()
+    if not flat[-1] or max(flat[:-1]) > T:
         return None
-    if st.engine is None or st.sig != sig:
-        t_max = int(min(max(getattr(model.config, 'max_position_embeddings', 2048), 256), 8192))
-        if RELEASE_CHECKPOINT:      # memory mode: from the first decode step on ONE copy of the packed weights (quant.release_checkpoint)
+    return [int(n) for n in flat[:-1]]
+
+
+def _engine_for(model, st, B, sig):
+    """the engine of this batch size (built and captured on first use), or None when the model has no route for it"""
+    from .decode import DecodeEngine
+    if st.sig != sig:
+        st.engines.clear()
+        st.declined.clear()
+        st.engine, st.cache_ref, st.released = None, None, False
+        if not _eligible_model(model):      # (walks all layers: only when the weights changed identity, not once per token)
+            return None, sig
+    elif model.training:
+        return None, sig
+    if B in st.declined:
+        return None, sig
+    eng = st.engines.get(B)
+    if eng is None:
+        if RELEASE_CHECKPOINT and not st.released:      # memory mode: from the first decode step on ONE copy of the packed weights
             from . import release_checkpoint
             release_checkpoint(model)
+            st.released = True
             sig = _signature(model)     # the placeholders are new tensor objects
-        st.engine = DecodeEngine(model, t_max=t_max).capture()
-        st.sig, st.cache_ref = sig, None
-    eng = st.engine
+        t_max = int(min(max(getattr(model.config, 'max_position_embeddings', 2048), 256), 8192))
+        try:
+            eng = DecodeEngine(model, t_max=t_max, batch=B).capture()
+        except NotImplementedError:
+            st.declined.add(B)
+            st.sig = sig
+            return None, sig
+        while len(st.engines) >= MAX_ENGINES:
+            old = next(iter(st.engines))
+            if st.engines[old] is st.engine:
+                _sync_back(st)
+                st.engine, st.cache_ref = None, None
+            del st.engines[old]
+        st.sig = sig
+    else:
+        del st.engines[B]               # re-insert: most recently used last
+    st.engines[B] = eng
+    return eng, sig
+
+
+def _engine_forward(model, st, input_ids, cache, attention_mask, position_ids, kw):
+    """one token per row through the DecodeEngine of this batch size, or None when this call has to go the eager way."""
+    B = input_ids.shape[0]
+    eng, sig = _engine_for(model, st, B, _signature(model))
+    if eng is None:
+        return None
     T = _cache_len(cache)
     if T is None:
         return None
-    tracked = st.cache_ref is not None and st.cache_ref() is cache and T == st.hf_len
+    tracked = st.engine is eng and st.cache_ref is not None and st.cache_ref() is cache and T == st.hf_len
     pos = st.pos if tracked else T
-    if attention_mask is not None and (attention_mask.dim() != 2 or attention_mask.shape[0] != 1 or attention_mask.shape[-1] != pos + 1):
+    if attention_mask is not None and (attention_mask.dim() != 2 or attention_mask.shape[0] != B or attention_mask.shape[-1] != pos + 1):
         return None          # a mask that is not "everything so far" (4-D masks, other lengths): eager
     if pos + 1 > eng.t_max:
         return None
     if not tracked:
-        # once per sequence (host sync): the mask must be ALL ones -- a left-padded prompt has a correctly shaped mask with zeros
-        # and shifted positions, the engine would attend to the pads -- and explicit positions must continue the cache
-        if attention_mask is not None and not bool(attention_mask.all()):
+        # once per sequence (host sync): zeros in the mask must be left padding, and explicit positions must continue the rows
+        npad = None
+        if attention_mask is not None:
+            npad = _left_pads(attention_mask, T)
+            if npad is None:
+                return None
+        cp = kw.get('cache_position')
+        if torch.is_tensor(cp) and cp.numel() and int(cp.reshape(-1)[0]) != T:
             return None
-        start = _start_position(position_ids, kw)
-        if start is not None and start != T:
-            return None
-        _sync_in(st, cache, T)
-    logits = eng.decode(input_ids.reshape(1))
+        if torch.is_tensor(position_ids) and position_ids.numel():
+            want = torch.tensor([T - n for n in (npad or [0] * B)], device=position_ids.device, dtype=position_ids.dtype)
+            got = position_ids.reshape(position_ids.shape[0], -1)[:, 0]
+            if got.numel() not in (1, B) or not bool((got == want).all()):
+                return None
+        if st.cache_ref is not None:
+            _sync_back(st)   # another sequence was being tracked: leave its cache complete before the engine moves on
+        st.engine = eng
+        _sync_in(st, cache, T, npad)
+    logits = eng.decode(input_ids.reshape(B))
     st.pos += 1
     st.steps += 1
     from transformers.modeling_outputs import CausalLMOutputWithPast
-    return CausalLMOutputWithPast(loss=None, logits=logits.view(1, 1, -1).clone(), past_key_values=cache)
+    return CausalLMOutputWithPast(loss=None, logits=logits.view(B, 1, -1).clone(), past_key_values=cache)
 
 
 def install_decode_engine(model):
@@ -169,7 +243,7 @@ def install_decode_engine(model):
                 labels=None, use_cache=None, **kw):
         fast = (ENABLED and not getattr(self, '_gptq_engine_disabled', False) and input_ids is not None and inputs_embeds is None
                 and labels is None and use_cache is not False and past_key_values is not None and hasattr(past_key_values, 'update')
-                and input_ids.dim() == 2 and input_ids.shape[0] == 1 and input_ids.shape[1] == 1 and input_ids.is_cuda
+                and input_ids.dim() == 2 and 1 <= input_ids.shape[0] <= MAX_BATCH and input_ids.shape[1] == 1 and input_ids.is_cuda
                 and not torch.is_grad_enabled() and not kw.get('output_attentions') and not kw.get('output_hidden_states')
                 and not torch.cuda.is_current_stream_capturing())
         if fast:
@@ -179,7 +253,7 @@ def install_decode_engine(model):
         if st.cache_ref is not None and st.cache_ref() is past_key_values and st.pos > st.hf_len:
             # the eager path continues the tracked cache: it must hold the engine's tokens up to where THIS call starts (see the
             # module docstring: explicit positions decide, a bare call needs the complete cache)
-            _sync_back(st, _start_position(position_ids, kw))
+            _sync_back(st, _start_index(st, position_ids, kw))
         elif st.cache_ref is not None:
             _sync_back(st)    # another cache object takes over: leave the tracked one complete
         st.cache_ref = None
@@ -210,6 +284,17 @@ def flush_decode_engine(model):
     if st is not None and st.cache_ref is not None:
         _sync_back(st)
         st.cache_ref = None
+
+
+def drop_decode_engines(model):
+    """flush, then free every engine the hook built (graphs, static K/V caches); the next one-token forward builds what it needs again"""
+    st = getattr(model, '_gptq_engine_state', None)
+    if st is None:
+        return
+    flush_decode_engine(model)
+    st.engines.clear()
+    st.declined.clear()
+    st.engine, st.sig, st.cache_ref, st.npad = None, None, None, None
 
 
 def engine_steps(model):

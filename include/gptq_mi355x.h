@@ -450,6 +450,34 @@ enum {
 int gptq_layer_route_for_shape(int M, int K, int N, int bits, int groupsize, int nsets, int kind, int has_image);
 int gptq_layer_route_for(const gptq_layer_t *layer, int M);
 
+/* ---- Batched decode (round 5) --------------------------------------------------------------------------------------------
+ * The reference serves every batch with the one kernel (matmul248 masks M only, quant/quant_linear.py:263-269, :373-377) and HF
+ * `generate` drives it with [B, 1] steps, left-padded prompts and per-row position_ids (llama_inference.py:119-127).  The entries
+ * below are what a graph-captured decode step of B <= 16 sequences is made of (quant/decode.py DecodeEngine(batch = B)):
+ *
+ * gptq_layer_decode_f16      y[M][N] = residual[M][..] + layer(rmsnorm(x[M][K]))   (norm_weight / residual may be NULL; 1 <= M <= 128)
+ *     one decoder block = four of these (input norm -> qkv, o_proj + residual, post-attention norm -> gate/up with SiLU, down_proj
+ *     + residual: quant/fused_attn.py:117-161, quant/fused_mlp.py:203-218 between HF's norms and adds).  The decode kernel takes norm
+ *     and residual into its own launch up to 4 rows (8 on shapes one round of workgroups covers); the 16-row MFMA tiles take the
+ *     residual into their epilogue, the norm then is one launch into `scratch` (gptq_layer_decode_scratch_bytes).  The residual is
+ *     added to the ROUNDED product (fp16(fp16(acc) + r)), as the module chain does it (one fp16 tensor add).  y must not alias x.
+ * gptq_decode_attn_batch_f16  the fused RoPE + KV append + single-query attention launch (gptq_decode_attn_fused_table_f16) for B rows:
+ *     positions[b] (negative = idle row), qkv row b at qkv + b ldq, out row b at out + b ldo, cache slice b at k_cache + b t_max heads 128.
+ * gptq_dense_matmat_f16       y[M][N] = rmsnorm(x)[M][K] . W[N][K]^T, M <= 16, ONE pass over the dense fp16 weight (the LM head).
+ * gptq_add_rows_f16           y = fp16(y + r), row by row.
+ */
+size_t gptq_layer_decode_scratch_bytes(const gptq_layer_t *layer, int M);
+int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, const void *norm_weight,
+                          float norm_eps, const void *residual, int64_t ldr, void *workspace, size_t workspace_bytes, void *scratch,
+                          size_t scratch_bytes, gptq_stream_t stream);
+size_t gptq_decode_attn_batch_workspace_bytes(int batch, int heads, int head_dim, int t_max);
+int gptq_decode_attn_batch_f16(const void *qkv, int64_t ldq, const int64_t *positions, void *k_cache, void *v_cache, void *out, int64_t ldo,
+                               void *workspace, size_t workspace_bytes, int batch, int heads, int head_dim, int t_max, float base, float scale,
+                               const float *rope_table, gptq_stream_t stream);
+int gptq_dense_matmat_f16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const void *bias, void *y, int64_t ldy, int M, int N,
+                          int K, const void *norm_weight, float norm_eps, gptq_stream_t stream);
+int gptq_add_rows_f16(void *y, int64_t ldy, const void *r, int64_t ldr, int M, int N, gptq_stream_t stream);
+
 /* ---- GPTQ solver (the caller that PRODUCES the weights; reference gptq.py:128-228) -------------------------------
  * One column block [i1, i1 + count), count <= 128, of the sequential quantise / error-feedback loop (gptq.py:177-199)
  * for all rows at once, in the reference's own fp32 arithmetic (IEEE division, round-half-even, no contraction).

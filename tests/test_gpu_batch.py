@@ -1,0 +1,402 @@
+"""Round 5: the batched decode path -- B sequences advance by one token per hipGraph replay.
+
+The reference serves any batch with its one kernel (matmul248 masks M only, quant/quant_linear.py:263-269, :373-377) and HF ``generate``
+drives it with [B, 1] steps, left-padded prompts and per-row position_ids (llama_inference.py:119-127).  Here:
+  * op level, through the C ABI: gptq_layer_decode_f16 (y = residual + layer(rmsnorm(x)), 1 .. 128 rows) against the oracle's
+    rmsnorm + matmul248 / fused_mlp; gptq_decode_attn_batch_f16 against B single-row launches (bit-exact) and against torch SDPA;
+    gptq_dense_matmat_f16 against the float64 product; gptq_add_rows_f16;
+  * engine level: DecodeEngine(batch = B) against the eager module chain run on the same batch;
+  * caller level: model.generate on left-padded prompts goes through the engine and gives the eager chain's tokens.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import quant
+from quant import decode as D
+from quant import _native
+from quant.layer import prepared
+from oracle import oracle
+from util import TOL, make_random_layer, rel_err, within
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _prepared(Ls, gs, K, N, bits, bias=None):
+    sets = tuple((dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx'])) for L in Ls)
+    return prepared(sets, None if bias is None else dev(bias), bits, K if gs == -1 else gs, K, N), sets
+
+
+def _decode(pl, x, M, N, norm=None, eps=1e-6, residual=None, ldr=None):
+    lib = _native.lib()
+    s = _native.stream_ptr(torch.device(DEV))
+    ws = _native.layer_workspace(torch.device(DEV), s)
+    need = lib.gptq_layer_decode_scratch_bytes(pl.handle, M)
+    scratch = torch.empty(max(need, 256), dtype=torch.uint8, device=DEV)
+    y = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+    rc = lib.gptq_layer_decode_f16(pl.handle, x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), M, _native.ptr(norm), eps, _native.ptr(residual),
+                                   0 if residual is None else (ldr or residual.stride(0)), ws.data_ptr(), ws.numel(), scratch.data_ptr(), scratch.numel(), s)
+    _native.check(rc, 'gptq_layer_decode_f16')
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+def _expect(x, Ls, bits, nw, eps, res, bias=None):
+    """fp16(fp16(layer(rmsnorm(x)) [+ bias]) + residual): the module chain's roundings (norm launch -> QuantLinear -> tensor add)"""
+    xn = oracle.rmsnorm(x, nw, eps) if nw is not None else x
+    sets = [(L['qweight'], L['scales'], L['qzeros'], L['g_idx']) for L in Ls]
+    y = oracle.matmul248(xn, *sets[0], bits, bias=bias) if len(Ls) == 1 else oracle.fused_mlp(xn, sets[0], sets[1], bits)
+    if res is not None:
+        y = (y.astype(np.float32) + res.astype(np.float32)).astype(np.float16)
+    return y
+
+
+@pytest.mark.parametrize('M', [1, 2, 3, 4, 5, 8, 9, 16, 17, 40, 128])
+@pytest.mark.parametrize('bits,K,N,gs,NS', [(4, 4096, 4096, 128, 1), (4, 1024, 288, 64, 1), (4, 4096, 11008, 128, 2), (4, 2176, 64, 32, 2), (4, 11008, 256, 128, 1),
+                                            (8, 1024, 96, 64, 1), (3, 1152, 96, 128, 1), (2, 1024, 64, 128, 2)])
+def test_layer_decode_norm_and_residual(bits, K, N, gs, NS, M):
+    """every rung of gptq_layer_decode_f16's ladder: norm + residual inside the decode kernel (M <= 4, 8 on one-round shapes), its row
+    groups, the 16-row tiles with the residual in their epilogue and the norm as its own launch"""
+    Ls = [make_random_layer(bits, gs, K, N, seed=500 + bits + i) for i in range(NS)]
+    pl, _keep = _prepared(Ls, gs, K, N, bits)
+    rng = np.random.default_rng(K + M)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+    res = rng.standard_normal((M, N)).astype(np.float16)
+    for use_norm in (False, True):
+        for use_res in ((False,) if NS == 2 else (False, True)):
+            y = _decode(pl, dev(x), M, N, norm=dev(nw) if use_norm else None, residual=dev(res) if use_res else None)
+            ref = _expect(x, Ls, bits, nw if use_norm else None, 1e-6, res if use_res else None)
+            assert np.isfinite(y.astype(np.float32)).all(), (use_norm, use_res)
+            # with a residual both sides round twice: the bar is held on the sum, normalised by it
+            assert rel_err(y, ref) < (TOL if not use_res else 1.5 * TOL), (use_norm, use_res, rel_err(y, ref))
+
+
+def test_layer_decode_bias_and_residual_strided():
+    """a layer WITH a bias and a residual (one add slot per launch: the bias rides, the residual is a second launch), strided x / residual
+    rows, y into a wider buffer"""
+    K, N, bits, gs = 1024, 288, 4, 128
+    L = make_random_layer(bits, gs, K, N, seed=91)
+    rng = np.random.default_rng(3)
+    bias = rng.standard_normal(N).astype(np.float16)
+    pl, _keep = _prepared([L], gs, K, N, bits, bias=bias)
+    for M in (2, 4, 7, 20):
+        xw = dev(rng.standard_normal((M, K + 64)).astype(np.float16))
+        rw = dev(rng.standard_normal((M, N + 32)).astype(np.float16))
+        x, r = xw[:, :K], rw[:, :N]
+        nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+        y = _decode(pl, x, M, N, norm=dev(nw), residual=r)
+        ref = _expect(x.cpu().numpy(), [L], bits, nw, 1e-6, None, bias=bias)
+        ref = (ref.astype(np.float32) + r.cpu().numpy().astype(np.float32)).astype(np.float16)
+        assert rel_err(y, ref) < 2 * TOL, (M, rel_err(y, ref))
+
+
+def test_layer_decode_act_order_batches():
+    """a regular act-order layer: M = 1 gathers x inside the decode kernel (norm fused), batches go through gptq_layer_forward's gather"""
+    K, N, bits, gs = 1024, 288, 4, 128
+    L = make_random_layer(bits, gs, K, N, act_order=True, seed=17)
+    pl, _keep = _prepared([L], gs, K, N, bits)
+    assert pl.kind == 1
+    rng = np.random.default_rng(4)
+    for M in (1, 3, 6, 20):
+        x = rng.standard_normal((M, K)).astype(np.float16)
+        nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+        res = rng.standard_normal((M, N)).astype(np.float16)
+        y = _decode(pl, dev(x), M, N, norm=dev(nw), residual=dev(res))
+        assert rel_err(y, _expect(x, [L], bits, nw, 1e-6, res)) < 1.5 * TOL, M
+
+
+@pytest.mark.parametrize('B,pos', [(2, [0, 5]), (4, [3, 130, -1, 127]), (3, [300, 128, 0]), (16, list(range(0, 160, 10)))])
+def test_decode_attention_batch_rows_equal_single_row_launches(B, pos):
+    """row b of gptq_decode_attn_batch_f16 is bit for bit the single-row launch at pos[b] on row b's cache slice (idle rows: untouched),
+    and both equal torch SDPA over the row's own history"""
+    lib = _native.lib()
+    heads, hd, t_max = 2, 128, 384
+    H = heads * hd
+    s = _native.stream_ptr(torch.device(DEV))
+    g = torch.Generator(device=DEV).manual_seed(B)
+    qkv = torch.randn((B, 3 * H), device=DEV, generator=g).half()
+    kc = (torch.randn((B, t_max, H), device=DEV, generator=g) * 0.5).half()
+    vc = (torch.randn((B, t_max, H), device=DEV, generator=g) * 0.5).half()
+    p = torch.tensor(pos, dtype=torch.int64, device=DEV)
+    tab = torch.empty((t_max, hd // 2, 2), dtype=torch.float32, device=DEV)
+    _native.check(lib.gptq_rope_table_f32(tab.data_ptr(), t_max, hd, 10000.0, s), 'rope table')
+    scale = 1.0 / np.sqrt(hd)
+    # batch launch
+    kb, vb = kc.clone(), vc.clone()
+    out = torch.full((B, H), float('nan'), dtype=torch.float16, device=DEV)
+    ws = torch.zeros(lib.gptq_decode_attn_batch_workspace_bytes(B, heads, hd, t_max), dtype=torch.uint8, device=DEV)
+    rc = lib.gptq_decode_attn_batch_f16(qkv.data_ptr(), 3 * H, p.data_ptr(), kb.data_ptr(), vb.data_ptr(), out.data_ptr(), H, ws.data_ptr(), ws.numel(), B, heads,
+                                        hd, t_max, 10000.0, scale, tab.data_ptr(), s)
+    _native.check(rc, 'gptq_decode_attn_batch_f16')
+    # one launch per row
+    ws1 = torch.zeros(lib.gptq_decode_attn_workspace_bytes(heads, hd, t_max), dtype=torch.uint8, device=DEV)
+    for b in range(B):
+        if pos[b] < 0:
+            assert torch.isnan(out[b]).all() and torch.equal(kb[b], kc[b])      # idle row: nothing read, nothing written
+            continue
+        k1, v1 = kc[b].clone(), vc[b].clone()
+        o1 = torch.empty((1, H), dtype=torch.float16, device=DEV)
+        rc = lib.gptq_decode_attn_fused_table_f16(qkv[b].data_ptr(), p[b:b + 1].data_ptr(), k1.data_ptr(), v1.data_ptr(), o1.data_ptr(), ws1.data_ptr(),
+                                                  ws1.numel(), heads, hd, t_max, 10000.0, scale, tab.data_ptr(), s)
+        _native.check(rc, 'gptq_decode_attn_fused_table_f16')
+        torch.cuda.synchronize()
+        assert torch.equal(o1[0], out[b]), b
+        assert torch.equal(k1, kb[b]) and torch.equal(v1, vb[b]), b
+        # ... and the arithmetic: SDPA of the rotated q over rows [0, pos] of the updated cache
+        T = pos[b] + 1
+        q = qkv[b, :H].view(heads, hd)                        # rotate q (twice: the op takes a q | k pair) with the product's RoPE
+        qk = torch.stack([q, q]).view(1, 1, 2, heads, hd).contiguous()
+        quant.fused_attn.hip_rotate_half_(qk, p[b:b + 1].view(1, 1))
+        qr = qk[0, 0, 0].float()                              # [heads, hd]
+        kk = kb[b, :T].view(T, heads, hd).transpose(0, 1).float()
+        vv = vb[b, :T].view(T, heads, hd).transpose(0, 1).float()
+        att = torch.softmax((qr[:, None, :] * kk).sum(-1) * scale, dim=-1)
+        ref = (att[:, :, None] * vv).sum(1).reshape(-1)
+        assert rel_err(out[b].float().cpu().numpy(), ref.cpu().numpy()) < 2e-3, b
+
+
+@pytest.mark.parametrize('M', [1, 2, 3, 4, 7, 8, 13, 16])
+@pytest.mark.parametrize('N,K', [(32000, 4096), (1000, 512), (515, 1288)])
+def test_dense_matmat_lm_head(M, N, K):
+    """the LM head of a decode batch: M rows against a dense fp16 [N][K] weight in one pass, final RMSNorm fused or not, vs float64"""
+    lib = _native.lib()
+    rng = np.random.default_rng(N + M)
+    W = (rng.standard_normal((N, K)) * 0.02).astype(np.float16)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+    dW, dx, dn = dev(W), dev(x), dev(nw)
+    s = _native.stream_ptr(torch.device(DEV))
+    for norm in (False, True):
+        y = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+        rc = lib.gptq_dense_matmat_f16(dx.data_ptr(), K, dW.data_ptr(), K, None, y.data_ptr(), N, M, N, K, dn.data_ptr() if norm else None, 1e-6, s)
+        _native.check(rc, 'gptq_dense_matmat_f16')
+        torch.cuda.synchronize()
+        xin = oracle.rmsnorm(x, nw, 1e-6) if norm else x
+        ref = xin.astype(np.float64) @ W.astype(np.float64).T
+        got = y.cpu().numpy()
+        assert np.isfinite(got.astype(np.float32)).all()
+        assert rel_err(got, ref) < TOL, (norm, rel_err(got, ref))
+        if M > 1:        # rows are independent: row 0 of the batch == the one-row launch
+            y1 = torch.empty((1, N), dtype=torch.float16, device=DEV)
+            _native.check(lib.gptq_dense_matmat_f16(dx.data_ptr(), K, dW.data_ptr(), K, None, y1.data_ptr(), N, 1, N, K, dn.data_ptr() if norm else None, 1e-6, s), 'm1')
+            torch.cuda.synchronize()
+            assert rel_err(y1.cpu().numpy()[0], got[0]) < 2e-4
+
+
+def test_add_rows():
+    lib = _native.lib()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    y = torch.randn((5, 4096 + 64), device=DEV, generator=g).half()
+    r = torch.randn((5, 4096), device=DEV, generator=g).half()
+    want = (y[:, :4096].float() + r.float()).half()
+    keep = y[:, 4096:].clone()
+    _native.check(lib.gptq_add_rows_f16(y.data_ptr(), y.stride(0), r.data_ptr(), r.stride(0), 5, 4096, _native.stream_ptr(torch.device(DEV))), 'add')
+    torch.cuda.synchronize()
+    assert torch.equal(y[:, :4096], want) and torch.equal(y[:, 4096:], keep)
+
+
+# ------------------------------------------------------------------------------------------------------------ engine level
+HD128 = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+             vocab_size=512, max_position_embeddings=512)
+ENGINE_TOL = 2.7e-3     # as tests/test_gpu_model.py: DecodeEngine vs the module chain on the same drop-in modules
+HOOK_TOL = 2e-2
+
+
+def run_steps(model, ids, prefill, mask=None):
+    """the eager module chain on a batch: prefill, then one token per row and step"""
+    from transformers.cache_utils import DynamicCache
+    cache = DynamicCache(config=model.config)
+    outs = []
+    model._gptq_engine_disabled = True
+    try:
+        with torch.no_grad():
+            out = model(ids[:, :prefill], past_key_values=cache, use_cache=True)
+            outs.append(out.logits[:, -1].float().cpu().numpy())
+            for i in range(prefill, ids.shape[1]):
+                out = model(ids[:, i:i + 1], past_key_values=cache, use_cache=True)
+                outs.append(out.logits[:, -1].float().cpu().numpy())
+    finally:
+        model._gptq_engine_disabled = False
+    return np.stack(outs)
+
+
+@pytest.mark.parametrize('graph', [False, True])
+@pytest.mark.parametrize('B', [2, 4, 5, 8, 16])
+def test_batched_decode_engine_matches_the_module_chain(B, graph):
+    """DecodeEngine(batch = B): every row's logits, step by step, against the HF decoder running the same drop-in modules on the batch"""
+    q = D.build_random_llama(DEV, seed=3 + B, **HD128)
+    ids = torch.randint(0, HD128['vocab_size'], (B, 9), device=DEV, generator=torch.Generator(device=DEV).manual_seed(B))
+    expect = run_steps(q, ids, 1)                       # [steps, B, vocab]
+    eng = D.DecodeEngine(q, t_max=64, batch=B)
+    if graph:
+        eng.capture()
+    got = np.stack([eng.decode(ids[:, i]).float().cpu().numpy() for i in range(ids.shape[1])])
+    within('engine_b%d_g%d' % (B, graph), np.abs(got - expect).max() / np.abs(expect).max(), ENGINE_TOL)
+    assert eng.pos.tolist() == [9] * B
+    r = D.benchmark_decode_engine(q, tokens=6, t_max=64, graph=graph, batch=B)
+    assert r['tokens_per_s'] > 0 and r['batch'] == B
+
+
+def test_batched_decode_engine_rows_at_different_depths_and_unfused():
+    """rows with DIFFERENT histories: row b is first fed b + 1 private tokens (the other rows idle, position -1), then all rows advance
+    together; each row must equal a batch-1 engine that saw only that row's tokens.  Also the unfused-norm variant of the step."""
+    q = D.build_random_llama(DEV, seed=21, **HD128)
+    B, vocab = 3, HD128['vocab_size']
+    g = torch.Generator(device=DEV).manual_seed(5)
+    hist = [torch.randint(0, vocab, (b + 1,), device=DEV, generator=g) for b in range(B)]
+    joint = torch.randint(0, vocab, (B, 5), device=DEV, generator=g)
+    for fuse in (True, False):
+        eng = D.DecodeEngine(q, t_max=64, batch=B, fuse_norm=fuse)
+        for b in range(B):                                # private prefixes, one row at a time
+            for t in hist[b]:
+                keep = eng.pos.clone()
+                eng.pos.fill_(-1)
+                eng.pos[b] = keep[b]
+                eng.decode(torch.full((B,), int(t), device=DEV))
+                new = keep.clone()
+                new[b] += 1
+                eng.pos.copy_(new)                        # (idle rows were bumped from -1 to 0 by the step: restore)
+        assert eng.pos.tolist() == [1, 2, 3]
+        got = np.stack([eng.decode(joint[:, i]).float().cpu().numpy() for i in range(joint.shape[1])])      # [5, B, vocab]
+        for b in range(B):
+            e1 = D.DecodeEngine(q, t_max=64)
+            for t in hist[b]:
+                e1.decode(t)
+            ref = np.stack([e1.decode(joint[b, i]).float().cpu().numpy()[0] for i in range(joint.shape[1])])
+            within('engine_rows_depth_f%d' % fuse, np.abs(got[:, b] - ref).max() / np.abs(ref).max(), ENGINE_TOL)
+
+
+@pytest.mark.parametrize('bits,gs,act', [(8, 64, False), (3, 128, False), (4, 128, True)])
+def test_batched_decode_engine_other_widths_and_act_order(bits, gs, act):
+    q = D.build_random_llama(DEV, bits=bits, groupsize=gs, seed=9 + bits, act_order=act, **HD128)
+    B = 4
+    ids = torch.randint(0, HD128['vocab_size'], (B, 7), device=DEV, generator=torch.Generator(device=DEV).manual_seed(bits))
+    expect = run_steps(q, ids, 1)
+    eng = D.DecodeEngine(q, t_max=64, batch=B).capture()
+    got = np.stack([eng.decode(ids[:, i]).float().cpu().numpy() for i in range(ids.shape[1])])
+    within('engine_b4_w%d_act%d' % (bits, act), np.abs(got - expect).max() / np.abs(expect).max(), ENGINE_TOL)
+
+
+# ------------------------------------------------------------------------------------------------------------ caller level
+HOOK_CFG = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                vocab_size=512, max_position_embeddings=256)
+
+
+def _generate(model, ids, mask, n, hook):
+    model._gptq_engine_disabled = not hook
+    try:
+        with torch.no_grad():
+            out = model.generate(ids, attention_mask=mask, do_sample=False, max_new_tokens=n, min_new_tokens=n, pad_token_id=0,
+                                 return_dict_in_generate=True, output_logits=True)
+    finally:
+        model._gptq_engine_disabled = False
+    return out.sequences[:, ids.shape[1]:].cpu().numpy(), torch.stack([l.float() for l in out.logits]).cpu().numpy(), out
+
+
+def _left_padded(B, T, seed):
+    ids = torch.randint(1, 512, (B, T), device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+    mask = torch.ones_like(ids)
+    for b in range(B):
+        n = 0 if (b == B - 1 and B > 1) else (3 * b + 2) % (T - 1)      # 2, 5, 8, ... pads: rows of different lengths; the last row of a batch has none
+        ids[b, :n] = 0
+        mask[b, :n] = 0
+    return ids, mask
+
+
+@pytest.mark.parametrize('B', [1, 4, 11])
+def test_generate_on_left_padded_prompts_goes_through_the_engine(B):
+    """model.generate on B left-padded prompts (llama_inference.py:119-127 with a batch): every step after the prefill is ONE engine
+    replay at M = B; tokens equal the eager module chain's, row by row, up to the first step where the eager chain itself has no clear
+    winner (margin-aware, as the batch-1 test); logits within the hook tolerance at every compared step."""
+    from quant.engine_hook import engine_steps
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=30 + B, fused=True, **HOOK_CFG)
+    ids, mask = _left_padded(B, 10, seed=B)
+    n = 24
+    tok_e, log_e, _ = _generate(model, ids, mask, n, hook=False)
+    assert engine_steps(model) == 0
+    tok_h, log_h, out = _generate(model, ids, mask, n, hook=True)
+    assert engine_steps(model) == n - 1                       # every step after the prefill, ONE engine step per [B, 1] forward
+    assert out.past_key_values.get_seq_length() == 10 + n - 1   # the caller's cache came back complete (flushed on return)
+    for b in range(B):
+        compared = 0
+        for i in range(n):
+            scale = max(1.0, np.abs(log_e[i, b]).max())
+            within('hook_left_pad_b%d' % B, np.abs(log_h[i, b] - log_e[i, b]).max() / scale, HOOK_TOL)
+            if tok_e[b, i] != tok_h[b, i]:
+                top2 = np.sort(log_e[i, b])[-2:]
+                assert top2[1] - top2[0] < HOOK_TOL * scale, 'engine token differs at a step with a clear winner (row %d step %d)' % (b, i)
+                break
+            compared += 1
+        assert compared >= 8, (b, compared)
+
+
+def test_batched_hook_keeps_the_callers_cache_consistent():
+    """engine steps on a left-padded batch, then a multi-token eager forward on the SAME cache (the engine-only tokens must have been
+    appended at the caller's uniform index), then engine steps again: logits of a run that never used the engine"""
+    from transformers.cache_utils import DynamicCache
+    from quant.engine_hook import engine_steps
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=41, fused=True, **HOOK_CFG)
+    B = 3
+    ids, mask0 = _left_padded(B, 6, seed=8)
+    more = torch.randint(1, 512, (B, 14), device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+
+    def run(hook):
+        model._gptq_engine_disabled = not hook
+        cache = DynamicCache(config=model.config)
+        outs = []
+        mask = mask0.clone()
+        pos_of = lambda m, n: (m.cumsum(1) - 1).clamp(min=0)[:, -n:]
+        with torch.no_grad():
+            outs.append(model(ids, attention_mask=mask, position_ids=pos_of(mask, 6), past_key_values=cache, use_cache=True).logits[:, -1])
+            t = 0
+            for _ in range(6):                                                                     # engine steps when hooked
+                mask = torch.cat([mask, torch.ones((B, 1), dtype=mask.dtype, device=DEV)], 1)
+                outs.append(model(more[:, t:t + 1], attention_mask=mask, position_ids=pos_of(mask, 1), past_key_values=cache, use_cache=True).logits[:, -1])
+                t += 1
+            mask = torch.cat([mask, torch.ones((B, 3), dtype=mask.dtype, device=DEV)], 1)          # three tokens at once: eager
+            outs.append(model(more[:, t:t + 3], attention_mask=mask, position_ids=pos_of(mask, 3), past_key_values=cache, use_cache=True).logits[:, -1])
+            t += 3
+            for _ in range(3):                                                                     # and back to the engine
+                mask = torch.cat([mask, torch.ones((B, 1), dtype=mask.dtype, device=DEV)], 1)
+                outs.append(model(more[:, t:t + 1], attention_mask=mask, position_ids=pos_of(mask, 1), past_key_values=cache, use_cache=True).logits[:, -1])
+                t += 1
+        model._gptq_engine_disabled = False
+        quant.engine_hook.flush_decode_engine(model)
+        return torch.stack(outs).float().cpu().numpy(), cache.get_seq_length()
+    ref, len_e = run(False)
+    before = engine_steps(model)
+    got, len_h = run(True)
+    assert engine_steps(model) == before + 9
+    assert len_e == len_h == 6 + 6 + 3 + 3
+    within('hook_batch_mixed', np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), HOOK_TOL)
+
+
+def test_hook_declines_masks_that_are_not_left_padding():
+    """holes or right padding in the mask: the engine would attend to entries the caller masked -- the hook must hand those calls to the
+    module chain (and give the eager result)"""
+    from transformers.cache_utils import DynamicCache
+    from quant.engine_hook import engine_steps
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=42, fused=True, **HOOK_CFG)
+    B = 2
+    ids = torch.randint(1, 512, (B, 8), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    mask = torch.ones_like(ids)
+    mask[0, 3] = 0                                           # a hole
+    outs = []
+    for hook in (False, True):
+        model._gptq_engine_disabled = not hook
+        before = engine_steps(model)
+        cache = DynamicCache(config=model.config)
+        with torch.no_grad():
+            model(ids[:, :7], attention_mask=mask[:, :7], past_key_values=cache, use_cache=True)
+            outs.append(model(ids[:, 7:8], attention_mask=mask, past_key_values=cache, use_cache=True).logits.float().cpu().numpy())
+        assert engine_steps(model) == before
+    model._gptq_engine_disabled = False
+    assert np.array_equal(outs[0], outs[1])

@@ -482,10 +482,11 @@ def test_generate_goes_through_the_decode_engine_and_matches_the_module_chain():
     assert s.shape[1] <= 40 and torch.equal(s[:, :7], ids)
 
 
-def test_batched_generate_runs_eagerly_through_the_small_batch_kernels():
-    """model.generate on a BATCH of prompts (padding mask, batch 4 and 12): the hook leaves batches to the module chain, whose
-    linears then run at M = batch; greedy tokens of the fused model equal those of the unfused one (QuantLinear inside stock HF
-    blocks) up to the first near-tie, and the prompts come back untouched"""
+def test_batched_generate_goes_through_the_batched_engine():
+    """model.generate on a BATCH of prompts (all-ones padding mask, batch 4 and 12): since round 5 the hook answers [B, 1] steps with
+    DecodeEngine(batch = B) -- the linears run at M = batch inside ONE hipGraph replay (decode kernel row groups at 4, 16-row MFMA tiles
+    at 12); greedy tokens of the fused model equal those of the unfused one (QuantLinear inside stock HF blocks, eager) up to the first
+    near-tie, and the prompts come back untouched.  (Left padding, per-row positions, cache hand-back: tests/test_gpu_batch.py.)"""
     from quant.engine_hook import engine_steps
     model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=13, fused=True, **HOOK_CFG)
     plain = D.build_random_llama(DEV, bits=4, groupsize=128, seed=13, fused=False, **HOOK_CFG)
@@ -496,7 +497,7 @@ def test_batched_generate_runs_eagerly_through_the_small_batch_kernels():
         with torch.no_grad():
             out = model.generate(ids, attention_mask=mask, do_sample=False, max_new_tokens=8, min_new_tokens=8, pad_token_id=0)
             ref = plain.generate(ids, attention_mask=mask, do_sample=False, max_new_tokens=8, min_new_tokens=8, pad_token_id=0)
-        assert engine_steps(model) == before                      # batches are not the engine's business
+        assert engine_steps(model) == before + 7                  # every [B, 1] step after the prefill
         assert out.shape == (batch, 14) and torch.equal(out[:, :6], ids)
         agree = (out[:, 6] == ref[:, 6]).float().mean().item()    # the first new token of (nearly) every row: fp16 near-ties may flip a few
         assert agree >= 0.75, agree
@@ -589,15 +590,15 @@ def test_engine_hook_explicit_positions_decide_what_is_appended():
         assert np.abs(got - ref).max() < ENGINE_TOL * 4 * max(1.0, np.abs(ref).max()), resend
 
 
-def test_left_padded_prompt_is_left_to_the_module_chain():
-    """batch 1 with LEFT padding: the mask has the right shape but holds zeros and the positions are shifted -- the engine would
-    attend to the pads.  The hook must decline (round-2 advisor finding) and the tokens equal the eager run's."""
+def test_right_padded_prompt_is_left_to_the_module_chain():
+    """batch 1 with padding that is NOT a left prefix (zeros at the end of the mask's history): the engine stores rows without their LEFT
+    pads and would attend to anything else -- the hook must decline, and the tokens equal the eager run's.  (Left padding goes through
+    the engine since round 5: tests/test_gpu_batch.py.)"""
     from quant.engine_hook import engine_steps
     model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=16, fused=True, **HOOK_CFG)
     ids = torch.randint(1, 512, (1, 8), device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
-    ids[0, :3] = 0
     mask = torch.ones_like(ids)
-    mask[0, :3] = 0
+    mask[0, 4:6] = 0
     outs = []
     for hook in (False, True):
         model._gptq_engine_disabled = not hook

@@ -292,11 +292,27 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert mv(nsets=3) == -2
     assert mv(nbytes=nb - 1) == -5
     assert mv(M=17) == -6                                             # at most sixteen rows per launch (gptq_stripe_matmul_f16 serves up to 64)
-    assert mv(M=2, norm=one) == -6                                     # fused RMSNorm is an M == 1 feature
+    # (round 5: the fused RMSNorm serves every row group -- one rstd per row -- so M = 2 with a norm weight is a launch, not a refusal)
+    assert lib.gptq_stripe_matvec_f16(one, 256, one, nb, None, one, 64, 2, 256, 64, 4, 128, 1, None, 0.0, one, None) == -6    # a permutation stays M == 1
     assert mv(M=2, ldx=252) == -3
     assert mv(x=None) == -4
     assert mv(x=2) == -3
     assert mv(M=0) == 0
+
+    # round 5: the entries of the batched decode engine validate before they touch anything
+    assert lib.gptq_layer_decode_f16(None, one, 256, one, 64, 2, None, 0.0, None, 0, one, 1 << 30, None, 0, None) == -4
+    assert lib.gptq_layer_decode_scratch_bytes(None, 4) == 0
+    assert lib.gptq_dense_matmat_f16(one, 256, one, 256, None, one, 64, 17, 64, 256, None, 0.0, None) == -6          # at most 16 rows share the pass
+    assert lib.gptq_dense_matmat_f16(one, 128, one, 256, None, one, 64, 2, 64, 256, None, 0.0, None) == -2          # ldx < K
+    assert lib.gptq_dense_matmat_f16(one, 256, one, 256, None, one, 64, 0, 64, 256, None, 0.0, None) == 0           # empty batch
+    assert lib.gptq_dense_matmat_f16(None, 256, one, 256, None, one, 64, 2, 64, 256, None, 0.0, None) == -4
+    assert lib.gptq_add_rows_f16(one, 64, one, 32, 2, 64, None) == -2 and lib.gptq_add_rows_f16(one, 64, None, 64, 2, 64, None) == -4
+    assert lib.gptq_add_rows_f16(one, 64, one, 64, 0, 64, None) == 0
+    assert lib.gptq_decode_attn_batch_workspace_bytes(4, 32, 128, 2048) == 4 * lib.gptq_decode_attn_workspace_bytes(32, 128, 2048)
+    assert lib.gptq_decode_attn_batch_workspace_bytes(4, 32, 64, 2048) == 0
+    assert lib.gptq_decode_attn_batch_f16(one, 3 * 256, one, one, one, one, 256, one, 16, 2, 2, 128, 64, 10000.0, 1.0, None, None) == -5    # workspace too small
+    assert lib.gptq_decode_attn_batch_f16(one, 256, one, one, one, one, 256, one, 1 << 20, 2, 2, 128, 64, 10000.0, 1.0, None, None) == -2   # ldq < 3 * hidden
+    assert lib.gptq_decode_attn_batch_f16(one, 3 * 256, None, one, one, one, 256, one, 1 << 20, 2, 2, 128, 64, 10000.0, 1.0, None, None) == -4
 
     # small-batch MFMA kernel on the same image (csrc/stripe_mm.inc): scratch workspace required, up to 256 rows
     def mm(x=one, st=one, nbytes=nb, y=one, M=16, bits=4, nsets=1, ws=256, wsb=1 << 20, ldx=256, ldy=64, gs=128):

@@ -27,11 +27,11 @@ def release_checkpoint(model):
     of the packed weights -- the footprint the reference quotes (README.md:23-29: 4891 MiB for 7B 4-bit g128) instead of two
     copies.  ``state_dict()`` is unchanged (tensors reproduced bit-exactly from the images).  Returns (released, kept) counts."""
     import torch
-    from .engine_hook import flush_decode_engine
-    flush_decode_engine(model)
+    from .engine_hook import drop_decode_engines
+    drop_decode_engines(model)    # engines built before hold references to the buffers about to be freed: rebuilt on the next decode step
     st = getattr(model, '_gptq_engine_state', None)
-    if st is not None:            # an engine built before holds references to the buffers about to be freed: it is rebuilt on the next decode step
-        st.engine, st.sig = None, None
+    if st is not None:
+        st.released = True
     done = kept = 0
     for m in model.modules():
         if isinstance(m, (quant_linear.QuantLinear, fused_mlp.QuantLlamaMLP)):

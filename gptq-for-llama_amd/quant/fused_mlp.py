@@ -108,8 +108,10 @@ class QuantLlamaMLP(nn.Module):
                 qw, sc, qz = pl.unpack(i)
                 setattr(self, p + 'qweight', qw), setattr(self, p + 'scales', sc), setattr(self, p + 'qzeros', qz)
 
-    def _apply(self, fn, *args, **kwargs):        # see QuantLinear._apply: a released pair comes back before it moves / is copied
-        self.restore_checkpoint()
+    def _apply(self, fn, *args, **kwargs):        # see QuantLinear._apply: a released pair comes back before it really moves / is cast
+        from .quant_linear import _moves_or_casts
+        if self._released is not None and _moves_or_casts(fn, self.gate_proj_qweight.device):
+            self.restore_checkpoint()
         return super()._apply(fn, *args, **kwargs)
 
     def __getstate__(self):

@@ -442,6 +442,18 @@ def _pack_fields(fields_u32, bits, axis_rows=True):
     return words.view(np.int32)
 
 
+def _moves_or_casts(fn, device):
+    """does this Module._apply callback change where / as what a module's fp16 buffers live?  HF and accelerate issue no-op
+    ``model.to(same_device)`` / ``.half()`` calls routinely; a released module must not rebuild its checkpoint buffers (and, on the next
+    decode step, its image: transiently three copies of the packed weights) for those."""
+    try:
+        probe = torch.empty(0, dtype=torch.float16, device=device)
+        out = fn(probe)
+        return out.device != probe.device or out.dtype != probe.dtype
+    except Exception:
+        return True
+
+
 class QuantLinear(nn.Module):
 
     def __init__(self, bits, groupsize, infeatures, outfeatures, bias):
@@ -497,8 +509,14 @@ class QuantLinear(nn.Module):
     # a released module holds a device image and a C handle that neither move nor pickle: anything that moves / casts / copies the
     # module (.to(), .cpu(), .half(), copy.deepcopy, pickling) first brings the checkpoint buffers back
     def _apply(self, fn, *args, **kwargs):
-        self.restore_checkpoint()
+        if self._released is not None and _moves_or_casts(fn, self.qweight.device):
+            self.restore_checkpoint()
         return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode=True):
+        if mode:
+            self.restore_checkpoint()      # training needs the checkpoint layout (backward reads qweight): leave memory mode
+        return super().train(mode)
 
     def __getstate__(self):
         self.restore_checkpoint()
@@ -565,9 +583,12 @@ class QuantLinear(nn.Module):
     def forward(self, x):
         out_shape = x.shape[:-1] + (self.outfeatures, )
         x2 = x.reshape(-1, x.shape[-1])
+        if self._released is not None and torch.is_grad_enabled() and x2.requires_grad:
+            # memory mode is an inference mode, and it is ON by default once the decode engine has run: a caller that goes on to a backward
+            # pass (eval -> generate -> train, the reference's autograd path QuantLinearFunction / transpose_matmul248, quant_linear.py:282-301)
+            # gets the checkpoint buffers back here instead of an error
+            self.restore_checkpoint()
         if self._released is not None:
-            if torch.is_grad_enabled() and x2.requires_grad:
-                raise RuntimeError('QuantLinear: release_checkpoint() is an inference mode; restore_checkpoint() before a backward pass')
             _native.require_device(x2, 'QuantLinear.forward')
             xr = _as_rows(x2)
             _apply_prefill_route()

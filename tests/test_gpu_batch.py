@@ -75,8 +75,9 @@ def test_layer_decode_norm_and_residual(bits, K, N, gs, NS, M):
             y = _decode(pl, dev(x), M, N, norm=dev(nw) if use_norm else None, residual=dev(res) if use_res else None)
             ref = _expect(x, Ls, bits, nw if use_norm else None, 1e-6, res if use_res else None)
             assert np.isfinite(y.astype(np.float32)).all(), (use_norm, use_res)
-            # with a residual both sides round twice: the bar is held on the sum, normalised by it
-            assert rel_err(y, ref) < (TOL if not use_res else 1.5 * TOL), (use_norm, use_res, rel_err(y, ref))
+            # with a residual both sides round twice: the bar is held on the sum, normalised by it; the SiLU pair multiplies two rounded
+            # sums (2e-3 wherever the fused MLP is tested against the oracle: test_stripe_mm_fused_mlp)
+            assert rel_err(y, ref) < (2 * TOL if NS == 2 else TOL if not use_res else 1.5 * TOL), (use_norm, use_res, rel_err(y, ref))
 
 
 def test_layer_decode_bias_and_residual_strided():

@@ -610,12 +610,14 @@ def test_right_padded_prompt_is_left_to_the_module_chain():
     assert torch.equal(outs[0], outs[1])
 
 
-def test_release_checkpoint_memory_mode():
+def test_release_checkpoint_memory_mode(monkeypatch):
     """quant.release_checkpoint(model): ONE copy of the packed weights (the stripe16 images) instead of two -- the reference's
     footprint (README.md:23-29).  Logits of a prefill (M = 9: MFMA tiles on the image; M = 200: the dense route on buffers unpacked
     from the image per call) and greedy decode through the engine are BIT-identical before and after, state_dict() still returns
     the original checkpoint tensors bit for bit, load_state_dict / restore_checkpoint bring the buffers back."""
     import quant
+    import quant.engine_hook
+    monkeypatch.setattr(quant.engine_hook, 'RELEASE_CHECKPOINT', False)     # the hook would release during the first generate(): here the release is the explicit call below
     model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=17, fused=True, **HOOK_CFG)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     g = torch.Generator(device=DEV).manual_seed(8)
@@ -628,6 +630,7 @@ def test_release_checkpoint_memory_mode():
             c = model.generate(ids9, do_sample=False, max_new_tokens=12, min_new_tokens=12)
         return a, b, c
     before = probe()
+    quant.engine_hook.drop_decode_engines(model)      # (its K/V cache and graph are not what this test weighs)
     torch.cuda.synchronize()
     mem0 = torch.cuda.memory_allocated()
     done, kept = quant.release_checkpoint(model)
@@ -642,10 +645,15 @@ def test_release_checkpoint_memory_mode():
     assert list(sd1) == list(sd0)
     for k in sd0:
         assert sd1[k].shape == sd0[k].shape and torch.equal(sd1[k], sd0[k]), k
+    # a no-op move (HF / accelerate issue them routinely) leaves memory mode alone; a backward pass takes the buffers back
+    model.to(DEV)
+    assert all(m._released is not None for m in model.modules() if isinstance(m, quant.QuantLinear))
     lin = next(m for m in model.modules() if isinstance(m, quant.QuantLinear))
-    with pytest.raises(RuntimeError):
-        with torch.enable_grad():
-            lin(torch.randn(2, lin.infeatures, device=DEV, dtype=torch.float16, requires_grad=True))
+    with torch.enable_grad():
+        xg = torch.randn(2, lin.infeatures, device=DEV, dtype=torch.float16, requires_grad=True)
+        lin(xg).float().sum().backward()
+    assert lin._released is None and lin.qweight.numel() > 0 and xg.grad is not None and bool(torch.isfinite(xg.grad).all())
+    assert torch.equal(lin.qweight, sd0[next(k for k, v in model.named_modules() if v is lin) + '.qweight'])
     model.load_state_dict(sd0)                                              # restores the buffers first, then copies
     assert all(m.qweight.numel() > 0 and m._released is None for m in model.modules() if isinstance(m, quant.QuantLinear))
     again = probe()
@@ -655,6 +663,41 @@ def test_release_checkpoint_memory_mode():
     quant.restore_checkpoint(model)
     for k, v in model.state_dict().items():
         assert torch.equal(v, sd0[k]), k
+
+
+def test_generate_then_backward_with_the_default_memory_mode():
+    """eval() -> generate() -> train() -> forward / backward: the first decode step through the hook releases every module's checkpoint
+    buffers BY DEFAULT (memory mode); the reference's autograd path (QuantLinearFunction / transpose_matmul248, quant_linear.py:282-301)
+    must keep working afterwards -- the modules take their buffers back instead of raising."""
+    import quant
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=19, fused=True, **HOOK_CFG)
+    ids = torch.randint(0, 512, (1, 6), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    lin = model.model.layers[0].self_attn.o_proj
+    qw0 = lin.qweight.clone()
+    xg = torch.randn(3, lin.infeatures, device=DEV, dtype=torch.float16)
+    with torch.no_grad():
+        y0 = lin(xg).clone()
+        model.generate(ids, do_sample=False, max_new_tokens=5, min_new_tokens=5)
+    assert lin._released is not None and lin.qweight.numel() == 0          # the hook's default
+    # (a) a grad-requiring input on a released module in eval mode
+    xa = xg.clone().requires_grad_(True)
+    with torch.enable_grad():
+        ya = lin(xa)
+        ya.float().sum().backward()
+    assert lin._released is None and torch.equal(lin.qweight, qw0) and torch.equal(ya.detach(), y0)
+    W = quant.quant_linear.dequantize(lin.qweight, lin.scales, lin.qzeros, lin.g_idx, lin.bits).float()
+    want = torch.ones_like(y0).float() @ W.t()
+    assert float((xa.grad.float() - want).abs().max() / want.abs().max()) < 2e-3
+    # (b) generate again (releases again), then model.train(): every QuantLinear leaves memory mode
+    with torch.no_grad():
+        model.generate(ids, do_sample=False, max_new_tokens=5, min_new_tokens=5)
+    assert lin._released is not None
+    model.train()
+    assert all(m._released is None for m in model.modules() if isinstance(m, quant.QuantLinear))
+    model.eval()
+    with torch.no_grad():
+        out = model.generate(ids, do_sample=False, max_new_tokens=5, min_new_tokens=5)
+    assert out.shape == (1, 11)
 
 
 @pytest.mark.parametrize('bits', [4, 3])

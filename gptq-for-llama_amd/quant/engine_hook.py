@@ -65,9 +65,10 @@ class _State:
 def _signature(model):
     """cheap identity of the weights the engine captured pointers of (rebuilt when the model moved or was reloaded)."""
     from .quant_linear import _ver
+    from .layer import RESTORE_EPOCH
     l0 = model.model.layers[0]
     w = l0.self_attn.qkv_proj.qweight
-    return (w.device, w.data_ptr(), _ver(w), model.lm_head.weight.data_ptr(), len(model.model.layers))
+    return (w.device, w.data_ptr(), _ver(w), model.lm_head.weight.data_ptr(), len(model.model.layers), RESTORE_EPOCH[0])
 
 
 def _eligible_model(model):

@@ -103,10 +103,12 @@ class QuantLlamaMLP(nn.Module):
 
     def restore_checkpoint(self):
         if self._released is not None:
+            from .layer import RESTORE_EPOCH
             pl, self._released = self._released, None
             for i, p in enumerate(('gate_proj_', 'up_proj_')):
                 qw, sc, qz = pl.unpack(i)
                 setattr(self, p + 'qweight', qw), setattr(self, p + 'scales', sc), setattr(self, p + 'qzeros', qz)
+            RESTORE_EPOCH[0] += 1
 
     def _apply(self, fn, *args, **kwargs):        # see QuantLinear._apply: a released pair comes back before it really moves / is cast
         from .quant_linear import _moves_or_casts

@@ -23,6 +23,12 @@ from . import _native
 USE_IMAGE = os.environ.get('GPTQ_STRIPE', '1') != '0'
 
 
+# bumped whenever a module takes its checkpoint buffers back (restore_checkpoint of a QuantLinear / QuantLlamaMLP): the decode-engine hook keeps
+# the value it built its engines at and rebuilds (and releases again) when it moved -- a restored module is otherwise invisible to the cheap
+# per-token signature, which looks at one layer only
+RESTORE_EPOCH = [0]
+
+
 def _ver(t):
     """version counter of a tensor; inference-mode tensors have none (they are immutable outside inference mode)."""
     try:

@@ -503,8 +503,10 @@ class QuantLinear(nn.Module):
     def restore_checkpoint(self):
         """undo release_checkpoint: the buffers come back out of the image (bit-exact)"""
         if self._released is not None:
+            from .layer import RESTORE_EPOCH
             pl, self._released = self._released, None
             self.qweight, self.scales, self.qzeros = pl.unpack(0)
+            RESTORE_EPOCH[0] += 1
 
     # a released module holds a device image and a C handle that neither move nor pickle: anything that moves / casts / copies the
     # module (.to(), .cpu(), .half(), copy.deepcopy, pickling) first brings the checkpoint buffers back

@@ -60,7 +60,9 @@ def _expect(x, Ls, bits, nw, eps, res, bias=None):
 
 @pytest.mark.parametrize('M', [1, 2, 3, 4, 5, 8, 9, 16, 17, 40, 128])
 @pytest.mark.parametrize('bits,K,N,gs,NS', [(4, 4096, 4096, 128, 1), (4, 1024, 288, 64, 1), (4, 4096, 11008, 128, 2), (4, 2176, 64, 32, 2), (4, 11008, 256, 128, 1),
-                                            (8, 1024, 96, 64, 1), (3, 1152, 96, 128, 1), (2, 1024, 64, 128, 2)])
+                                            (8, 1024, 96, 64, 1), (3, 1152, 96, 128, 1), (2, 1024, 64, 128, 2),
+                                            # the shapes of the tiny test models (K = 256 / 512: two and four row blocks, fewer than the eight waves)
+                                            (4, 256, 768, 128, 1), (4, 256, 256, 128, 1), (4, 256, 512, 128, 2), (4, 512, 256, 128, 1)])
 def test_layer_decode_norm_and_residual(bits, K, N, gs, NS, M):
     """every rung of gptq_layer_decode_f16's ladder: norm + residual inside the decode kernel (M <= 4, 8 on one-round shapes), its row
     groups, the 16-row tiles with the residual in their epilogue and the norm as its own launch"""
@@ -165,7 +167,7 @@ def test_decode_attention_batch_rows_equal_single_row_launches(B, pos):
 
 
 @pytest.mark.parametrize('M', [1, 2, 3, 4, 7, 8, 13, 16])
-@pytest.mark.parametrize('N,K', [(32000, 4096), (1000, 512), (515, 1288)])
+@pytest.mark.parametrize('N,K', [(32000, 4096), (1000, 512), (515, 1288), (1000, 5120), (515, 8192), (48, 256)])
 def test_dense_matmat_lm_head(M, N, K):
     """the LM head of a decode batch: M rows against a dense fp16 [N][K] weight in one pass, final RMSNorm fused or not, vs float64"""
     lib = _native.lib()

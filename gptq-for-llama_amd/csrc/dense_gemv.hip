@@ -276,9 +276,10 @@ int dense_mm16_launch(const half_t *x, int64_t ldx, const half_t *W, int64_t ldw
     return (int)hipGetLastError();
 }
 
-// rows from which the matrix-core kernel takes over (A/B runs: GPTQ_LM_HEAD_MFMA_MIN_ROWS; 17 = never)
+// rows from which the matrix-core kernel takes over (A/B runs: GPTQ_LM_HEAD_MFMA_MIN_ROWS; 17 = never).  Measured on the 32000 x 4096 head
+// (gpurun_out r5c, us, dot2 / matrix core): 1 row 43.1 / 46.7, 2: 44.9 / 46.8, 4: 48.4 / 47.4, 5: 83 / 47.4, 8: 84 / 49.0, 16: 205 / 53.3
 int dense_mm16_min_rows() {
-    static const int v = [] { const char *e = getenv("GPTQ_LM_HEAD_MFMA_MIN_ROWS"); return e ? atoi(e) : 5; }();
+    static const int v = [] { const char *e = getenv("GPTQ_LM_HEAD_MFMA_MIN_ROWS"); return e ? atoi(e) : 4; }();
     return v;
 }
 

@@ -20,6 +20,17 @@ for B in (8, 16):
             err = np.abs(got - expect).max(axis=2) / np.abs(expect).max()
             print('B', B, 'fuse_norm', fuse, 'lm_kernel', lm, 'max %.2e' % err.max(), 'per step', ' '.join('%.1e' % e for e in err.max(axis=1)),
                   'worst row', int(err.max(axis=0).argmax()), flush=True)
+    if B == 16:       # who is closer to a dense fp16 twin (stock HF modules, oracle-dequantised weights) at the worst (step, row)?
+        from test_gpu_model import dense_twin
+        qu = D.build_random_llama(DEV, seed=3 + B, fused=False, **HD128)
+        ref = run_steps(dense_twin(qu, HD128), ids, 1)
+        D.LM_HEAD_KERNEL = True
+        eng = D.DecodeEngine(q, t_max=64, batch=B)
+        got = np.stack([eng.decode(ids[:, i]).float().cpu().numpy() for i in range(ids.shape[1])])
+        sc = np.abs(ref).max()
+        for name, a in (('engine', got), ('chain', expect)):
+            e = np.abs(a - ref).max(axis=2) / sc
+            print('%s vs dense twin: max %.2e at (step, row) %s; at (4, 13): %.2e; median %.2e' % (name, e.max(), np.unravel_index(e.argmax(), e.shape), e[4, 13], np.median(e)), flush=True)
     # the eager chain against itself at another batch composition: rows 0..7 alone (M = 8 kernels) vs inside the batch of 16
     if B == 16:
         e8 = run_steps(q, ids[:8], 1)

@@ -30,7 +30,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, 'gptq-for-llama_amd'))
+PKG = os.path.join(ROOT, 'gptq-for-llama_amd')
+sys.path.insert(0, PKG)
 sys.path.insert(0, ROOT)
 
 import torch
@@ -592,17 +593,36 @@ def config4_leg(dev):
     return out
 
 
-def pmc_traffic():
-    """HBM bytes per launch from the newest committed PMC pass (profiles/*/traffic.json, produced by
-    tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` on this same command; counters cannot be
-    read from inside the timed process, so this is a separate-pass figure)."""
+def csrc_sha16():
+    """identity of the kernels a measurement belongs to: sha256 over the device sources (csrc/*.hip, *.inc, *.h) in name order.  The GPU box
+    has no .git (gpurun ships a snapshot), so this -- not a commit id -- is what ties a PMC pass to the build it was taken on."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic.json')))
-    if not files:
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(PKG, 'csrc', '*'))):
+        if f.endswith(('.hip', '.inc', '.h')):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(pmc_file=None):
+    """HBM bytes per launch from a PMC pass (traffic.json, produced by tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` on this same
+    command; counters cannot be read from inside the timed process, so this is a separate-pass figure).  --pmc-file names the pass taken in
+    the same validation call; otherwise the newest committed profiles/*/traffic.json.  A pass stamped with the kernel sources of ANOTHER
+    build (csrc_sha16) is refused: (None, reason)."""
+    import glob
+    files = [pmc_file] if pmc_file else sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic.json')))
+    if not files or not os.path.exists(files[-1]):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        return int(d['hbm_bytes_per_launch_avg']), os.path.relpath(files[-1], ROOT)
+        rel = os.path.relpath(files[-1], ROOT)
+        stamp = d.get('csrc_sha16')
+        if stamp is not None and stamp != csrc_sha16():
+            return None, '%s refused: taken on kernel sources %s, this build is %s' % (rel, stamp, csrc_sha16())
+        src = rel + (' (same kernel sources: csrc_sha16 %s)' % stamp if stamp else ' (unstamped: taken before round 5)')
+        return int(d['hbm_bytes_per_launch_avg']), src
     except Exception:
         return None, None
 
@@ -748,6 +768,7 @@ def main():
     ap.add_argument('--no-prefill', action='store_true')
     ap.add_argument('--no-config4', action='store_true')
     ap.add_argument('--no-small-batch', action='store_true')
+    ap.add_argument('--pmc-file', default=None, help='traffic.json of a `rocprofv3 --pmc FETCH_SIZE` pass over this command (tools/pmc_traffic.py)')
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
@@ -803,12 +824,20 @@ def main():
     torch.cuda.synchronize()
     graph = None
     capturable = not (args.tp and distributed and args.allreduce == 'rccl' and os.environ.get('GPTQ_BENCH_BACKEND', 'nccl') != 'nccl')   # gloo collectives cannot be captured
-    if not args.eager and capturable:
+    # test hook: GPTQ_BENCH_FORCE_EAGER_TP=1 makes the capture of a tensor-parallel stack FAIL (an exception inside the capture region, the way a
+    # collective that does not support stream capture fails) so that the eager fallback below is exercised, not just written
+    force_fail = bool(args.tp and os.environ.get('GPTQ_BENCH_FORCE_EAGER_TP'))
+    capture_failed = False
+    if not args.eager and (capturable or force_fail):
         try:                       # the collectives are captured with the kernels (RCCL supports stream capture)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
+                if force_fail:
+                    work._partial(work.x_h[:, slice(*work.kb_h)], work.layers[0]['o'], work.p_h, work.kb_h[1] - work.kb_h[0], H65, 1)   # something IS in the capture
+                    raise RuntimeError('GPTQ_BENCH_FORCE_EAGER_TP: capture aborted on purpose')
                 work.step()
         except Exception:
+            capture_failed = True
             if not args.tp:
                 raise
             graph = None           # a stack that cannot capture its collectives: eager launches, still correct
@@ -819,7 +848,7 @@ def main():
                 pass
             torch.cuda.synchronize()
     run = graph.replay if graph is not None else work.step
-    launch_mode = 'hipGraph replay' if graph is not None else 'eager'
+    launch_mode = 'hipGraph replay' if graph is not None else ('eager (the capture failed: fallback)' if capture_failed else 'eager')
 
     for _ in range(args.warmup):
         run()
@@ -889,7 +918,7 @@ def main():
         us_per_launch = ev_ms * 1e3 / (args.steps * work.launches_per_step)
         bytes_per_launch = work.bytes_per_step / work.launches_per_step
         achieved = bytes_per_launch / us_per_launch / 1e3
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src = pmc_traffic(args.pmc_file)
         if args.tp:
             try:   # rank 0 alone (the other ranks wait in the final barrier): same stack, world 1
                 tp1 = tp_world1_leg(dev, args.tp, args.tp_layers) if not os.environ.get('GPTQ_BENCH_NO_TP1') else None

@@ -334,7 +334,10 @@ class DecodeEngine:
     # -- launches ------------------------------------------------------------------------------
     def _gemv(self, x, w, y, s, residual=None):
         if w['bias'] is not None and residual is not None:
-            raise NotImplementedError('bias + fused residual')
+            # one add slot per launch: the bias rides in the matvec, the residual is a second launch (gptq_layer_decode_f16 does both)
+            if self.scratch is None:
+                self.scratch = torch.empty(max(256, self.lib.gptq_layer_decode_scratch_bytes(w['_keep'].handle, 1)), dtype=torch.uint8, device=self.dev)
+            return self._lin(w, x, y, s, self.native.layer_workspace(self.dev, s), residual=residual)
         b = residual if residual is not None else w['bias']
         ptr = self.native.ptr
         if w['st'] is not None:       # stripe16: no K split, no workspace (act-order: x gathered through perm in the kernel)

@@ -801,6 +801,137 @@ def test_tensor_parallel_decode_engine_two_ranks_one_gpu(world):
     assert ret.get(timeout=5) == 1
 
 
+def _tp_load_worker(rank, world, port, ret, path):
+    """shard at load: the engine built from a checkpoint FILE (only this rank's slices are read) against the engine sliced out of a
+    materialised model of the same weights"""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from quant.tp_decode import TPDecodeEngine
+        torch.cuda.set_device(0)
+        cfg = dict(HD128, num_attention_heads=4, num_key_value_heads=4, hidden_size=512, intermediate_size=1024, num_hidden_layers=3)
+        if rank == 0:          # the checkpoint in the reference's format: the state_dict of the UNFUSED quantised model (llama_inference.py:57-60)
+            from safetensors.torch import save_file
+            plain = D.build_random_llama('cpu' if False else DEV, bits=4, groupsize=128, seed=33, fused=False, **cfg)
+            save_file({k: v.detach().cpu().contiguous() for k, v in plain.state_dict().items()}, path)
+            del plain
+            torch.cuda.empty_cache()
+        dist.barrier()
+        from transformers import LlamaConfig
+        c = dict(D.LLAMA_7B)
+        c.update(cfg)
+        config = LlamaConfig(**c)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        eng = TPDecodeEngine(checkpoint=path, config=config, bits=4, groupsize=128, device=DEV, t_max=64)
+        torch.cuda.synchronize()
+        peak, held = torch.cuda.max_memory_allocated() - base, torch.cuda.memory_allocated() - base
+        H, I, nl, V = 512, 1024, 3, cfg['vocab_size']
+        packed = nl * ((3 * H * H + H * H + 3 * H * I) // 2 + (3 * H + H + 2 * I) * (H // 128) * (2 + 0.5) + H * (I // 128) * 2.5)   # qweight + scales + qzeros
+        replicated = 2 * V * H * 2 + (2 * nl + 1) * H * 2
+        kv = 2 * nl * 64 * (H // world) * 2
+        images = packed / world * 1.06               # the stripe16 image of a shard: its packed words + a {scale, zero} table
+        # what this rank holds: its images (NOT the shard tensors they were built from, NOT anything unsharded) + the replicated tensors + K/V
+        assert held <= images + replicated + kv + (2 << 20), (held, images, replicated, kv)
+        # ... and what it ever held while loading: one layer's shard tensors on top of that
+        assert peak <= held + 1.5 * packed / world / nl + (2 << 20), (peak, held)
+        assert eng.source.bytes_read <= packed / world * 1.15 + replicated + nl * (H + I) * 4 * 4, eng.source.bytes_read     # (+ the g_idx vectors)
+        model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=33, **cfg)
+        ref = TPDecodeEngine(model, t_max=64)
+        ids = torch.randint(0, V, (8,), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+        a = torch.stack([eng.decode(ids[i]).clone() for i in range(8)])
+        b = torch.stack([ref.decode(ids[i]).clone() for i in range(8)])
+        ok = bool(torch.equal(a, b)) and eng.status() == 0
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            ret.put(int(t.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _tp_variants_worker(rank, world, port, ret, variant):
+    """bias on every attention linear / an act-order checkpoint through the tensor-parallel engine, against the module chain"""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from quant.tp_decode import TPDecodeEngine
+        torch.cuda.set_device(0)
+        cfg = dict(HD128, num_attention_heads=4, num_key_value_heads=4, hidden_size=512, intermediate_size=1024)
+        if variant == 'bias':
+            model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=35, fused=False, attention_bias=True, **cfg)
+            g = torch.Generator(device=DEV).manual_seed(1)
+            for m in model.modules():
+                if isinstance(m, quant.QuantLinear) and m.bias is not None:
+                    m.bias.copy_((torch.randn(m.bias.shape, device=DEV, generator=g) * 0.05).half())
+            quant.make_quant_attn(model)
+            quant.make_quant_norm(model)
+            quant.make_fused_mlp(model)
+            assert model.model.layers[0].self_attn.o_proj.bias is not None and model.model.layers[0].self_attn.qkv_proj.bias is not None
+        else:
+            model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=36, act_order=True, **cfg)
+        ids = torch.randint(0, cfg['vocab_size'], (1, 9), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+        expect = run_steps(model, ids, 1)[:, 0]
+        ok = True
+        for graph in (False, True):
+            eng = TPDecodeEngine(model, t_max=64)
+            if graph:
+                eng.capture()
+            got = np.stack([eng.decode(ids[0, i]).float().cpu().numpy()[0] for i in range(9)])
+            err = np.abs(got - expect).max() / np.abs(expect).max()
+            # (act-order row shards run the generic kernel with fp16 partials: one more rounding per rank)
+            ok = ok and np.isfinite(got).all() and err < (ENGINE_TOL if variant == 'bias' else 2 * ENGINE_TOL) and eng.status() == 0
+        if variant == 'bias' and rank == 0:      # the single-GPU engine takes bias + residual too (one launch for the matvec + bias, one for the add)
+            e1 = D.DecodeEngine(model, t_max=64).capture()
+            g1 = np.stack([e1.decode(ids[0, i]).float().cpu().numpy()[0] for i in range(9)])
+            ok = ok and np.abs(g1 - expect).max() / np.abs(expect).max() < ENGINE_TOL
+        t = torch.tensor([1 if ok else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            ret.put(int(t.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(target, world, extra=(), timeout=300):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context('spawn')
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, ret) + tuple(extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+        if p.exitcode is None:
+            p.kill()
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) == 1
+
+
+def test_tensor_parallel_engine_shards_at_load(tmp_path):
+    """every rank reads ONLY its rows / columns from the checkpoint file and never holds an unsharded tensor; same tokens
+    as the engine sliced out of a materialised model, bit for bit"""
+    _spawn(_tp_load_worker, 2, extra=(str(tmp_path / 'ckpt.safetensors'),))
+
+
+@pytest.mark.parametrize('variant', ['bias', 'act_order'])
+def test_tensor_parallel_engine_bias_and_act_order(variant):
+    """the refusals of biased and act-order layers are gone"""
+    _spawn(_tp_variants_worker, 2, extra=(variant,))
+
+
 # ---------------------------------------------------------------------------------------
 # the line the driver's scaling tier collects: `bench.py --gpus N` with N > 1 (BASELINE config 5, --tp row by default).  Two ranks
 # on the one GPU of the test box through gloo (RCCL refuses two ranks on one device): the contract fields of the TP line.
@@ -826,6 +957,44 @@ def test_bench_gpus2_prints_the_tensor_parallel_contract_line():
     assert d['config']['parallelism'] == 'tp2 row' and d['config']['world_size_reported_by_backend'] == 2
     assert d['value'] > 0 and d['ms_per_step'] > 0 and d['unit'] == 'GB/s' and d['config']['collectives_per_step'] == 4 * 2
     assert 'GBps_whole_job' in d['replicas_reported_only'], d['replicas_reported_only']
+
+
+@pytest.mark.parametrize('allreduce', ['rccl', 'p2p'])
+def test_bench_gpus8_really_runs_eight_processes(allreduce):
+    """the command the driver's scaling tier runs at N = 8 -- `python bench.py --gpus 8` -- with eight real processes (all on
+    the one GPU of the test box, gloo for torch.distributed; `--allreduce p2p`: the one-shot exchange over eight IPC peer mappings)"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(GPTQ_BENCH_BACKEND='gloo', GPTQ_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0', GPTQ_BENCH_NO_REPLICAS='1', GPTQ_BENCH_NO_TP1='1')
+    cmd = [sys.executable, os.path.join(ROOT_DIR, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--tp-layers', '1', '--allreduce', allreduce]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['world_size_reported_by_backend'] == 8 and d['config']['parallelism'] == 'tp8 row'
+    assert np.isfinite(d['value']) and d['value'] > 0 and d['ms_per_step'] > 0
+    if allreduce == 'p2p':
+        assert d['allreduce_us']['p2p_status'] == 0 and 'one-shot' in d['config']['collective']
+        assert d['config']['launch_mode'] == 'hipGraph replay'          # the exchange is captured with the kernels
+
+
+def test_bench_tp_falls_back_to_eager_when_the_capture_fails():
+    """the `except` branch behind the hipGraph capture of a tensor-parallel stack (bench.py) -- a collective that cannot be
+    captured -- is exercised for real: GPTQ_BENCH_FORCE_EAGER_TP aborts the capture from inside; the line must still come out, eager"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(GPTQ_BENCH_BACKEND='gloo', GPTQ_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0', GPTQ_BENCH_NO_REPLICAS='1', GPTQ_BENCH_NO_TP1='1',
+               GPTQ_BENCH_FORCE_EAGER_TP='1')
+    cmd = [sys.executable, os.path.join(ROOT_DIR, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--tp-layers', '1', '--allreduce', 'p2p']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 2 and 'fallback' in d['config']['launch_mode'] and d['value'] > 0 and d['allreduce_us']['p2p_status'] == 0
 
 
 def test_bench_gpus2_without_a_launcher_starts_its_own_ranks():

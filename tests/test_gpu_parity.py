@@ -1414,7 +1414,7 @@ def _p2p_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 4, 8])      # 8: the world the driver's scaling tier ends at
 def test_p2p_allreduce_two_processes_one_gpu(world):
     import socket
     import torch.multiprocessing as mp

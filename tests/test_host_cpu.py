@@ -569,3 +569,41 @@ def test_bench_gpus_n_spawns_n_ranks_and_refuses_a_wrong_world_size():
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=dict(env, WORLD_SIZE='4', RANK='0'),
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 2 and 'refusing' in out.stderr
+
+
+def test_checkpoint_source_reads_only_the_slices_it_is_asked_for(tmp_path):
+    """round 5, shard at load (quant/tp_decode.py): a rank's rows / columns out of a reference-format checkpoint -- a dict of tensors or a
+    .safetensors file -- are the slices of the full tensors, and the byte counter says how little was pulled"""
+    import torch
+    from safetensors.torch import save_file
+    from quant.tp_decode import CheckpointSource
+    g = torch.Generator().manual_seed(0)
+    sd = {'a.qweight': torch.randint(-2**31, 2**31 - 1, (64, 96), dtype=torch.int32, generator=g), 'a.scales': torch.rand((4, 96), generator=g).half(),
+          'a.bias': torch.rand(96, generator=g).half()}
+    path = str(tmp_path / 'ckpt.safetensors')
+    save_file(sd, path)
+    for src in (CheckpointSource(sd), CheckpointSource(path)):
+        assert src.has('a.qweight') and not src.has('b.qweight')
+        assert torch.equal(src.get('a.qweight', rows=(16, 48)), sd['a.qweight'][16:48])
+        assert torch.equal(src.get('a.qweight', cols=(32, 64)), sd['a.qweight'][:, 32:64]) and src.get('a.qweight', cols=(32, 64)).is_contiguous()
+        assert torch.equal(src.get('a.scales', rows=(1, 3), cols=(0, 32)), sd['a.scales'][1:3, 0:32])
+        assert torch.equal(src.get('a.bias'), sd['a.bias'])
+        assert src.bytes_read == 32 * 96 * 4 + 2 * 64 * 32 * 4 + 2 * 32 * 2 + 96 * 2
+
+
+def test_bench_refuses_a_pmc_pass_of_another_build(tmp_path):
+    """roofline.traffic comes from a separate rocprofv3 --pmc pass; since round 5 tools/pmc_traffic.py stamps the pass with a hash of the kernel
+    sources and bench.py refuses one taken on other sources"""
+    import json
+    import bench
+    good, bad, old = tmp_path / 'good.json', tmp_path / 'bad.json', tmp_path / 'old.json'
+    good.write_text(json.dumps({'hbm_bytes_per_launch_avg': 123, 'csrc_sha16': bench.csrc_sha16()}))
+    bad.write_text(json.dumps({'hbm_bytes_per_launch_avg': 123, 'csrc_sha16': '0' * 16}))
+    old.write_text(json.dumps({'hbm_bytes_per_launch_avg': 456}))
+    v, src = bench.pmc_traffic(str(good))
+    assert v == 123 and 'same kernel sources' in src
+    v, src = bench.pmc_traffic(str(bad))
+    assert v is None and 'refused' in src
+    v, src = bench.pmc_traffic(str(old))
+    assert v == 456 and 'unstamped' in src
+    assert len(bench.csrc_sha16()) == 16

@@ -7,7 +7,10 @@ usage: python tools/pmc_traffic.py <counter_collection.csv> [out.json]"""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 per = collections.defaultdict(list)
@@ -23,6 +26,11 @@ for (name, grid), v in sorted(per.items()):
     tot_b += b * len(v)
     tot_n += len(v)
 out['hbm_bytes_per_launch_avg'] = round(tot_b / max(tot_n, 1))
+try:        # the kernel sources this pass was taken on: bench.py refuses a pass of another build (roofline.traffic_source)
+    from bench import csrc_sha16
+    out['csrc_sha16'] = csrc_sha16()
+except Exception as e:
+    out['csrc_sha16_error'] = repr(e)[:100]
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], 'w'), indent=1)

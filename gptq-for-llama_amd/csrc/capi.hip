@@ -1294,9 +1294,9 @@ int gptq_layer_route_for_shape(int M, int K, int N, int bits, int groupsize, int
     const bool image = has_image && gq != -2 && kind != 2;
     const int rows_max = decode_rows_max(N, nsets);
     const int gemm_max = g_stripe_gemm_max_rows.load();
-    if (image && (kind == 0 || M == 1) && M <= rows_max && (M <= 4 || K <= 9216)) return GPTQ_ROUTE_STRIPE_DECODE;
+    if (image && (kind == 0 || M == 1) && M <= rows_max && (M <= 4 || K <= 9216 || (K <= 12288 && nsets == 1))) return GPTQ_ROUTE_STRIPE_DECODE;
     if (image && M > 1) {
-        if (M <= rows_max && kind == 1 && (M <= 4 || K <= 9216)) return GPTQ_ROUTE_STRIPE_DECODE;       // after one gather of x
+        if (M <= rows_max && kind == 1 && (M <= 4 || K <= 9216 || (K <= 12288 && nsets == 1))) return GPTQ_ROUTE_STRIPE_DECODE;       // after one gather of x
         if (M <= LAYER_STRIPE_MM_MAX_M) return GPTQ_ROUTE_STRIPE_TILES;
         if (M <= gemm_max && bits != 2 && (gq == -1 || gq >= 2)) return GPTQ_ROUTE_STRIPE_GEMM;       // groups of at least a row block
     }

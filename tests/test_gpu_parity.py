@@ -991,14 +991,33 @@ def test_stripe_mm_fused_mlp(bits, K, N, gs, M):
     assert np.array_equal(c.view(np.uint16), c2.view(np.uint16))
 
 
-def test_stripe_long_k_small_batch_falls_back():
-    """M rows of x must fit in LDS: M = 8 on K = 11008 is refused by the stripe kernel (GPTQ_E_VARIANT) and the default
-    dispatch takes the weight-streaming MFMA kernel -- same result"""
+def test_stripe_long_k_small_batch():
+    """M rows of x must fit in LDS.  Round 5: 5 .. 8 rows on K = 11008 (LLaMA-7B down_proj) run in the decode kernel with x staged in two K
+    halves (stripe_gemv2p_kernel) -- with a bias and with a per-row residual; 16 rows on that K, or 8 rows on K = 22016, are still refused by
+    the stripe kernel (GPTQ_E_VARIANT) and the default dispatch takes the 16-row MFMA tiles -- same result"""
     L = make_random_layer(4, 128, 11008, 256, seed=8)
-    x = np.random.default_rng(8).standard_normal((8, 11008)).astype(np.float16)
+    rng = np.random.default_rng(8)
+    for M in (5, 7, 8):
+        x = rng.standard_normal((M, 11008)).astype(np.float16)
+        y = hip_forward(x, L, family='stripe')
+        assert rel_err(y, oracle_forward(x, L)) < TOL, M
+        bias = rng.standard_normal(256).astype(np.float16)
+        yb = hip_forward(x, L, bias=bias, family='stripe')
+        assert rel_err(yb, exact_forward(x, L, bias)) < TOL, M
+        check_forward(x, L)                                   # the default dispatch takes the same kernel
+    # ragged tail: K = 11008 + 128 (87 row blocks: the last wave-round is partial in the second phase), one group per 64 k
+    L2 = make_random_layer(4, 64, 11136, 96, seed=9)
+    x = rng.standard_normal((6, 11136)).astype(np.float16)
+    assert rel_err(hip_forward(x, L2, family='stripe'), oracle_forward(x, L2)) < TOL
+    x = rng.standard_normal((16, 11008)).astype(np.float16)
     with pytest.raises(RuntimeError):
         hip_forward(x, L, family='stripe')
     check_forward(x, L)
+    L3 = make_random_layer(4, 128, 22016, 64, seed=10)
+    x = rng.standard_normal((8, 22016)).astype(np.float16)
+    with pytest.raises(RuntimeError):
+        hip_forward(x, L3, family='stripe')
+    check_forward(x, L3)
 
 
 @pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 11008, 128), (8, 1024, 288, 64), (2, 1024, 96, 128), (3, 4096, 11008, 4096), (3, 1152, 96, 128)])

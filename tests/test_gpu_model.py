@@ -835,8 +835,10 @@ def _tp_load_worker(rank, world, port, ret, path):
         replicated = 2 * V * H * 2 + (2 * nl + 1) * H * 2
         kv = 2 * nl * 64 * (H // world) * 2
         images = packed / world * 1.06               # the stripe16 image of a shard: its packed words + a {scale, zero} table
+        from quant import _native
+        fixed = _native.lib().gptq_query(3) + (1 << 20)      # the per-process split-K workspace (16.7 MB whatever the model) + attention scratch, RoPE table
         # what this rank holds: its images (NOT the shard tensors they were built from, NOT anything unsharded) + the replicated tensors + K/V
-        assert held <= images + replicated + kv + (2 << 20), (held, images, replicated, kv)
+        assert held <= images + replicated + kv + fixed + (1 << 20), (held, images, replicated, kv, fixed)
         # ... and what it ever held while loading: one layer's shard tensors on top of that
         assert peak <= held + 1.5 * packed / world / nl + (2 << 20), (peak, held)
         assert eng.source.bytes_read <= packed / world * 1.15 + replicated + nl * (H + I) * 4 * 4, eng.source.bytes_read     # (+ the g_idx vectors)

@@ -6,11 +6,14 @@
 // a preallocated [t_max, heads*head_dim] buffer (no torch.cat, no shape change per token).
 //
 // HBM-bound elementwise / reduction work (K,V rows are read once per token): no MFMA.
+#include <cstdlib>
+
 #include "gptq_device.h"
 #include "gptq_internal.h"
 
 namespace gptq {
 
+int decode_attn_ts_grid(int t_max, int batch);
 
 // Cross-lane reductions on the VALU (DPP row operations + gfx950 permlane swaps) instead of __shfl_xor, which hipcc lowers to
 // ds_bpermute_b32: ~120 cycles of LDS round trip per dependent step -- the per-wave stamps (tools/timeline_attn.py) showed 3500
@@ -88,6 +91,7 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(half_t *__restrict__ qkv, 
 // exit at once.  Partial = {max, sum, acc[128]} in fp32; attn_combine_kernel merges the splits.
 // ---------------------------------------------------------------------------------------
 constexpr int ATT_TS = 128;   // timesteps per split
+constexpr int ATT_LONG = 1024; // contexts above this many tokens run 64-step splits when the grid was launched for them (batch 1)
 constexpr int ATT_HD = 128;   // head_dim served
 constexpr int ATT_REC = ATT_HD + 2;
 
@@ -199,7 +203,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
                                                                 half_t *__restrict__ kc, half_t *__restrict__ vc,
                                                                 half_t *__restrict__ out, float *__restrict__ ws, int heads, int t_max,
                                                                 float inv_base, float scale, const float2 *__restrict__ rope_tab,
-                                                                u64_t *__restrict__ dbg, int ldq, int ldo) {
+                                                                u64_t *__restrict__ dbg, int ldq, int ldo, int ts_grid) {
     {   // this workgroup's row of the batch
         const int b = blockIdx.z;
         const size_t hdz = (size_t)heads * ATT_HD;
@@ -221,17 +225,27 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     __shared__ float sc[ATT_TS];
     __shared__ float accs[4][ATT_HD];
     __shared__ int last_flag;
-    const int h = blockIdx.x, s = blockIdx.y, nsplit = gridDim.y;
+    const int h = blockIdx.x, nsplit = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t pos = pos_ptr[0];
     if (dbg) st_[2] = stamp_cycles((uint32_t)pos);
     if (pos < 0 || pos >= t_max) return;
     const int len = (int)pos + 1;
-    const int t0 = s * ATT_TS;
+    // Round 5: the split length is chosen at RUN time.  The grid is fixed when the step is captured (ts_grid = 128, or 64 for a batch-1
+    // launch: twice the workgroups); a launch whose context is at most ATT_LONG tokens folds two grid splits into one 128-step split (odd grid
+    // splits leave at once), a longer one keeps 64-step splits -- 24 workgroups per head stream K / V at 1500 tokens instead of 12, each with
+    // half the dependent chain (~3.5 TB/s marginal on K / V with 128-step splits).
+    int s = blockIdx.y, ts = ATT_TS;
+    if (ts_grid == ATT_TS / 2) {
+        if (len > ATT_LONG) ts = ATT_TS / 2;
+        else if (s & 1) return;
+        else s >>= 1;
+    }
+    const int t0 = s * ts;
     if (t0 >= len) return;
-    const int nact = (len - t0) < ATT_TS ? (len - t0) : ATT_TS;
-    const int nsp = (len + ATT_TS - 1) / ATT_TS;         // active splits of this head
-    const bool own_new = (int)pos >= t0 && (int)pos < t0 + ATT_TS;
+    const int nact = (len - t0) < ts ? (len - t0) : ts;
+    const int nsp = (len + ts - 1) / ts;                 // active splits of this head
+    const bool own_new = (int)pos >= t0 && (int)pos < t0 + ts;
     const int hd = heads * ATT_HD;
     const int tnew = own_new ? (int)pos - t0 : -1;
     const int d8 = tid & 15, tsub = tid >> 4;
@@ -439,10 +453,12 @@ int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, cons
 
 int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
                              float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s, int batch, int64_t ldq, int64_t ldo) {
-    const int nsplit = (t_max + ATT_TS - 1) / ATT_TS;
+    // batch 1 and a cache that can hold a long context: a grid of 64-step splits (the kernel folds pairs of them below ATT_LONG tokens)
+    const int ts_grid = decode_attn_ts_grid(t_max, batch);
+    const int nsplit = (t_max + ts_grid - 1) / ts_grid;
     const float inv_base = -2.0f * logf(base) / (float)ATT_HD;
     hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(heads, nsplit, batch), dim3(256), 0, s, qkv, pos, kc, vc, out, ws, heads, t_max, inv_base,
-                       scale, (const float2 *)rope_table, dbg, (int)ldq, (int)ldo);
+                       scale, (const float2 *)rope_table, dbg, (int)ldq, (int)ldo, ts_grid);
     return (int)hipGetLastError();
 }
 
@@ -460,8 +476,14 @@ int rope_table_launch(float *table, int t_max, int head_dim, float base, hipStre
     return (int)hipGetLastError();
 }
 
+int decode_attn_ts_grid(int t_max, int batch) {
+    static const int long_splits = [] { const char *e = getenv("GPTQ_ATTN_LONG_SPLITS"); return e ? atoi(e) : 1; }();   // 0: 128-step splits always (A/B runs)
+    return (batch == 1 && t_max > ATT_LONG && long_splits) ? ATT_TS / 2 : ATT_TS;
+}
+
 size_t decode_attn_ws_bytes(int heads, int t_max, int batch) {
-    return (size_t)batch * ((size_t)heads * ((t_max + ATT_TS - 1) / ATT_TS) * ATT_REC * sizeof(float) + (size_t)heads * sizeof(unsigned));
+    const int ts = decode_attn_ts_grid(t_max, batch);    // (the two-launch path below uses 128-step splits: never more records than this)
+    return (size_t)batch * ((size_t)heads * ((t_max + ts - 1) / ts) * ATT_REC * sizeof(float) + (size_t)heads * sizeof(unsigned));
 }
 
 }  // namespace gptq

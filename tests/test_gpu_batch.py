@@ -167,6 +167,47 @@ def test_decode_attention_batch_rows_equal_single_row_launches(B, pos):
         assert rel_err(out[b].float().cpu().numpy(), ref.cpu().numpy()) < 2e-3, b
 
 
+@pytest.mark.parametrize('pos', [5, 1023, 1024, 1025, 1500, 2047])
+def test_decode_attention_long_context_splits(pos):
+    """a cache of 2048 tokens, batch 1: the launch has a grid of 64-step splits; up to 1024 tokens of context pairs of them fold into 128-step
+    splits, beyond they stay (24 workgroups per head at 1500 tokens).  Both regimes against fp32 softmax attention over the row's history and
+    against the two-launch path (RoPE + append, then 128-step partials + merge)."""
+    lib = _native.lib()
+    heads, hd, t_max = 4, 128, 2048
+    H = heads * hd
+    s = _native.stream_ptr(torch.device(DEV))
+    g = torch.Generator(device=DEV).manual_seed(pos)
+    qkv = torch.randn((1, 3 * H), device=DEV, generator=g).half()
+    kc = (torch.randn((t_max, H), device=DEV, generator=g) * 0.5).half()
+    vc = (torch.randn((t_max, H), device=DEV, generator=g) * 0.5).half()
+    p = torch.tensor([pos], dtype=torch.int64, device=DEV)
+    tab = torch.empty((t_max, hd // 2, 2), dtype=torch.float32, device=DEV)
+    _native.check(lib.gptq_rope_table_f32(tab.data_ptr(), t_max, hd, 10000.0, s), 'rope table')
+    scale = 1.0 / np.sqrt(hd)
+    nb = lib.gptq_decode_attn_workspace_bytes(heads, hd, t_max)
+    ws = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    k1, v1, out = kc.clone(), vc.clone(), torch.full((1, H), float('nan'), dtype=torch.float16, device=DEV)
+    for rep in range(2):          # twice: the arrival tickets must be back at zero
+        rc = lib.gptq_decode_attn_fused_table_f16(qkv.data_ptr(), p.data_ptr(), k1.data_ptr(), v1.data_ptr(), out.data_ptr(), ws.data_ptr(), nb, heads, hd, t_max,
+                                                  10000.0, scale, tab.data_ptr(), s)
+        _native.check(rc, 'gptq_decode_attn_fused_table_f16')
+    # the two-launch path on its own copies
+    k2, v2, q2, o2 = kc.clone(), vc.clone(), qkv.clone(), torch.empty((1, H), dtype=torch.float16, device=DEV)
+    ws2 = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    _native.check(lib.gptq_decode_rope_kv_f16(q2.data_ptr(), p.data_ptr(), k2.data_ptr(), v2.data_ptr(), heads, hd, t_max, 10000.0, s), 'rope_kv')
+    _native.check(lib.gptq_decode_attn_f16(q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), p.data_ptr(), o2.data_ptr(), ws2.data_ptr(), nb, heads, hd, t_max, scale, s), 'attn')
+    torch.cuda.synchronize()
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)                        # the appended row
+    assert rel_err(out.float().cpu().numpy(), o2.float().cpu().numpy()) < 1e-3
+    T = pos + 1
+    qr = q2[0, :H].view(heads, hd).float()                                    # q2 was rotated in place by the two-launch path
+    kk = k1[:T].view(T, heads, hd).transpose(0, 1).float()
+    vv = v1[:T].view(T, heads, hd).transpose(0, 1).float()
+    att = torch.softmax((qr[:, None, :] * kk).sum(-1) * scale, dim=-1)
+    ref = (att[:, :, None] * vv).sum(1).reshape(-1)
+    assert rel_err(out[0].float().cpu().numpy(), ref.cpu().numpy()) < 2e-3
+
+
 @pytest.mark.parametrize('M', [1, 2, 3, 4, 7, 8, 13, 16])
 @pytest.mark.parametrize('N,K', [(32000, 4096), (1000, 512), (515, 1288), (1000, 5120), (515, 8192), (48, 256)])
 def test_dense_matmat_lm_head(M, N, K):

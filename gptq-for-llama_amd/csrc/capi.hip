@@ -1269,6 +1269,11 @@ static int decode_rows_max(int N, int nsets) {
 /* persistent workspace every forward takes: [split-K words, zero on first use and left zero][scratch of the 16-row MFMA tiles] */
 size_t gptq_layer_workspace_bytes(void) { return WS_BYTES + STRIPE_MM_WS_BYTES; }
 
+// a released layer whose dense route needs no checkpoint layout: trivial g_idx, an image, a product the tile GEMM of gemm8.hip takes
+static bool layer_dense_from_image(const gptq_layer &L, int M) {
+    return L.released && L.kind == 0 && L.stripe && L.K % 128 == 0 && gemm8_wanted(M, L.N, L.nsets == 2) && (L.nsets == 2 || !L.bias || aligned(L.bias, 8));
+}
+
 /* transient scratch that gives forward(M) its fast route: the gathered x of an act-order batch, the per-call dequantised weight */
 size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M) {
     if (!layer || M <= 0) return 0;
@@ -1276,9 +1281,22 @@ size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M) {
     // act-order layer: no K * N dequantised copy per call on the prompt path.  Should that kernel decline at launch, the ladder goes on
     // with what it was given (library-free kernels, or GPTQ_E_WORKSPACE for a released layer).
     if (gptq_layer_route_for(layer, M) == GPTQ_ROUTE_STRIPE_GEMM) return layer->kind == 1 ? a256((size_t)M * layer->K * 2) : 0;
-    const size_t unpack = (layer->released && M > 1) ? layer_unpacked_bytes(*layer) : 0;   // (M == 1 always runs on the image)
-    if (M >= LAYER_PREFILL_MIN_M && (M > LAYER_STRIPE_MM_MAX_M || !layer->stripe)) return unpack + gptq_prefill_workspace_bytes(M, layer->K, layer->N, layer->nsets);
+    size_t unpack = (layer->released && M > 1) ? layer_unpacked_bytes(*layer) : 0;   // (M == 1 always runs on the image)
+    if (M >= LAYER_PREFILL_MIN_M && (M > LAYER_STRIPE_MM_MAX_M || !layer->stripe)) {
+        // round 5: a released layer with a trivial g_idx feeds the tile GEMM straight from its image (stripe_dequant_t_kernel): no checkpoint
+        // layout is rebuilt.  Should that GEMM decline at launch the call returns GPTQ_E_WORKSPACE: gptq_layer_fallback_scratch_bytes() is the retry.
+        if (layer_dense_from_image(*layer, M)) unpack = 0;
+        return unpack + gptq_prefill_workspace_bytes(M, layer->K, layer->N, layer->nsets);
+    }
     return unpack + (layer->kind == 1 && M > 1 ? a256((size_t)M * layer->K * 2) : 0);
+}
+
+/* the scratch with which forward(M) cannot fail for lack of memory: every fall-back's needs (the rebuilt checkpoint layout of a released layer,
+ * the dense route's workspace, the gathered x of an act-order batch).  What a caller retries with after GPTQ_E_WORKSPACE. */
+size_t gptq_layer_fallback_scratch_bytes(const gptq_layer_t *layer, int M) {
+    if (!layer || M <= 0) return 0;
+    return (layer->released ? layer_unpacked_bytes(*layer) : 0) + gptq_prefill_workspace_bytes(M, layer->K, layer->N, layer->nsets) +
+           a256((size_t)M * layer->K * 2);
 }
 
 static int layer_forward_checkpoint(const gptq_layer &L, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace, void *scratch,
@@ -1349,6 +1367,14 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
                                          STRIPE_MM_WS_BYTES, true);
             if (rc != GPTQ_E_VARIANT) return rc;
         }
+    }
+    if (M >= LAYER_PREFILL_MIN_M && layer_dense_from_image(L, M) && scratch && aligned(scratch, 256) && scratch_bytes >= a256((size_t)K * N * ns * 2)) {
+        // memory mode, prompt sizes: image -> W^T in ONE pass (bit-identical to the weight the two-pass route dequantises), then the tile GEMM
+        half_t *Wt = (half_t *)scratch;
+        int rc = stripe_dequant_t_launch(L.stripe, K, N, bits, gs, ns, Wt, K, (hipStream_t)stream);
+        if (rc == 0) rc = gemm8_dense_f16((const half_t *)x, ldx, Wt, K, ns == 2 ? nullptr : (const half_t *)L.bias, (half_t *)y, ldy, M, K, N, ns == 2,
+                                          (hipStream_t)stream);
+        if (rc != GPTQ_E_VARIANT) return rc;
     }
     gptq_layer Lr;   // a released layer: the checkpoint layout is rebuilt from the image into the head of `scratch` for the routes below
     const gptq_layer *Lp = &L;

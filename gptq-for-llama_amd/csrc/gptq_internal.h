@@ -137,6 +137,9 @@ uint32_t *stripe_progress_counter();   // capi.hip: gptq_set_progress_counter (N
 int stripe_unpack_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, int set, uint32_t *qw, half_t *sc, int32_t *qz,
                          hipStream_t s, const int32_t *invperm = nullptr);
 
+// round 5: Wt[set * N + n][k] fp16 (k contiguous: the operand of gemm8) straight from an image with trivial g_idx; bit-identical to dequant_t_launch
+int stripe_dequant_t_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, half_t *out, int64_t ldo, hipStream_t s);
+
 int gptq_block_launch(const float *W, int64_t ldw, const float *Hinv, int64_t ldh, int rows, int i1, int count, int groupsize, int maxq,
                       const float *scale, const float *zero, int64_t ldg, float *Q, int64_t ldq, float *Err, int64_t lde, float *loss_rows,
                       hipStream_t s);

@@ -35,6 +35,8 @@
 // arithmetic of rms_norm_fwd_fused, quant/triton_norm.py:22-39, every workgroup sees all of x anyway), barrier, then
 // the remaining blocks are requested one ahead of the math (a CU keeps only ~32-40 KiB of loads in flight; a wave
 // parked in a full queue cannot work on data that has already arrived).
+#include <algorithm>
+
 #include "gptq_device.h"
 #include "gptq_internal.h"
 #include "stripe_common.h"
@@ -239,6 +241,56 @@ __global__ void __launch_bounds__(256) stripe_untable3_kernel(const uint32_t *__
     }
 }
 
+// ---- image -> dense fp16 W^T (round 5): the operand of the prefill tile GEMM straight from the stripe16 image ----
+// A released layer (memory mode: the image is the only copy) used to rebuild the checkpoint layout per call (stripe_unpack_kernel) and then
+// dequantise THAT (dequant_t_kernel): two passes over the weights in front of every prompt.  One pass: thread = (stripe, row block, set, lane)
+// owns the lane's block of LK consecutive k of ONE column -- exactly its WPL image words -- and writes Wt[n][k .. k + LK) (2 LK bytes, the four
+// lanes of a column 8 LK bytes contiguous).  The arithmetic is dequant_t_kernel's, element for element: fp16(q - (zero + 1)) * fp16 scale, one
+// rounding (reference quant_linear.py:128) -- bit-identical weights, hence bit-identical products.  Trivial g_idx (the image of an act-order
+// layer holds sorted rows: its W^T would be a 2-byte scatter; those layers keep the two-pass route).
+template <int BITS>
+__global__ void __launch_bounds__(256) stripe_dequant_t_kernel(const uint32_t *__restrict__ R, const uint32_t *__restrict__ tab, half_t *__restrict__ out,
+                                                               int64_t ldo, int K, int N, int nrb, int NS, int G, int groupsize) {
+    constexpr int F = BITS == 3 ? 0 : 32 / BITS, WPLv = BITS == 3 ? 3 : 4, LKv = stripe_lk(BITS);
+    const size_t total = (size_t)(N / 16) * nrb * NS * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int l = (int)(i & 63);
+        size_t b = i >> 6;
+        const int set = (int)(b % NS); b /= NS;
+        const int rb = (int)(b % nrb);
+        const int stripe = (int)(b / nrb);
+        const int c = l & 15, n = 16 * stripe + c, k0 = rb * 4 * LKv + (l >> 4) * LKv;
+        uint32_t w[WPLv];
+#pragma unroll
+        for (int j = 0; j < WPLv; j++) w[j] = R[i * WPLv + j];
+        const int g = groupsize >= K ? 0 : k0 / groupsize;
+        half2_t e = as_half2(tab[(((size_t)stripe * NS + set) * G + g) * 16 + c]);
+        half_t *dst = out + ((size_t)set * N + n) * ldo + k0;
+#pragma unroll
+        for (int j8 = 0; j8 < LKv / 8; j8++) {
+            half8_t v;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int kk = 8 * j8 + t;                       // k inside the lane block
+                if (groupsize < LKv && groupsize < K) {            // groups smaller than a lane block (8-bit g16 ...): per element
+                    const int g2 = (k0 + kk) / groupsize;
+                    e = as_half2(tab[(((size_t)stripe * NS + set) * G + g2) * 16 + c]);
+                }
+                uint32_t q;
+                if constexpr (BITS == 3) {
+                    q = image3_field(w, kk);
+                } else {
+                    const int word = kk / F, f = kk % F;          // packed row of the lane, field (natural k order) inside it
+                    const int pos = (f & 1) ? (f - 1) / 2 + F / 2 : f / 2;   // inverse of stripe_k_of_pos
+                    q = (w[word] >> (BITS * pos)) & ((1u << BITS) - 1u);
+                }
+                v[t] = (half_t)((half_t)(float)q - e[1]) * e[0];
+            }
+            *(half8_t *)(dst + 8 * j8) = v;
+        }
+    }
+}
+
 }  // namespace
 
 int stripe_unpack_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, int set, uint32_t *qw, half_t *sc, int32_t *qz,
@@ -258,6 +310,24 @@ int stripe_unpack_launch(const void *image, int K, int N, int bits, int groupsiz
     if (bits == 2) hipLaunchKernelGGL(stripe_untable_kernel<2>, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
     else if (bits == 4) hipLaunchKernelGGL(stripe_untable_kernel<4>, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
     else hipLaunchKernelGGL(stripe_untable_kernel<8>, dim3(512), dim3(256), 0, s, tab, sc, (uint32_t *)qz, N, G, nsets, set);
+    return (int)hipGetLastError();
+}
+
+// Wt[set * N + n][k] (row stride ldo) = the dense fp16 weight of every set of the image, k contiguous
+int stripe_dequant_t_launch(const void *image, int K, int N, int bits, int groupsize, int nsets, half_t *out, int64_t ldo, hipStream_t s) {
+    if (stripe_gq_shift(K, N, bits, groupsize) == -2 || nsets < 1 || nsets > 2) return GPTQ_E_VARIANT;
+    if (ldo % 8 != 0 || ((uintptr_t)out % 16) != 0 || ldo < K) return GPTQ_E_ALIGN;
+    const int G = groupsize >= K ? 1 : K / groupsize, nrb = K / (4 * stripe_lk(bits));
+    const uint32_t *R = (const uint32_t *)image;
+    const uint32_t *tab = (const uint32_t *)((const char *)image + stripe_tab_offset(K, N, bits, nsets));
+    const size_t total = (size_t)(N / 16) * nrb * nsets * 64;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+    switch (bits) {
+        case 2: hipLaunchKernelGGL(stripe_dequant_t_kernel<2>, dim3(grid), dim3(256), 0, s, R, tab, out, ldo, K, N, nrb, nsets, G, groupsize); break;
+        case 3: hipLaunchKernelGGL(stripe_dequant_t_kernel<3>, dim3(grid), dim3(256), 0, s, R, tab, out, ldo, K, N, nrb, nsets, G, groupsize); break;
+        case 4: hipLaunchKernelGGL(stripe_dequant_t_kernel<4>, dim3(grid), dim3(256), 0, s, R, tab, out, ldo, K, N, nrb, nsets, G, groupsize); break;
+        default: hipLaunchKernelGGL(stripe_dequant_t_kernel<8>, dim3(grid), dim3(256), 0, s, R, tab, out, ldo, K, N, nrb, nsets, G, groupsize); break;
+    }
     return (int)hipGetLastError();
 }
 

@@ -114,6 +114,7 @@ _SIGNATURES = {
     'gptq_layer_route_for': [c_void_p, c_int],
     'gptq_layer_workspace_bytes': [],
     'gptq_layer_scratch_bytes': [c_void_p, c_int],
+    'gptq_layer_fallback_scratch_bytes': [c_void_p, c_int],
     'gptq_layer_forward': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p],
     'gptq_set_progress_counter': [c_void_p],
     'gptq_stripe_matmul_partial_f32': [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
@@ -161,6 +162,7 @@ def lib():
             L.gptq_layer_image_bytes.restype = c_size_t
             L.gptq_layer_workspace_bytes.restype = c_size_t
             L.gptq_layer_scratch_bytes.restype = c_size_t
+            L.gptq_layer_fallback_scratch_bytes.restype = c_size_t
             L.gptq_layer_decode_scratch_bytes.restype = c_size_t
             L.gptq_decode_attn_batch_workspace_bytes.restype = c_size_t
             L.gptq_layer_destroy.restype = None

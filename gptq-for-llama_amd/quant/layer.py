@@ -127,6 +127,14 @@ class PreparedLayer:
         scratch = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None     # caching allocator: the next layer reuses it
         rc = lib.gptq_layer_forward(self.handle, x.data_ptr(), x.stride(0) if M > 1 else self.K, out.data_ptr(), out.stride(0) if M > 1 else self.N, M,
                                     ws.data_ptr(), ws.numel(), _native.ptr(scratch), need, stream)
+        if rc == -5:
+            # GPTQ_E_WORKSPACE: a kernel of the fast route declined at launch (LDS opt-in, a strided x beyond its address range ...) and the fall-back
+            # wants scratch the fast route did not ask for (the rebuilt checkpoint layout of a released layer, the dense route's workspace): once
+            # more with everything
+            need = lib.gptq_layer_fallback_scratch_bytes(self.handle, M)
+            scratch = torch.empty(need, dtype=torch.uint8, device=x.device)
+            rc = lib.gptq_layer_forward(self.handle, x.data_ptr(), x.stride(0) if M > 1 else self.K, out.data_ptr(), out.stride(0) if M > 1 else self.N, M,
+                                        ws.data_ptr(), ws.numel(), scratch.data_ptr(), need, stream)
         _native.check(rc, 'gptq_layer_forward')
         return out
 

@@ -433,6 +433,8 @@ int gptq_layer_release_checkpoint(gptq_layer_t *layer);
 int gptq_layer_unpack_checkpoint(const gptq_layer_t *layer, int set, int32_t *qweight, void *scales, int32_t *qzeros, gptq_stream_t stream);
 size_t gptq_layer_workspace_bytes(void);
 size_t gptq_layer_scratch_bytes(const gptq_layer_t *layer, int M);
+/* every fall-back's needs at once: the scratch to retry with when forward() answers GPTQ_E_WORKSPACE (a kernel of the fast route declined at launch) */
+size_t gptq_layer_fallback_scratch_bytes(const gptq_layer_t *layer, int M);
 int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, void *workspace,
                        size_t workspace_bytes, void *scratch, size_t scratch_bytes, gptq_stream_t stream);
 /* The M -> kernel table of gptq_layer_forward as a host-only query (no launch, no GPU needed): the kernel family a batch of M rows takes,

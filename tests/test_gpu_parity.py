@@ -1708,3 +1708,60 @@ def test_small_batches_on_multi_round_shapes(bits, K, N, M):
         assert QL.stripe_matvec(xd[m:m + 1], st, one, K, N, bits, 128, bias=dev(b))
         # two independently rounded fp16 results (bias: two roundings each): ONE fp16 spacing at the top of the range is already 1e-3 of max|y|
         assert rel_err(y[m:m + 1], one.cpu().numpy()) < 2 * TOL
+
+
+@pytest.mark.parametrize('bits,gs,K,N,pair', [(4, 128, 4096, 4096, False), (4, 128, 1024, 2816, True), (8, 64, 1024, 288, False), (3, 128, 1152, 320, False),
+                                             (2, 128, 1024, 96, False)])
+def test_released_layer_prefill_straight_from_the_image(bits, gs, K, N, pair):
+    """round 5: memory mode at prompt sizes.  A released layer used to rebuild the checkpoint layout per call and dequantise
+    THAT; now its W^T comes out of the stripe16 image in one pass (stripe_dequant_t_kernel) -- the SAME fp16 weight, so the product of the
+    tile GEMM is bit-identical to the two-copy route's, for every width, the gate/up pair included; the scratch request shrinks by the
+    rebuilt buffers; against the oracle as well."""
+    lib = _native.lib()
+    A = make_random_layer(bits, gs, K, N, seed=K + N + bits)
+    B = make_random_layer(bits, gs, K, N, seed=K + N + bits + 1)
+    sets = tuple((dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx'])) for L in ((A, B) if pair else (A,)))
+    from quant.layer import PreparedLayer
+    pl = PreparedLayer(sets, None, bits, gs, K, N)
+    M = 2600                                          # above the fused tile GEMM on the image (2048 rows): the dense route
+    x = dev((np.random.default_rng(5).standard_normal((M, K)) * 0.5).astype(np.float16))
+    y0 = torch.empty((M, N), dtype=torch.float16, device=DEV)
+    pl.forward(x, y0)
+    need0 = lib.gptq_layer_scratch_bytes(pl.handle, M)
+    assert pl.release()
+    need1 = lib.gptq_layer_scratch_bytes(pl.handle, M)
+    if K % 128 == 0:
+        assert need1 == need0                         # nothing is rebuilt: the dense workspace alone
+    assert lib.gptq_layer_fallback_scratch_bytes(pl.handle, M) > need1
+    for t in sets:
+        for u in t[:3]:
+            u.fill_(0)                                # the "freed" buffers must never be read again
+    y1 = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+    pl.forward(x, y1)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    xs = x[:64].cpu().numpy()
+    ta = (A['qweight'], A['scales'], A['qzeros'], A['g_idx'])
+    ref = oracle.fused_mlp(xs, ta, (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits) if pair else oracle.matmul248(xs, *ta, bits)
+    assert rel_err(y1[:64].cpu().numpy(), ref) < (2 * TOL if pair else TOL)
+
+
+def test_released_layer_retries_with_the_fallback_scratch():
+    """gptq_layer_scratch_bytes answers for the route the table picks; when that kernel declines at launch -- here the fused tile
+    GEMM on the image refuses an x whose rows are 2^23 halves apart (its buffer descriptor ends at 2 GB) -- a released layer's fall-back
+    needs the rebuilt checkpoint layout + the dense workspace.  PreparedLayer.forward retries once with gptq_layer_fallback_scratch_bytes
+    instead of raising GPTQ_E_WORKSPACE."""
+    K, N, bits, gs = 1024, 512, 4, 128
+    L = make_random_layer(bits, gs, K, N, seed=77)
+    from quant.layer import PreparedLayer
+    pl = PreparedLayer(((dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx'])),), None, bits, gs, K, N)
+    assert pl.release()
+    M, ld = 200, 1 << 23
+    big = torch.zeros(M * ld, dtype=torch.float16, device=DEV)
+    xv = torch.as_strided(big, (M, K), (ld, 1))
+    xs = (np.random.default_rng(9).standard_normal((M, K)) * 0.5).astype(np.float16)
+    xv.copy_(dev(xs))
+    y = torch.empty((M, N), dtype=torch.float16, device=DEV)
+    pl.forward(xv, y)
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), oracle_forward(xs, L)) < TOL

@@ -231,10 +231,10 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     if (dbg) st_[2] = stamp_cycles((uint32_t)pos);
     if (pos < 0 || pos >= t_max) return;
     const int len = (int)pos + 1;
-    // Round 5: the split length is chosen at RUN time.  The grid is fixed when the step is captured (ts_grid = 128, or 64 for a batch-1
-    // launch: twice the workgroups); a launch whose context is at most ATT_LONG tokens folds two grid splits into one 128-step split (odd grid
-    // splits leave at once), a longer one keeps 64-step splits -- 24 workgroups per head stream K / V at 1500 tokens instead of 12, each with
-    // half the dependent chain (~3.5 TB/s marginal on K / V with 128-step splits).
+    // Round 5: the split length can be chosen at RUN time.  The grid is fixed when the step is captured (ts_grid = 128, or -- an A/B knob, see
+    // decode_attn_ts_grid: measured, slower, off by default -- 64 for a batch-1 launch: twice the workgroups); with the 64-step grid a launch whose
+    // context is at most ATT_LONG tokens folds two grid splits into one 128-step split (odd grid splits leave at once), a longer one keeps
+    // 64-step splits: 24 workgroups per head stream K / V at 1500 tokens instead of 12.
     int s = blockIdx.y, ts = ATT_TS;
     if (ts_grid == ATT_TS / 2) {
         if (len > ATT_LONG) ts = ATT_TS / 2;
@@ -477,7 +477,11 @@ int rope_table_launch(float *table, int t_max, int head_dim, float base, hipStre
 }
 
 int decode_attn_ts_grid(int t_max, int batch) {
-    static const int long_splits = [] { const char *e = getenv("GPTQ_ATTN_LONG_SPLITS"); return e ? atoi(e) : 1; }();   // 0: 128-step splits always (A/B runs)
+    // MEASURED AND OFF (gpurun_out r5f / profiles/r5*/engine_context.txt, tok/s of the 7B engine at 0 / 500 / 1000 / 1500 / 1900 tokens of context):
+    // 64-step splits 922 / 784 / 746 / 699 / 671 against 925 / 795 / 763 / 749 / 720 for 128-step splits -- twice the workgroups per head mean twice
+    // the records in the merge and twice the tickets, and the K / V stream of a head was not short of parallelism: the launch is bound by the
+    // dependent round trips of the merge, not by the splits.  GPTQ_ATTN_LONG_SPLITS=1 switches the 64-step grid on for A/B runs.
+    static const int long_splits = [] { const char *e = getenv("GPTQ_ATTN_LONG_SPLITS"); return e ? atoi(e) : 0; }();
     return (batch == 1 && t_max > ATT_LONG && long_splits) ? ATT_TS / 2 : ATT_TS;
 }
 

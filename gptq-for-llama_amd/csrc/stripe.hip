@@ -248,46 +248,59 @@ __global__ void __launch_bounds__(256) stripe_untable3_kernel(const uint32_t *__
 // lanes of a column 8 LK bytes contiguous).  The arithmetic is dequant_t_kernel's, element for element: fp16(q - (zero + 1)) * fp16 scale, one
 // rounding (reference quant_linear.py:128) -- bit-identical weights, hence bit-identical products.  Trivial g_idx (the image of an act-order
 // layer holds sorted rows: its W^T would be a 2-byte scatter; those layers keep the two-pass route).
+// Workgroup = one stripe (16 columns) x 4 consecutive row blocks x one set; wave = row block.  The 16 x (4 BK) tile goes through LDS so that it
+// leaves as whole rows: 8 BK bytes contiguous per column (1 KiB for 4 bits) instead of 2 LK-byte pieces per lane (the first version: 64-byte
+// stores, +7 .. 14 % on a 4096 x 4096 prompt against the two-copy route; gpurun_out r5f).
 template <int BITS>
 __global__ void __launch_bounds__(256) stripe_dequant_t_kernel(const uint32_t *__restrict__ R, const uint32_t *__restrict__ tab, half_t *__restrict__ out,
                                                                int64_t ldo, int K, int N, int nrb, int NS, int G, int groupsize) {
-    constexpr int F = BITS == 3 ? 0 : 32 / BITS, WPLv = BITS == 3 ? 3 : 4, LKv = stripe_lk(BITS);
-    const size_t total = (size_t)(N / 16) * nrb * NS * 64;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int l = (int)(i & 63);
-        size_t b = i >> 6;
+    constexpr int F = BITS == 3 ? 1 : 32 / BITS, WPLv = BITS == 3 ? 3 : 4, LKv = stripe_lk(BITS), BKv = 4 * LKv, TK = 4 * BKv, PITCH = TK + 8;
+    __shared__ __attribute__((aligned(16))) half_t tile[16 * PITCH];
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+    const int nq = (nrb + 3) / 4;                                 // groups of four row blocks
+    const size_t ntiles = (size_t)(N / 16) * nq * NS;
+    for (size_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        size_t b = tix;
         const int set = (int)(b % NS); b /= NS;
-        const int rb = (int)(b % nrb);
-        const int stripe = (int)(b / nrb);
-        const int c = l & 15, n = 16 * stripe + c, k0 = rb * 4 * LKv + (l >> 4) * LKv;
-        uint32_t w[WPLv];
+        const int q4 = (int)(b % nq);
+        const int stripe = (int)(b / nq);
+        const int rb = q4 * 4 + wv;
+        const int c = l & 15, kl = wv * BKv + (l >> 4) * LKv;      // k inside the tile
+        if (rb < nrb) {
+            const size_t i = (((size_t)stripe * nrb + rb) * NS + set) * 64 + l;
+            uint32_t w[WPLv];
 #pragma unroll
-        for (int j = 0; j < WPLv; j++) w[j] = R[i * WPLv + j];
-        const int g = groupsize >= K ? 0 : k0 / groupsize;
-        half2_t e = as_half2(tab[(((size_t)stripe * NS + set) * G + g) * 16 + c]);
-        half_t *dst = out + ((size_t)set * N + n) * ldo + k0;
+            for (int j = 0; j < WPLv; j++) w[j] = R[i * WPLv + j];
+            const int k0 = q4 * TK + kl;
+            const int g = groupsize >= K ? 0 : k0 / groupsize;
+            const half2_t e = as_half2(tab[(((size_t)stripe * NS + set) * G + g) * 16 + c]);
 #pragma unroll
-        for (int j8 = 0; j8 < LKv / 8; j8++) {
-            half8_t v;
+            for (int j8 = 0; j8 < LKv / 8; j8++) {
+                half8_t v;
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int kk = 8 * j8 + t;                       // k inside the lane block
-                if (groupsize < LKv && groupsize < K) {            // groups smaller than a lane block (8-bit g16 ...): per element
-                    const int g2 = (k0 + kk) / groupsize;
-                    e = as_half2(tab[(((size_t)stripe * NS + set) * G + g2) * 16 + c]);
+                for (int t = 0; t < 8; t++) {
+                    const int kk = 8 * j8 + t;                       // k inside the lane block
+                    uint32_t q;
+                    if constexpr (BITS == 3) {
+                        q = image3_field(w, kk);
+                    } else {
+                        const int word = kk / F, f = kk % F;          // packed row of the lane, field (natural k order) inside it
+                        const int pos = (f & 1) ? (f - 1) / 2 + F / 2 : f / 2;   // inverse of stripe_k_of_pos
+                        q = (w[word] >> (BITS * pos)) & ((1u << BITS) - 1u);
+                    }
+                    v[t] = (half_t)((half_t)(float)q - e[1]) * e[0];
                 }
-                uint32_t q;
-                if constexpr (BITS == 3) {
-                    q = image3_field(w, kk);
-                } else {
-                    const int word = kk / F, f = kk % F;          // packed row of the lane, field (natural k order) inside it
-                    const int pos = (f & 1) ? (f - 1) / 2 + F / 2 : f / 2;   // inverse of stripe_k_of_pos
-                    q = (w[word] >> (BITS * pos)) & ((1u << BITS) - 1u);
-                }
-                v[t] = (half_t)((half_t)(float)q - e[1]) * e[0];
+                *(half8_t *)(tile + c * PITCH + kl + 8 * j8) = v;
             }
-            *(half8_t *)(dst + 8 * j8) = v;
         }
+        __syncthreads();
+        // 16 rows x TK / 8 pieces of 16 bytes: consecutive threads -> consecutive pieces of one row
+        constexpr int PPR = TK / 8;
+        for (int p = tid; p < 16 * PPR; p += 256) {
+            const int r = p / PPR, pc = p % PPR, k = q4 * TK + pc * 8;
+            if (k < K) *(half8_t *)(out + ((size_t)set * N + 16 * stripe + r) * ldo + k) = *(const half8_t *)(tile + r * PITCH + pc * 8);
+        }
+        __syncthreads();
     }
 }
 
@@ -320,8 +333,8 @@ int stripe_dequant_t_launch(const void *image, int K, int N, int bits, int group
     const int G = groupsize >= K ? 1 : K / groupsize, nrb = K / (4 * stripe_lk(bits));
     const uint32_t *R = (const uint32_t *)image;
     const uint32_t *tab = (const uint32_t *)((const char *)image + stripe_tab_offset(K, N, bits, nsets));
-    const size_t total = (size_t)(N / 16) * nrb * nsets * 64;
-    const int grid = (int)std::min<size_t>((total + 255) / 256, 16384);
+    const size_t ntiles = (size_t)(N / 16) * ((nrb + 3) / 4) * nsets;
+    const int grid = (int)std::min<size_t>(ntiles, 8192);
     switch (bits) {
         case 2: hipLaunchKernelGGL(stripe_dequant_t_kernel<2>, dim3(grid), dim3(256), 0, s, R, tab, out, ldo, K, N, nrb, nsets, G, groupsize); break;
         case 3: hipLaunchKernelGGL(stripe_dequant_t_kernel<3>, dim3(grid), dim3(256), 0, s, R, tab, out, ldo, K, N, nrb, nsets, G, groupsize); break;

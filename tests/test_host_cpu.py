@@ -79,7 +79,7 @@ def test_argument_validation_needs_no_gpu():
         _native.check(-1, 'x')
     with pytest.raises(RuntimeError):
         _native.check(-7, 'x')
-    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == 32 * 32 * 130 * 4 + 32 * 4      # round 5: a batch-1 cache beyond 1024 tokens gets a grid of 64-step splits
+    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == 32 * (32 if os.environ.get('GPTQ_ATTN_LONG_SPLITS', '0') != '0' else 16) * 130 * 4 + 32 * 4
     assert lib.gptq_decode_attn_workspace_bytes(32, 64, 2048) == 0
 
 
@@ -310,7 +310,7 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert lib.gptq_add_rows_f16(one, 64, one, 64, 0, 64, None) == 0
     rec = lambda heads, splits: heads * splits * 130 * 4 + heads * 4          # {max, sum, acc[128]} per (head, split) + one ticket per head
     assert lib.gptq_decode_attn_batch_workspace_bytes(4, 32, 128, 2048) == 4 * rec(32, 16)        # a batch: 128-step splits
-    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == rec(32, 32)                     # one row, a cache beyond 1024 tokens: 64-step grid
+    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == rec(32, 32 if os.environ.get('GPTQ_ATTN_LONG_SPLITS', '0') != '0' else 16)   # (64-step grid: an A/B knob, off)
     assert lib.gptq_decode_attn_workspace_bytes(32, 128, 1024) == rec(32, 8)
     assert lib.gptq_decode_attn_batch_workspace_bytes(4, 32, 64, 2048) == 0
     assert lib.gptq_decode_attn_batch_f16(one, 3 * 256, one, one, one, one, 256, one, 16, 2, 2, 128, 64, 10000.0, 1.0, None, None) == -5    # workspace too small

@@ -730,8 +730,6 @@ def decode_tokens_per_s(dev, tokens=64):
     # (README.md:26, protocol llama.py:426-438)
     out['drop_in_forward'] = benchmark_decode(model, tokens)
     out['drop_in_generate'] = benchmark_generate(model)
-    # round 5: generate on FOUR left-padded prompts -- [4, 1] steps with per-row positions answered by DecodeEngine(batch=4)
-    out['drop_in_generate_b4_left_padded'] = benchmark_generate(model, batch=4, left_pad=True, new_tokens=64)
     from quant.engine_hook import drop_decode_engines
     drop_decode_engines(model)     # the hook's engines (1 GB of K/V cache per row + a graph each) would sit next to the ones measured below
     torch.cuda.empty_cache()
@@ -745,6 +743,11 @@ def decode_tokens_per_s(dev, tokens=64):
     for B in (2, 4, 8, 16):
         torch.cuda.empty_cache()
         out['engine_graph_b%d' % B] = benchmark_decode_engine(model, tokens=32, graph=True, batch=B)
+    # ... and through the reference's own call site: generate on FOUR left-padded prompts -- [4, 1] steps with per-row positions, answered by the hook's
+    # DecodeEngine(batch=4) (HF's per-step host work included)
+    torch.cuda.empty_cache()
+    out['drop_in_generate_b4_left_padded'] = benchmark_generate(model, batch=4, left_pad=True, new_tokens=64)
+    drop_decode_engines(model)
     return out
 
 

@@ -911,8 +911,9 @@ size_t gptq_decode_attn_batch_workspace_bytes(int batch, int heads, int head_dim
 
 int gptq_decode_attn_batch_f16(const void *qkv, int64_t ldq, const int64_t *positions, void *k_cache, void *v_cache, void *out, int64_t ldo,
                                void *workspace, size_t workspace_bytes, int batch, int heads, int head_dim, int t_max, float base, float scale,
-                               const float *rope_table, gptq_stream_t stream) {
+                               const float *rope_table, const int32_t *out_perm, gptq_stream_t stream) {
     if (!qkv || !k_cache || !v_cache || !positions || !out || !workspace) return GPTQ_E_NULL;
+    if (out_perm && !aligned(out_perm, 4)) return GPTQ_E_ALIGN;
     if (batch <= 0 || batch > 65535 || heads <= 0 || head_dim != 128 || t_max <= 0 || ldq < 3 * (int64_t)heads * head_dim || ldo < (int64_t)heads * head_dim)
         return GPTQ_E_SHAPE;
     if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4) || (rope_table && !aligned(rope_table, 8)) ||
@@ -920,7 +921,7 @@ int gptq_decode_attn_batch_f16(const void *qkv, int64_t ldq, const int64_t *posi
         return GPTQ_E_ALIGN;
     if (workspace_bytes < decode_attn_ws_bytes(heads, t_max, batch)) return GPTQ_E_WORKSPACE;
     return decode_attn_fused_launch((const half_t *)qkv, positions, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out, (float *)workspace, heads, t_max,
-                                    base, scale, rope_table, (u64_t *)g_debug_buffer.load(), (hipStream_t)stream, batch, ldq, ldo);
+                                    base, scale, rope_table, (u64_t *)g_debug_buffer.load(), (hipStream_t)stream, batch, ldq, ldo, out_perm);
 }
 
 // ---- stripe16: no-split-K decode GEMV on a load-time repacked copy (stripe*.hip) ----
@@ -944,7 +945,8 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
 
 static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, float *y32,
                          int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
-                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false, int64_t ldb = 0) {
+                         gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false, int64_t ldb = 0,
+                         const int32_t *yperm = nullptr) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
@@ -955,6 +957,7 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     if (M > 1 && (perm || (y32 && (M > 4 || norm_weight)))) return GPTQ_E_VARIANT;
     if (norm_weight && mm_ws) return GPTQ_E_VARIANT;        // the fused norm lives in the decode kernel only (every row its own rstd)
     if (ldb != 0 && (!bias || ldb < N || y32)) return GPTQ_E_SHAPE;
+    if (yperm && (mm_ws || y32 || !aligned(yperm, 4))) return GPTQ_E_VARIANT;          // the scattered store lives in the decode kernel only
     if (stripes_bytes < stripe_total_bytes(K, N, bits, groupsize, nsets)) return GPTQ_E_WORKSPACE;
     if (!aligned(x, 16) || !aligned(stripes, 16) || !aligned(y, 2) || !aligned(y32, 4) || (norm_weight && !aligned(norm_weight, 16)) ||
         (perm && !aligned(perm, 16)) || (M > 1 && (ldx % 8 != 0 || ldy < N)))
@@ -970,6 +973,7 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.y32 = y32;
     p.bias = (const half_t *)bias;
     p.ldb = ldb;
+    p.yperm = yperm;
     p.norm_w = (const half_t *)norm_weight;
     p.norm_eps = norm_eps;
     p.xperm = perm;
@@ -1036,6 +1040,17 @@ int gptq_stripe_matvec_f16(const void *x, int64_t ldx, const void *stripes, size
                            gptq_stream_t stream) {
     if (!y) return GPTQ_E_NULL;
     return stripe_matvec(x, ldx, stripes, stripes_bytes, bias, y, ldy, nullptr, M, K, N, bits, groupsize, nsets, norm_weight, norm_eps, perm, stream);
+}
+
+/* the same launch with the columns of y stored through a permutation: y[m][y_perm[n]] = result column n (round 5: the consumer of y is an act-order
+ * layer whose image holds group-sorted rows -- written in ITS order, it runs the trivial kernel instead of gathering x per launch).  M <= 4 (8 / 16
+ * where the row groups run); y_perm: int32 [N], a permutation of 0 .. N - 1. */
+int gptq_stripe_matvec_perm_out_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
+                                    int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
+                                    const int32_t *y_perm, gptq_stream_t stream) {
+    if (!y) return GPTQ_E_NULL;
+    return stripe_matvec(x, ldx, stripes, stripes_bytes, bias, y, ldy, nullptr, M, K, N, bits, groupsize, nsets, norm_weight, norm_eps, perm, stream, nullptr, 0,
+                         false, 0, y_perm);
 }
 
 int gptq_stripe_matmul_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
@@ -1230,6 +1245,13 @@ int gptq_layer_stripe_image(const gptq_layer_t *layer, const void **stripe, size
     if (stripe) *stripe = layer->stripe;
     if (stripe_bytes) *stripe_bytes = layer->stripe_bytes;
     if (perm16) *perm16 = layer->perm16;
+    return GPTQ_OK;
+}
+/* regular act-order layer: original k -> position in the group-sorted order of its image (int32 [K]; NULL for other layers).  What a PRODUCER of
+ * this layer's input stores through (gptq_stripe_matvec_perm_out_f16, gptq_decode_attn_batch_f16 out_perm) so that the layer needs no gather. */
+int gptq_layer_inverse_perm(const gptq_layer_t *layer, const int32_t **invperm32) {
+    if (!layer || !invperm32) return GPTQ_E_NULL;
+    *invperm32 = layer->kind == 1 ? layer->invperm32 : nullptr;
     return GPTQ_OK;
 }
 

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
                                                                 half_t *__restrict__ kc, half_t *__restrict__ vc,
                                                                 half_t *__restrict__ out, float *__restrict__ ws, int heads, int t_max,
                                                                 float inv_base, float scale, const float2 *__restrict__ rope_tab,
-                                                                u64_t *__restrict__ dbg, int ldq, int ldo, int ts_grid) {
+                                                                u64_t *__restrict__ dbg, int ldq, int ldo, int ts_grid, const int32_t *__restrict__ out_perm) {
     {   // this workgroup's row of the batch
         const int b = blockIdx.z;
         const size_t hdz = (size_t)heads * ATT_HD;
@@ -227,6 +227,9 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     __shared__ int last_flag;
     const int h = blockIdx.x, nsplit = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // out_perm (round 5): o_proj is an act-order layer whose image holds group-sorted rows -- element k of the attention output goes where its sorted
+    // order wants it, so o_proj runs the trivial kernel.  Requested first: nothing depends on it until the store.
+    const int ocol = (tid < ATT_HD) ? (out_perm ? out_perm[h * ATT_HD + tid] : h * ATT_HD + tid) : 0;
     const int64_t pos = pos_ptr[0];
     if (dbg) st_[2] = stamp_cycles((uint32_t)pos);
     if (pos < 0 || pos >= t_max) return;
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     if (tid < ATT_HD) acc = accs[0][tid] + accs[1][tid] + accs[2][tid] + accs[3][tid];
 
     if (nsp == 1) {  // short context: this workgroup is the whole head
-        if (tid < ATT_HD) out[(size_t)h * ATT_HD + tid] = (half_t)(acc / l);
+        if (tid < ATT_HD) out[ocol] = (half_t)(acc / l);
         if (dbg && lane == 0) {
             st_[6] = stamp_cycles(__builtin_bit_cast(uint32_t, acc));
             const u64_t te = stamp_realtime();
@@ -432,7 +435,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
                     den += w * li[i];
                 }
         }
-        out[(size_t)h * ATT_HD + tid] = (half_t)(num / den);
+        out[ocol] = (half_t)(num / den);
     }
 }
 
@@ -452,13 +455,14 @@ int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, cons
 }
 
 int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
-                             float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s, int batch, int64_t ldq, int64_t ldo) {
+                             float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s, int batch, int64_t ldq, int64_t ldo,
+                             const int32_t *out_perm) {
     // batch 1 and a cache that can hold a long context: a grid of 64-step splits (the kernel folds pairs of them below ATT_LONG tokens)
     const int ts_grid = decode_attn_ts_grid(t_max, batch);
     const int nsplit = (t_max + ts_grid - 1) / ts_grid;
     const float inv_base = -2.0f * logf(base) / (float)ATT_HD;
     hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(heads, nsplit, batch), dim3(256), 0, s, qkv, pos, kc, vc, out, ws, heads, t_max, inv_base,
-                       scale, (const float2 *)rope_table, dbg, (int)ldq, (int)ldo, ts_grid);
+                       scale, (const float2 *)rope_table, dbg, (int)ldq, (int)ldo, ts_grid, out_perm);
     return (int)hipGetLastError();
 }
 

@@ -123,6 +123,7 @@ struct StripeParams {
     float *y32;            // non-NULL: store the fp32 sums [M][NS][N] here instead of fp16 y (no bias): partial of a K-sharded layer (M <= 4)
     int M, K, N, G, NS, gq_shift, bits;
     uint32_t *progress;    // non-NULL: the decode kernel adds 1 here when it starts (debug hook gptq_set_progress_counter)
+    const int32_t *yperm;  // non-NULL: column n of y is stored at yperm[n] (the consumer's sorted order: decode kernel only)
 };
 int stripe_gq_shift(int K, int N, int bits, int groupsize);            // log2(groupsize / (4 KPW)), -1 one group, -2 ineligible
 size_t stripe_tab_offset(int K, int N, int bits, int nsets);
@@ -152,7 +153,7 @@ size_t decode_attn_ws_bytes(int heads, int t_max, int batch = 1);
 // batch rows: pos[batch], qkv rows ldq apart, out rows ldo apart, kc / vc [batch][t_max][heads * 128], ws of decode_attn_ws_bytes(heads, t_max, batch)
 int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
                              float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s, int batch = 1, int64_t ldq = 0,
-                             int64_t ldo = 0);
+                             int64_t ldo = 0, const int32_t *out_perm = nullptr);
 int rope_table_launch(float *table, int t_max, int head_dim, float base, hipStream_t s);
 
 }  // namespace gptq

@@ -124,7 +124,10 @@ _SIGNATURES = {
     'gptq_add_rows_f16': [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p],
     'gptq_decode_attn_batch_workspace_bytes': [c_int, c_int, c_int, c_int],
     'gptq_decode_attn_batch_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_int, c_int, c_int, c_int,
-                                   c_float, c_float, c_void_p, c_void_p],
+                                   c_float, c_float, c_void_p, c_void_p, c_void_p],
+    'gptq_layer_inverse_perm': [c_void_p, c_void_p],
+    'gptq_stripe_matvec_perm_out_f16': [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_float, c_void_p, c_void_p, c_void_p],
     'gptq_layer_decode_scratch_bytes': [c_void_p, c_int],
     'gptq_layer_decode_f16': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_size_t,
                               c_void_p, c_size_t, c_void_p],

@@ -210,6 +210,9 @@ class DecodeEngine:
         four rows, 16-row MFMA tiles above), attention through gptq_decode_attn_batch_f16, the LM head through gptq_dense_matmat_f16:
         still ONE hipGraph replay per step."""
         from . import _native
+        # act-order layers fed by one of the engine's own launches (o_proj <- attention, down_proj <- gate/up + SiLU) get their input written in THEIR
+        # sorted order by the producer (round 5) and run the trivial kernel; GPTQ_PRODUCER_PERM=0: the in-kernel gather of round 3 / 4 (A/B)
+        self.producer_perm = os.environ.get('GPTQ_PRODUCER_PERM', '1') != '0'
         self.batch = int(batch)
         if not 1 <= self.batch <= MAX_BATCH:
             raise NotImplementedError('DecodeEngine: batch must be 1 .. %d' % MAX_BATCH)
@@ -291,7 +294,7 @@ class DecodeEngine:
         released = qweight is None or qweight.shape[0] == 0
         return dict(qw=None if released else quant_linear._int32c(qweight), sc=None if released else scales,
                     qz=None if released else quant_linear._int32c(qzeros), gi=gi, bits=bits, gs=gs, K=K, N=N, bias=bias, srt=srt, st=st,
-                    perm=pl.perm16 if st is not None else None, _keep=pl)
+                    perm=pl.perm16 if st is not None else None, invperm=pl.invperm32 if st is not None else None, _keep=pl)
 
     def _pack_raw(self, qweight, scales, qzeros, g_idx, bits, groupsize, K, N, bias=None):
         from .layer import prepared
@@ -332,7 +335,8 @@ class DecodeEngine:
         return g, u
 
     # -- launches ------------------------------------------------------------------------------
-    def _gemv(self, x, w, y, s, residual=None):
+    def _gemv(self, x, w, y, s, residual=None, x_sorted=False):
+        """x_sorted: x was written in this layer's group-sorted order by its producer -- no gather (the image IS the sorted rows)"""
         if w['bias'] is not None and residual is not None:
             # one add slot per launch: the bias rides in the matvec, the residual is a second launch (gptq_layer_decode_f16 does both)
             if self.scratch is None:
@@ -341,7 +345,7 @@ class DecodeEngine:
         b = residual if residual is not None else w['bias']
         ptr = self.native.ptr
         if w['st'] is not None:       # stripe16: no K split, no workspace (act-order: x gathered through perm in the kernel)
-            quant_linear.stripe_matvec(x, w['st'], y, w['K'], w['N'], w['bits'], w['gs'], bias=b, perm=w['perm'])
+            quant_linear.stripe_matvec(x, w['st'], y, w['K'], w['N'], w['bits'], w['gs'], bias=b, perm=None if x_sorted else w['perm'])
             return
         if w['srt'] is not None:      # act-order layer: group-sorted copy + fused x gather
             qs, perm = w['srt']
@@ -383,16 +387,18 @@ class DecodeEngine:
         self._norm(x, nw, self.h, s)
         self._gemv(self.h, w, y, s)
 
-    def _norm_mlp(self, x, nw, g, u, c, s):
+    def _norm_mlp(self, x, nw, g, u, c, s, out_perm=None):
+        """out_perm: store column n of silu(gate) * up at out_perm[n] (down_proj's sorted order); only the stripe16 pair kernel does that"""
         ptr = self.native.ptr
         if g.get('st2') is not None:
             perm = g['perm2']
             if self.fuse_norm:
-                quant_linear.stripe_matvec(x, g['st2'], c, g['K'], g['N'], g['bits'], g['gs'], nsets=2, norm_weight=nw, eps=self.eps, perm=perm)
+                quant_linear.stripe_matvec(x, g['st2'], c, g['K'], g['N'], g['bits'], g['gs'], nsets=2, norm_weight=nw, eps=self.eps, perm=perm, out_perm=out_perm)
             else:
                 self._norm(x, nw, self.h, s)
-                quant_linear.stripe_matvec(self.h, g['st2'], c, g['K'], g['N'], g['bits'], g['gs'], nsets=2, perm=perm)
+                quant_linear.stripe_matvec(self.h, g['st2'], c, g['K'], g['N'], g['bits'], g['gs'], nsets=2, perm=perm, out_perm=out_perm)
             return
+        assert out_perm is None
         if g.get('pair_sorted') and self.fuse_norm:
             rc = self.lib.gptq_rmsnorm_sorted_f16(x.data_ptr(), nw.data_ptr(), self.eps, g['srt'][1].data_ptr(), g['srt'][0].data_ptr(),
                                                   g['sc'].data_ptr(), g['qz'].data_ptr(), u['srt'][0].data_ptr(), u['sc'].data_ptr(),
@@ -464,7 +470,7 @@ class DecodeEngine:
             rc = lib.gptq_decode_attn_batch_f16(self.qkvb.data_ptr(), self.qkvb.stride(0), self.pos.data_ptr(), self.kcb[li].data_ptr(),
                                                 self.vcb[li].data_ptr(), self.ab.data_ptr(), self.ab.stride(0), self.attn_ws.data_ptr(),
                                                 self.attn_ws.numel(), B, self.heads, self.head_dim, self.t_max, L['theta'], scale,
-                                                self.native.ptr(tab), s)
+                                                self.native.ptr(tab), None, s)
             self.native.check(rc, 'gptq_decode_attn_batch_f16')
             self._lin(L['o'], self.ab, self.x2, s, lws, residual=self.x)                       # x2 = x + o_proj(attn)
             if self.fuse_norm:
@@ -490,9 +496,18 @@ class DecodeEngine:
         scale = 1.0 / float(np.sqrt(self.head_dim))
         for li, L in enumerate(self.layers):
             self._norm_gemv(self.x, L['ln1'], L['qkv'], self.qkvb, s)       # qkv = qkv_proj(rmsnorm(x))
+            # producer-side permutation: o_proj / down_proj of an act-order checkpoint read x in their sorted order -- written that way by the attention /
+            # gate-up launch when those are the stripe16 kernels (else: the in-kernel gather)
+            o_inv = L['o'].get('invperm') if (self.producer_perm and self.fuse_attn and L['o']['st'] is not None) else None
+            d_inv = L['down'].get('invperm') if (self.producer_perm and L['gate'].get('st2') is not None and L['down']['st'] is not None) else None
             if self.fuse_attn:
                 tab = self._rope_table(L['theta'], s)
-                if tab is not None:
+                if o_inv is not None:
+                    rc = lib.gptq_decode_attn_batch_f16(self.qkvb.data_ptr(), self.qkvb.stride(0), self.pos.data_ptr(), self.kc[li].data_ptr(),
+                                                        self.vc[li].data_ptr(), self.ab.data_ptr(), self.ab.stride(0), self.attn_ws.data_ptr(),
+                                                        self.attn_ws.numel(), 1, self.heads, self.head_dim, self.t_max, L['theta'], scale,
+                                                        self.native.ptr(tab), o_inv.data_ptr(), s)
+                elif tab is not None:
                     rc = lib.gptq_decode_attn_fused_table_f16(self.qkvb.data_ptr(), self.pos.data_ptr(), self.kc[li].data_ptr(),
                                                               self.vc[li].data_ptr(), self.ab.data_ptr(), self.attn_ws.data_ptr(),
                                                               self.attn_ws.numel(), self.heads, self.head_dim, self.t_max, L['theta'], scale,
@@ -510,9 +525,9 @@ class DecodeEngine:
                                               self.ab.data_ptr(), self.attn_ws.data_ptr(), self.attn_ws.numel(), self.heads,
                                               self.head_dim, self.t_max, scale, s)
                 self.native.check(rc, 'gptq_decode_attn_f16')
-            self._gemv(self.ab, L['o'], self.x2, s, residual=self.x)        # x2 = x + o_proj(attn)
-            self._norm_mlp(self.x2, L['ln2'], L['gate'], L['up'], self.cb, s)
-            self._gemv(self.cb, L['down'], self.x, s, residual=self.x2)     # x = x2 + down(silu(gate) * up)
+            self._gemv(self.ab, L['o'], self.x2, s, residual=self.x, x_sorted=o_inv is not None)        # x2 = x + o_proj(attn)
+            self._norm_mlp(self.x2, L['ln2'], L['gate'], L['up'], self.cb, s, out_perm=d_inv)
+            self._gemv(self.cb, L['down'], self.x, s, residual=self.x2, x_sorted=d_inv is not None)     # x = x2 + down(silu(gate) * up)
         self._lm_head(s)
         self.pos.add_(1)
 

@@ -85,6 +85,12 @@ class PreparedLayer:
         if p16.value and self.image is not None:
             off = p16.value - self.image.data_ptr()
             self.perm16 = self.image[off:off + 2 * K].view(torch.int16)
+        # regular act-order layer: original k -> sorted position (what a PRODUCER of this layer's input stores through, so that the layer needs no gather)
+        self.invperm32 = None
+        inv = ctypes.c_void_p()
+        if lib.gptq_layer_inverse_perm(h, ctypes.byref(inv)) == 0 and inv.value and self.image is not None:
+            off = inv.value - self.image.data_ptr()
+            self.invperm32 = self.image[off:off + 4 * K].view(torch.int32)
 
     def __del__(self):
         h, self.handle = getattr(self, 'handle', None), None

@@ -155,11 +155,21 @@ def perm_u16(perm):
     return p16
 
 
-def stripe_matvec(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, norm_weight=None, eps=0.0, perm=None, strict=True):
+def stripe_matvec(x, st, out, K, N, bits, groupsize, nsets=1, bias=None, norm_weight=None, eps=0.0, perm=None, strict=True, out_perm=None):
     """out[M, N] = x[M, K] (1 <= M <= 4) through a stripe16 image (gptq_stripe_matvec_f16) on the current stream.
     strict=False: return False instead of raising when the kernel does not serve the call (GPTQ_E_VARIANT: e.g. four rows of a
-    very long K do not fit in LDS) so that the caller can take another kernel family."""
+    very long K do not fit in LDS) so that the caller can take another kernel family.
+    out_perm (int32 [N], round 5): column n of the result is stored at out_perm[n] -- the consumer's sorted order (an act-order layer)."""
     M = x.shape[0]
+    if out_perm is not None:
+        rc = _native.lib().gptq_stripe_matvec_perm_out_f16(x.data_ptr(), x.stride(0) if M > 1 else K, st.data_ptr(), st.numel(), _native.ptr(bias),
+                                                           out.data_ptr(), out.stride(0) if M > 1 else N, M, K, N, bits, groupsize, nsets,
+                                                           _native.ptr(norm_weight), float(eps), _native.ptr(perm_u16(perm)), out_perm.data_ptr(),
+                                                           _native.stream_ptr(x.device))
+        if rc == -6 and not strict:
+            return False
+        _native.check(rc, 'gptq_stripe_matvec_perm_out_f16')
+        return True
     rc = _native.lib().gptq_stripe_matvec_f16(x.data_ptr(), x.stride(0) if M > 1 else K, st.data_ptr(), st.numel(), _native.ptr(bias),
                                               out.data_ptr(), out.stride(0) if M > 1 else N, M, K, N, bits, groupsize, nsets,
                                               _native.ptr(norm_weight), float(eps), _native.ptr(perm_u16(perm)), _native.stream_ptr(x.device))

@@ -464,7 +464,8 @@ int gptq_layer_route_for(const gptq_layer_t *layer, int M);
  *     residual into their epilogue, the norm then is one launch into `scratch` (gptq_layer_decode_scratch_bytes).  The residual is
  *     added to the ROUNDED product (fp16(fp16(acc) + r)), as the module chain does it (one fp16 tensor add).  y must not alias x.
  * gptq_decode_attn_batch_f16  the fused RoPE + KV append + single-query attention launch (gptq_decode_attn_fused_table_f16) for B rows:
- *     positions[b] (negative = idle row), qkv row b at qkv + b ldq, out row b at out + b ldo, cache slice b at k_cache + b t_max heads 128.
+ *     positions[b] (negative = idle row), qkv row b at qkv + b ldq, out row b at out + b ldo, cache slice b at k_cache + b t_max heads 128;
+ *     out_perm != NULL: element k of an output row is stored at out_perm[k] (see "Producer-side permutation" below).
  * gptq_dense_matmat_f16       y[M][N] = rmsnorm(x)[M][K] . W[N][K]^T, M <= 16, ONE pass over the dense fp16 weight (the LM head).
  * gptq_add_rows_f16           y = fp16(y + r), row by row.
  */
@@ -475,7 +476,16 @@ int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx,
 size_t gptq_decode_attn_batch_workspace_bytes(int batch, int heads, int head_dim, int t_max);
 int gptq_decode_attn_batch_f16(const void *qkv, int64_t ldq, const int64_t *positions, void *k_cache, void *v_cache, void *out, int64_t ldo,
                                void *workspace, size_t workspace_bytes, int batch, int heads, int head_dim, int t_max, float base, float scale,
-                               const float *rope_table, gptq_stream_t stream);
+                               const float *rope_table, const int32_t *out_perm, gptq_stream_t stream);
+/* Producer-side permutation (round 5): the reference gathers g_idx / scales / zeros per k row in its kernel (quant_linear.py:114-118); here a regular
+ * act-order layer runs on the image of its group-sorted rows, which needs x in sorted order.  At M = 1 the decode kernel gathers x itself; where the
+ * PRODUCER of x is one of our launches it can write x sorted instead: out_perm above (attention -> o_proj) and gptq_stripe_matvec_perm_out_f16
+ * (gate/up + SiLU -> down_proj) store element n at perm[n], perm = gptq_layer_inverse_perm() of the consuming layer, which then runs the trivial
+ * kernel (perm = NULL).  NULL = natural order. */
+int gptq_layer_inverse_perm(const gptq_layer_t *layer, const int32_t **invperm32);
+int gptq_stripe_matvec_perm_out_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
+                                    int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
+                                    const int32_t *y_perm, gptq_stream_t stream);
 int gptq_dense_matmat_f16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const void *bias, void *y, int64_t ldy, int M, int N,
                           int K, const void *norm_weight, float norm_eps, gptq_stream_t stream);
 int gptq_add_rows_f16(void *y, int64_t ldy, const void *r, int64_t ldr, int M, int N, gptq_stream_t stream);

@@ -138,7 +138,7 @@ def test_decode_attention_batch_rows_equal_single_row_launches(B, pos):
     out = torch.full((B, H), float('nan'), dtype=torch.float16, device=DEV)
     ws = torch.zeros(lib.gptq_decode_attn_batch_workspace_bytes(B, heads, hd, t_max), dtype=torch.uint8, device=DEV)
     rc = lib.gptq_decode_attn_batch_f16(qkv.data_ptr(), 3 * H, p.data_ptr(), kb.data_ptr(), vb.data_ptr(), out.data_ptr(), H, ws.data_ptr(), ws.numel(), B, heads,
-                                        hd, t_max, 10000.0, scale, tab.data_ptr(), s)
+                                        hd, t_max, 10000.0, scale, tab.data_ptr(), None, s)
     _native.check(rc, 'gptq_decode_attn_batch_f16')
     # one launch per row
     ws1 = torch.zeros(lib.gptq_decode_attn_workspace_bytes(heads, hd, t_max), dtype=torch.uint8, device=DEV)

@@ -326,6 +326,27 @@ def test_decode_engine_act_order_checkpoint(bits):
     within('engine_act_order', np.abs(got - expect).max() / np.abs(expect).max(), ENGINE_TOL)
 
 
+@pytest.mark.parametrize('bits', [4, 3])
+def test_decode_engine_act_order_producer_side_permutation(bits):
+    """round 5: o_proj and down_proj of an --act-order checkpoint read x in their group-sorted order.  The engine's own launches
+    produce those inputs -- attention and the gate/up + SiLU matvec -- and now store them THROUGH the consumer's inverse permutation, so the
+    consumer runs the trivial kernel instead of gathering x per launch.  Same values in the same places: the logits are BIT-identical to the
+    engine that gathers in the consumer (GPTQ_PRODUCER_PERM=0), eager launches and hipGraph replay."""
+    q = D.build_random_llama(DEV, seed=4 if bits == 4 else 5, bits=bits, act_order=True, **HD128)
+    ids = torch.randint(0, HD128['vocab_size'], (1, 8), device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+    outs = {}
+    for mode in (True, False):
+        for graph in (False, True):
+            eng = D.DecodeEngine(q, t_max=64)
+            eng.producer_perm = mode
+            assert all(L['o']['invperm'] is not None and L['down']['invperm'] is not None for L in eng.layers)
+            if graph:
+                eng.capture()
+            outs[(mode, graph)] = torch.stack([eng.decode(ids[0, i]).clone() for i in range(ids.shape[1])])
+    assert torch.equal(outs[(True, False)], outs[(False, False)]) and torch.equal(outs[(True, True)], outs[(False, True)])
+    assert torch.equal(outs[(True, False)], outs[(True, True)])
+
+
 # ---------------------------------------------------------------------------------------
 # GPTQ solver on the GPU (gptq-for-llama_amd/gptq.py + csrc/gptq_solver.hip) vs the reference's own results
 # (tests/golden/gptq_*.npz) and vs the CPU restatement on a larger layer

@@ -313,9 +313,11 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == rec(32, 32 if os.environ.get('GPTQ_ATTN_LONG_SPLITS', '0') != '0' else 16)   # (64-step grid: an A/B knob, off)
     assert lib.gptq_decode_attn_workspace_bytes(32, 128, 1024) == rec(32, 8)
     assert lib.gptq_decode_attn_batch_workspace_bytes(4, 32, 64, 2048) == 0
-    assert lib.gptq_decode_attn_batch_f16(one, 3 * 256, one, one, one, one, 256, one, 16, 2, 2, 128, 64, 10000.0, 1.0, None, None) == -5    # workspace too small
-    assert lib.gptq_decode_attn_batch_f16(one, 256, one, one, one, one, 256, one, 1 << 20, 2, 2, 128, 64, 10000.0, 1.0, None, None) == -2   # ldq < 3 * hidden
-    assert lib.gptq_decode_attn_batch_f16(one, 3 * 256, None, one, one, one, 256, one, 1 << 20, 2, 2, 128, 64, 10000.0, 1.0, None, None) == -4
+    assert lib.gptq_decode_attn_batch_f16(one, 3 * 256, one, one, one, one, 256, one, 16, 2, 2, 128, 64, 10000.0, 1.0, None, None, None) == -5    # workspace too small
+    assert lib.gptq_decode_attn_batch_f16(one, 256, one, one, one, one, 256, one, 1 << 20, 2, 2, 128, 64, 10000.0, 1.0, None, None, None) == -2   # ldq < 3 * hidden
+    assert lib.gptq_decode_attn_batch_f16(one, 3 * 256, None, one, one, one, 256, one, 1 << 20, 2, 2, 128, 64, 10000.0, 1.0, None, None, None) == -4
+    assert lib.gptq_layer_inverse_perm(None, None) == -4
+    assert lib.gptq_stripe_matvec_perm_out_f16(one, 256, one, nb, None, None, 64, 1, 256, 64, 4, 128, 1, None, 0.0, None, one, None) == -4    # NULL y
 
     # small-batch MFMA kernel on the same image (csrc/stripe_mm.inc): scratch workspace required, up to 256 rows
     def mm(x=one, st=one, nbytes=nb, y=one, M=16, bits=4, nsets=1, ws=256, wsb=1 << 20, ldx=256, ldy=64, gs=128):

@@ -765,6 +765,7 @@ int gptq_prefill_route_for(int M, int K, int N, int nsets, int trans) {
 }
 int gptq_set_library_enabled(int on) { return dense_gemm_set_enabled(on); }
 int gptq_set_gemm8_mfma(int shape) { return gemm8_set_mfma(shape); }
+int gptq_set_gemm8_tile(int rows) { return gemm8_set_tile(rows); }
 int gptq_prefill_plan_count(void) { return dense_gemm_plan_count(); }
 
 int gptq_set_prefill_route(int route) {

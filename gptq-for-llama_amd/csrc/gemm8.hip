@@ -41,7 +41,7 @@ namespace gptq {
 
 namespace {
 
-constexpr int TM = 256, TK = 64;   // (n tile: 256 columns, 128 in PAIR mode)
+constexpr int TK = 64;   // (m tile: 4 XH rows = 256, or 192 in the round-5 instance; n tile: 256 columns, 128 in PAIR mode)
 constexpr int UNIT_BYTES = 128 * 128;          // 128 rows x 64 k x 2 B
 constexpr int BUF_BYTES = 4 * UNIT_BYTES;      // X0 X1 W0 W1
 constexpr int OFF_X0 = 0, OFF_X1 = UNIT_BYTES, OFF_W0 = 2 * UNIT_BYTES, OFF_W1 = 3 * UNIT_BYTES;
@@ -69,8 +69,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // MF32: v_mfma_f32_32x32x16_f16 instead of 16x16x32 (8 instead of 16 MFMAs per phase at the same LDS traffic; the larger shape reaches
 // the full 1024 flop / cycle / SIMD, the smaller one ~85-94 % of it) -- same units, phases and waits, other fragment maps.
-template <bool PAIR, bool MF32>
+//
+// XH (round 5): rows of an X unit per wave row -- 64 gives the 256-row tile above; 48 gives a 192-row tile (wave tile 96 x 64,
+// 12 MFMAs per phase instead of 16, 96 accumulators) for the row counts where 256-row tiles leave the last round of workgroups mostly empty:
+// 3072 x 4096 is 12 x 16 = 192 tiles of 256 rows on 256 CUs (a quarter of the chip idle) but 16 x 16 = 256 tiles of 192 rows, one full round of
+// 3/4 the work; 3072 x 12288 is 576 tiles = 2.25 rounds (three are paid) against 768 = three rounds of 3/4 the work.  Same units, phases, waits
+// and vmcnt bookkeeping: an X unit is 96 rows instead of 128, so the DMA instructions of waves 6 and 7 repeat those of waves 0 and 1 (same
+// bytes to the same LDS address -- benign, and every wave keeps the same number of loads in flight).  The K order of every accumulator is
+// unchanged: results are bit-identical to the 256-row tile.
+template <bool PAIR, bool MF32, int XH>
 __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
+    static_assert(XH == 64 || (XH == 48 && !MF32), "X unit half: 64 rows, or 48 (16-row fragments only)");
+    constexpr int TM = 4 * XH, XU = 2 * XH;   // rows of the workgroup tile; rows of an X unit (both wave rows)
     extern __shared__ __attribute__((aligned(16))) char smem[];   // ALL of the kernel's LDS (one object: see the guide's .s traps)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,15 +97,18 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
     // ---- LDS-DMA sources.  Instruction q (0, 1) of a unit covers unit rows 16 wave + 8 q + lane / 8; lane lands at chunk
     // position lane % 8 and therefore FETCHES chunk (lane % 8) ^ ((row >> 1) & 7) of that row.
     const half_t *sx[2][2], *sw[2][2];   // [unit half][q]
+    int xdst[2];                         // LDS row of this wave's X instruction q (XH = 48: waves 6, 7 repeat waves 0, 1)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int u = 16 * wave + 8 * q + (lane >> 3);
         const int ch = (lane & 7) ^ ((u >> 1) & 7);
+        xdst[q] = (16 * wave + 8 * q) % XU;
+        const int ux = u % XU, chx = (lane & 7) ^ ((ux >> 1) & 7);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            // X unit h, unit row u: wave row u / 64, local row u % 64 -> tile row (u / 64) * 128 + h * 64 + u % 64
-            const int mrow = min(m0 + (u >> 6) * 128 + h * 64 + (u & 63), M - 1);
-            sx[h][q] = p.x + (size_t)mrow * p.ldx + ch * 8;
+            // X unit h, unit row ux: wave row ux / XH, local row ux % XH -> tile row (ux / XH) * 2 XH + h * XH + ux % XH
+            const int mrow = min(m0 + (ux / XH) * XU + h * XH + (ux % XH), M - 1);
+            sx[h][q] = p.x + (size_t)mrow * p.ldx + chx * 8;
             // W unit h, unit row u: wave column u / 32, local column u % 32
             int nrow;
             if constexpr (PAIR) nrow = h * N + min(n0 + (u >> 5) * 32 + (u & 31), N - 1);             // gate | up rows of the stacked matrix
@@ -104,13 +117,15 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
         }
     }
     const int nt = K / TK;
-    auto stage = [&](const half_t *(&src)[2], int buf_unit_off, int t) {
+    auto stage_rows = [&](const half_t *(&src)[2], int buf_unit_off, int t, int r0, int r1) {
         const int k0 = min(t, nt - 1) * TK;   // past the end: re-fetch the last tile (keeps the vmcnt bookkeeping uniform)
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[q] + k0),
-                                             (__attribute__((address_space(3))) void *)(smem + buf_unit_off + (16 * wave + 8 * q) * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[0] + k0),
+                                         (__attribute__((address_space(3))) void *)(smem + buf_unit_off + r0 * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[1] + k0),
+                                         (__attribute__((address_space(3))) void *)(smem + buf_unit_off + r1 * 128), 16, 0, 0);
     };
+    auto stage = [&](const half_t *(&src)[2], int buf_unit_off, int t) { stage_rows(src, buf_unit_off, t, 16 * wave, 16 * wave + 8); };   // W units
+    auto stage_x = [&](const half_t *(&src)[2], int buf_unit_off, int t) { stage_rows(src, buf_unit_off, t, xdst[0], xdst[1]); };
 
     // ---- fragment reads.  A 16x16x32 operand: lane l holds row l % 16, k = 8 (l / 16) .. +7 of a 32-k step; both operands
     // come out of LDS the same way.  Chunk of k-step ks: (4 ks + l / 16) ^ swz, swz = ((l % 16) >> 1) & 7 (unit rows start at
@@ -122,8 +137,8 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
     const int swz = (frow >> 1) & 7;
     const int lb0 = frow * 128 + ((fkb ^ swz) << 4);
     const int lb1 = lb0 ^ 64;
-    const int xbase = wr * 64 * 128, wbase = wc * 32 * 128;
-    constexpr int XF = MF32 ? 2 : 4, WF = MF32 ? 1 : 2, KS = MF32 ? 4 : 2;   // m reps of an X unit, n reps of a W unit, k steps of a tile
+    const int xbase = wr * XH * 128, wbase = wc * 32 * 128;
+    constexpr int XF = XH / RL, WF = MF32 ? 1 : 2, KS = MF32 ? 4 : 2;   // m reps of an X unit, n reps of a W unit, k steps of a tile
     half8_t xf[XF][KS], wf[2][WF][KS];   // X fragments of the current m half [ii][ks]; W fragments [nh][jj][ks]
     auto read_x = [&](int buf, int mh) {
         const char *b = smem + buf * BUF_BYTES + (mh ? OFF_X1 : OFF_X0) + xbase;
@@ -141,7 +156,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
     };
     // accumulators: 16x16: [8 m reps][4 n reps] x 4 floats; 32x32: [4 m reps][2 n reps] x 16 floats -- 128 registers either way
     typedef typename std::conditional<MF32, float16_t, f32x4>::type acc_t;
-    constexpr int AM = MF32 ? 4 : 8, AN = MF32 ? 2 : 4;
+    constexpr int AM = 2 * XF, AN = MF32 ? 2 : 4;
     acc_t acc[AM][AN];   // n rep j = WF nh + jj
 #pragma unroll
     for (int i = 0; i < AM; i++)
@@ -163,11 +178,11 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
     };
 
     // ---- prologue: tile 0 completely, X0 / W0 of tile 1; issue order per tile is X0, W0, W1, X1 everywhere
-    stage(sx[0], 0 * BUF_BYTES + OFF_X0, 0);
+    stage_x(sx[0], 0 * BUF_BYTES + OFF_X0, 0);
     stage(sw[0], 0 * BUF_BYTES + OFF_W0, 0);
     stage(sw[1], 0 * BUF_BYTES + OFF_W1, 0);
-    stage(sx[1], 0 * BUF_BYTES + OFF_X1, 0);
-    stage(sx[0], 1 * BUF_BYTES + OFF_X0, 1);
+    stage_x(sx[1], 0 * BUF_BYTES + OFF_X1, 0);
+    stage_x(sx[0], 1 * BUF_BYTES + OFF_X0, 1);
     stage(sw[0], 1 * BUF_BYTES + OFF_W0, 1);
     G8_VMCNT8();          // X0(0), W0(0) of this wave have landed
     G8_BAR();
@@ -189,7 +204,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
         G8_BAR();
         // R2
         read_w(b, 1);
-        stage(sx[1], oth + OFF_X1, t + 1);
+        stage_x(sx[1], oth + OFF_X1, t + 1);
         G8_VMCNT8();      // X1(t) landed
         G8_BAR();
         G8_LGKM0();
@@ -198,7 +213,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
         G8_BAR();
         // R3
         read_x(b, 1);
-        stage(sx[0], cur + OFF_X0, t + 2);   // X0(t) was last read two phases ago
+        stage_x(sx[0], cur + OFF_X0, t + 2);   // X0(t) was last read two phases ago
         G8_BAR();
         G8_LGKM0();
         __builtin_amdgcn_sched_barrier(0);
@@ -222,7 +237,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
     // 32x32: per (i, j) and register group rg = reg / 4: m = m0 + 128 wr + 32 i + l % 32, n starting at 8 rg + 4 (l / 32).
     // Either way: one 8-byte store per four accumulators.
     constexpr int NG = MF32 ? 4 : 1;                  // groups of four consecutive n per accumulator tile
-    const int mloc = wr * 128 + frow;
+    const int mloc = wr * XU + frow;
     const int n4 = MF32 ? (lane >> 5) * 4 : (lane >> 4) * 4;
     auto acc4 = [&](const acc_t &a, int rg, int r) -> float {
         if constexpr (MF32) return a[4 * rg + r];
@@ -268,9 +283,9 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
     }
 }
 
-template <bool PAIR, bool MF32>
+template <bool PAIR, bool MF32, int XH>
 int gemm8_launch(const Gemm8Params &p, hipStream_t s) {
-    auto kern = gemm8_kernel<PAIR, MF32>;
+    auto kern = gemm8_kernel<PAIR, MF32, XH>;
     constexpr int lds = 2 * BUF_BYTES;   // 131 072 B
     static LdsOptIn opt_in;   // per instantiation; per device inside
     if (int rc = opt_in.ensure((const void *)kern, lds)) return rc;
@@ -280,6 +295,21 @@ int gemm8_launch(const Gemm8Params &p, hipStream_t s) {
 }
 
 std::atomic<int> g_gemm8_mfma{16};   // MFMA shape of the tile GEMM: 16 = 16x16x32, 32 = 32x32x16 (gemm8_set_mfma: tests / A-B runs)
+std::atomic<int> g_gemm8_tile{0};    // rows of the workgroup tile: 0 = chosen per launch (gemm8_tile_rows), 192, 256 (gemm8_set_tile: tests / A-B runs)
+
+// Rows of the workgroup tile for an [M, ntn n-tiles] product: the tile whose rounds of 256 workgroups cost less.  A workgroup's time is
+// proportional to its rows; the 192-row tile pays G8_EFF192 per flop (12 MFMAs per phase against the same barriers, W fragment reads and
+// DMA instructions as 16: measured, tools/bench_gemm8.py TILE=192/256, profiles/r5e_gemm8_tile/).
+constexpr double G8_EFF192 = 0.93;
+int gemm8_tile_rows(int M, int ntn) {
+    const int forced = g_gemm8_tile.load();
+    if (forced) return forced;
+    auto cost = [&](int rows, double eff) {
+        const long tiles = (long)((M + rows - 1) / rows) * ntn;
+        return (double)((tiles + 255) / 256) * rows / eff;
+    };
+    return cost(192, G8_EFF192) < cost(256, 1.0) ? 192 : 256;
+}
 
 }  // namespace
 
@@ -294,12 +324,16 @@ int gemm8_dense_f16(const half_t *x, int64_t ldx, const half_t *wt, int64_t ldw,
     p.x = x; p.wt = wt; p.bias = bias; p.c = c;
     p.ldx = ldx; p.ldw = ldw; p.ldc = ldc;
     p.M = M; p.K = K; p.N = N;
-    p.ntm = (M + TM - 1) / TM;
     p.ntn = (N + (pair ? 128 : 256) - 1) / (pair ? 128 : 256);
-    if (g_gemm8_mfma.load() == 32) return pair ? gemm8_launch<true, true>(p, s) : gemm8_launch<false, true>(p, s);
-    return pair ? gemm8_launch<true, false>(p, s) : gemm8_launch<false, false>(p, s);
+    const bool mf32 = g_gemm8_mfma.load() == 32;
+    const int rows = mf32 ? 256 : gemm8_tile_rows(M, p.ntn);
+    p.ntm = (M + rows - 1) / rows;
+    if (mf32) return pair ? gemm8_launch<true, true, 64>(p, s) : gemm8_launch<false, true, 64>(p, s);
+    if (rows == 192) return pair ? gemm8_launch<true, false, 48>(p, s) : gemm8_launch<false, false, 48>(p, s);
+    return pair ? gemm8_launch<true, false, 64>(p, s) : gemm8_launch<false, false, 64>(p, s);
 }
 
 int gemm8_set_mfma(int shape) { return (shape == 16 || shape == 32) ? g_gemm8_mfma.exchange(shape) : GPTQ_E_VARIANT; }
+int gemm8_set_tile(int rows) { return (rows == 0 || rows == 192 || rows == 256) ? g_gemm8_tile.exchange(rows) : GPTQ_E_VARIANT; }
 
 }  // namespace gptq

@@ -89,6 +89,7 @@ int dequant_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, cons
 int dequant_t_launch(const uint32_t *qw, const half_t *sc, const int32_t *qz, const int32_t *gi, int K, int N, int G, int groupsize,
                      int bits, half_t *out, int64_t ldo, hipStream_t s);   // the same weight as [N][K] (k contiguous)
 // gemm8.hip: the hand-written prefill GEMM: c = x . wt^T (+ bias) / silu(x . wt_gate^T) * (x . wt_up^T); GPTQ_E_VARIANT when not served
+int gemm8_set_tile(int rows);   // 0 (per launch), 192, 256; returns the previous value
 int gemm8_set_mfma(int shape);   // 16 (16x16x32) or 32 (32x32x16); returns the previous value
 int gemm8_dense_f16(const half_t *x, int64_t ldx, const half_t *wt, int64_t ldw, const half_t *bias, half_t *c, int64_t ldc, int M, int K, int N,
                     bool pair, hipStream_t s);

@@ -35,6 +35,7 @@ _SIGNATURES = {
     'gptq_prefill_route_for': [c_int, c_int, c_int, c_int, c_int],
     'gptq_set_library_enabled': [c_int],
     'gptq_set_gemm8_mfma': [c_int],
+    'gptq_set_gemm8_tile': [c_int],
     'gptq_prefill_plan_count': [],
     'gptq_matmul248_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p],

@@ -95,6 +95,9 @@ int gptq_prefill_route_for(int M, int K, int N, int nsets, int trans);
 int gptq_set_library_enabled(int on);
 /* MFMA shape of the tile GEMM (tests / A-B runs): 16 = v_mfma_f32_16x16x32_f16, 32 = v_mfma_f32_32x32x16_f16; returns the previous value */
 int gptq_set_gemm8_mfma(int shape);
+/* Rows of the tile GEMM's workgroup tile: 0 = chosen per launch (the tile whose rounds of 256 workgroups cost less), 192, 256.  Returns the
+ * previous value, GPTQ_E_VARIANT for anything else.  Results do not depend on it (same K order per accumulator).  Test / A-B hook. */
+int gptq_set_gemm8_tile(int rows);
 int gptq_prefill_plan_count(void);
 /* Development aid: when non-NULL, the decode kernels write per-wave s_memtime checkpoints
  * ([block][wave][8] uint64) into this device buffer.  Returns the previous pointer. */

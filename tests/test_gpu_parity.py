@@ -275,6 +275,42 @@ def test_fused_mlp_prefill_routes(bits, gs, act, M, route, monkeypatch):
     QL._apply_prefill_route()
 
 
+@pytest.mark.parametrize('bits,gs,act,M,K,N', [(4, 128, False, 3072, 1024, 4096), (4, 128, True, 2100, 1024, 768), (8, 128, False, 577, 512, 4096),
+                                               (4, 128, False, 191, 512, 320), (4, 128, False, 193, 512, 320), (3, -1, False, 700, 512, 320)])
+def test_gemm8_tile_rows_same_bits(bits, gs, act, M, K, N):
+    """Round 5: the tile GEMM's 192-row workgroup tile (csrc/gemm8.hip XH = 48) against the 256-row one -- every accumulator
+    sums the same products in the same K order, so the outputs are the SAME BITS (plain with bias, and the gate/up pair with SiLU on the fp32
+    sums), and the 192-row result meets the oracle on sampled rows.  Row counts around the tile edges (191, 193: one / two tiles; 577: a ragged
+    fourth tile; 3072 = 16 x 192 = 12 x 256); the per-launch choice (gptq_set_gemm8_tile(0)) is one of the two."""
+    lib = _native.lib()
+    L = make_random_layer(bits, gs, K, N, act_order=act, seed=M + bits)
+    U = make_random_layer(bits, gs, K, N, act_order=act, seed=M + bits + 1)
+    if act:
+        U['g_idx'] = L['g_idx']
+    rng = np.random.default_rng(M)
+    x = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float16) if bits == 8 else None
+    gate = tuple(dev(L[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(U[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    prev_rows = lib.gptq_set_stripe_gemm_max_rows(0)          # the dense route for every row count above 128
+    prev_tile = lib.gptq_set_gemm8_tile(0)
+    try:
+        assert lib.gptq_set_gemm8_tile(100) == -6 and lib.gptq_set_gemm8_tile(0) == 0
+        got = {}
+        for tile in (192, 256, 0):
+            lib.gptq_set_gemm8_tile(tile)
+            got[tile] = (hip_forward(x, L, bias=bias), quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs if gs != -1 else K).cpu().numpy())
+        for j in (0, 1):
+            assert np.array_equal(got[192][j], got[256][j]) and np.array_equal(got[0][j], got[256][j])
+        rows = np.unique(np.concatenate([np.arange(0, M, max(M // 24, 1)), [M - 1, 47, 48, 95, 96, 190]]))
+        assert rel_err(got[192][0][rows], oracle_forward(x[rows], L, bias=bias)) < TOL
+        ref = oracle.fused_mlp(x[rows], (L['qweight'], L['scales'], L['qzeros'], L['g_idx']), (U['qweight'], U['scales'], U['qzeros'], U['g_idx']), bits)
+        assert rel_err(got[192][1][rows], ref) < TOL
+    finally:
+        lib.gptq_set_gemm8_tile(prev_tile)
+        lib.gptq_set_stripe_gemm_max_rows(prev_rows)
+
+
 def test_prefill_falls_back_to_the_own_kernels_without_the_library(monkeypatch):
     """GPTQ_E_LIBRARY (hipBLASLt not loadable) from the prefill entries: the library-free kernels of the C ABI answer -- forward,
     fused MLP (inside gptq_layer_forward) and backward (one Python warning), same results."""

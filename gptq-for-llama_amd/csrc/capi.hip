@@ -989,10 +989,10 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     if (gemm_rows) {   // 2-D tiles, weights kept packed (stripe_gemm_kernel)
         int rc;
         switch (bits) {
-            case 2: rc = stripe_gemm_dispatch_b2(p, (hipStream_t)stream); break;
-            case 3: rc = stripe_gemm_dispatch_b3(p, (hipStream_t)stream); break;
-            case 4: rc = stripe_gemm_dispatch_b4(p, (hipStream_t)stream); break;
-            default: rc = stripe_gemm_dispatch_b8(p, (hipStream_t)stream); break;
+            case 2: rc = stripe_gemm_dispatch_b2(p, mm_ws, mm_ws_bytes, (hipStream_t)stream); break;
+            case 3: rc = stripe_gemm_dispatch_b3(p, mm_ws, mm_ws_bytes, (hipStream_t)stream); break;
+            case 4: rc = stripe_gemm_dispatch_b4(p, mm_ws, mm_ws_bytes, (hipStream_t)stream); break;
+            default: rc = stripe_gemm_dispatch_b8(p, mm_ws, mm_ws_bytes, (hipStream_t)stream); break;
         }
         if (rc != GPTQ_E_VARIANT) return rc;
     }
@@ -1289,6 +1289,21 @@ static int decode_rows_max(int N, int nsets) {
     return nsets == 2 ? pair : wide;
 }
 
+// Round 5: 129 .. gptq_set_stripe_gemm_max_rows() rows -- the fused tile GEMM on the image, or dequantise + the tile GEMM of gemm8.hip?  Once gemm8 gave
+// every XCD the same number of tiles (gemm8.hip, round 5) the dense route became the faster OWN kernel where the image route's 128 x 128 tiles no
+// longer fit the chip at once (two workgroups per CU = 512 tiles; beyond that its time steps up: 4096 x 12288 at 640 / 768 rows 84.6 / 118.9 us
+// against 103.7 / 105.9) AND the product is long enough to pay for the dequantise pass (2.5 bytes per weight against 2 M flops: the ratio depends on
+// M alone).  Measured on the four LLaMA-7B shapes, 192 .. 2560 rows (profiles/r5e_gemm8_tile/image_vs_dense_192_2560_rows.txt): single sets -- dense
+// wins from 768 rows on 4096 x 12288 / 4096 x 11008 (0.84-0.96 of the image route's time; tie at 2048), never on the N = 4096 shapes (at most 512
+// tiles up to 2048 rows); gate | up pair (A fragments shared by both sets: the image kernel's best case) -- dense wins from 1280 rows (0.85-0.96).
+// Act-order layers keep the image route (their dense route rebuilds the checkpoint order first; not measured).
+static bool image_gemm_wanted(int M, int K, int N, int nsets, int kind) {
+    if (M > g_stripe_gemm_max_rows.load()) return false;
+    if (kind != 0 || K % 128 != 0 || !gemm8_wanted(M, N, nsets == 2)) return true;   // the alternative would not be the tile GEMM
+    const long tiles = (long)((M + 127) / 128) * (((long)N * nsets + 127) / 128);
+    return tiles <= 512 || M <= (nsets == 2 ? 1152 : 640);
+}
+
 /* persistent workspace every forward takes: [split-K words, zero on first use and left zero][scratch of the 16-row MFMA tiles] */
 size_t gptq_layer_workspace_bytes(void) { return WS_BYTES + STRIPE_MM_WS_BYTES; }
 
@@ -1334,12 +1349,11 @@ int gptq_layer_route_for_shape(int M, int K, int N, int bits, int groupsize, int
     const int gq = stripe_gq_shift(K, N, bits, groupsize);
     const bool image = has_image && gq != -2 && kind != 2;
     const int rows_max = decode_rows_max(N, nsets);
-    const int gemm_max = g_stripe_gemm_max_rows.load();
     if (image && (kind == 0 || M == 1) && M <= rows_max && (M <= 4 || K <= 9216 || (K <= 12288 && nsets == 1))) return GPTQ_ROUTE_STRIPE_DECODE;
     if (image && M > 1) {
         if (M <= rows_max && kind == 1 && (M <= 4 || K <= 9216 || (K <= 12288 && nsets == 1))) return GPTQ_ROUTE_STRIPE_DECODE;       // after one gather of x
         if (M <= LAYER_STRIPE_MM_MAX_M) return GPTQ_ROUTE_STRIPE_TILES;
-        if (M <= gemm_max && bits != 2 && (gq == -1 || gq >= 2)) return GPTQ_ROUTE_STRIPE_GEMM;       // groups of at least a row block
+        if (image_gemm_wanted(M, K, N, nsets, kind) && bits != 2 && (gq == -1 || gq >= 2)) return GPTQ_ROUTE_STRIPE_GEMM;       // groups of at least a row block
     }
     if (M >= LAYER_PREFILL_MIN_M)
         return (gemm8_wanted(M, N, nsets == 2) && K % 128 == 0) ? GPTQ_ROUTE_DENSE_TILE_GEMM : GPTQ_ROUTE_DENSE_LIBRARY;
@@ -1369,7 +1383,15 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
             const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream);
             if (rc != GPTQ_E_VARIANT) return rc;
         }
-        if (M > 4 && M <= std::max(LAYER_STRIPE_MM_MAX_M, g_stripe_gemm_max_rows.load())) {   // ... 128 rows: 16-row tiles; above: the fused tile GEMM
+        // ... 128 rows: 16-row tiles; above: the fused tile GEMM, unless the dense route is the faster own kernel for this batch (image_gemm_wanted)
+        // AND the caller brought the scratch it needs (gptq_layer_scratch_bytes says so; without it the batch stays on the image)
+        bool on_image = M <= LAYER_STRIPE_MM_MAX_M || M <= g_stripe_gemm_max_rows.load();
+        if (on_image && M > LAYER_STRIPE_MM_MAX_M && !image_gemm_wanted(M, K, N, ns, 0)) {
+            const size_t need = !L.released ? gptq_prefill_workspace_bytes(M, K, N, ns)
+                                            : layer_dense_from_image(L, M) ? a256((size_t)K * N * ns * 2) : layer_unpacked_bytes(L) + gptq_prefill_workspace_bytes(M, K, N, ns);
+            on_image = !(scratch && aligned(scratch, 256) && scratch_bytes >= need);
+        }
+        if (M > 4 && on_image) {
             const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, L.bias, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, mm_ws,
                                          STRIPE_MM_WS_BYTES, true);
             if (rc != GPTQ_E_VARIANT) return rc;

@@ -30,7 +30,7 @@
 //    waves that share a SIMD (w and w + 4) are always in opposite sections -- one issues MFMAs while the other reads LDS and
 //    issues DMA.  Waits sit at the END of an R section, i.e. one barrier before the staggered partner's first read
 //    (guide: "one barrier MORE when two wave groups run staggered");
-//  * workgroups are numbered so that all n tiles of an m tile run on one XCD (X panel fetched once per XCD-group).
+//  * workgroups are numbered so that every XCD runs a contiguous, equally long run of the m-major tile list (X panel shared through its L2; round 5).
 #include <atomic>
 #include <type_traits>
 
@@ -54,6 +54,7 @@ struct Gemm8Params {
     int64_t ldx, ldw, ldc;
     int M, K, N;
     int ntm, ntn;
+    int per;             // tiles per XCD: ceil(ntm ntn / 8)
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -86,10 +87,15 @@ __global__ void __launch_bounds__(512) gemm8_kernel(const Gemm8Params p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    // XCD-aware tile order: XCD x (= block % 8) walks m tiles x, x + 8, ... and all n tiles of each
+    // XCD-aware tile order.  Workgroup b runs on XCD b % 8; the tiles are numbered m-major (all n tiles of m tile 0, then of m tile 1, ...) and XCD x
+    // owns the CONTIGUOUS run [x per, (x + 1) per) of that list, per = ceil(tiles / 8): the workgroups an XCD runs at the same time share one X
+    // panel (two at a seam) through its L2, and every XCD gets the same number of tiles.  (Rounds 3-4 gave XCD x the WHOLE m tiles x, x + 8, ...:
+    // with ntm % 8 != 0 some XCDs carried twice the tiles of the others -- 2304 x 12288: m tiles 0 and 8 on XCD 0 = 96 tiles = three rounds of its
+    // 32 CUs while seven XCDs finished after two; measured 305 us against 229 us for the library, profiles/r5e_gemm8_tile/.)
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int tm = (jb / p.ntn) * 8 + xcd, tn = jb % p.ntn;
-    if (tm >= p.ntm) return;
+    const int tile_id = xcd * p.per + jb;
+    if (tile_id >= p.ntm * p.ntn) return;
+    const int tm = tile_id / p.ntn, tn = tile_id % p.ntn;
     constexpr int NCOLS = PAIR ? 128 : 256;    // output columns of a workgroup tile
     const int m0 = tm * TM, n0 = tn * NCOLS;
     const int M = p.M, N = p.N, K = p.K;
@@ -289,24 +295,24 @@ int gemm8_launch(const Gemm8Params &p, hipStream_t s) {
     constexpr int lds = 2 * BUF_BYTES;   // 131 072 B
     static LdsOptIn opt_in;   // per instantiation; per device inside
     if (int rc = opt_in.ensure((const void *)kern, lds)) return rc;
-    const int groups_of_8 = (p.ntm + 7) / 8;
-    hipLaunchKernelGGL(kern, dim3(groups_of_8 * 8 * p.ntn), dim3(512), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3(8 * p.per), dim3(512), lds, s, p);
     return (int)hipGetLastError();
 }
 
 std::atomic<int> g_gemm8_mfma{16};   // MFMA shape of the tile GEMM: 16 = 16x16x32, 32 = 32x32x16 (gemm8_set_mfma: tests / A-B runs)
 std::atomic<int> g_gemm8_tile{0};    // rows of the workgroup tile: 0 = chosen per launch (gemm8_tile_rows), 192, 256 (gemm8_set_tile: tests / A-B runs)
 
-// Rows of the workgroup tile for an [M, ntn n-tiles] product: the tile whose rounds of 256 workgroups cost less.  A workgroup's time is
-// proportional to its rows; the 192-row tile pays G8_EFF192 per flop (12 MFMAs per phase against the same barriers, W fragment reads and
-// DMA instructions as 16: measured, tools/bench_gemm8.py TILE=192/256, profiles/r5e_gemm8_tile/).
+// Rows of the workgroup tile for an [M, ntn n-tiles] product: the tile whose rounds cost less.  One workgroup per CU (128 KB of LDS), an XCD runs its
+// ceil(tiles / 8) tiles in rounds of its 32 CUs, a workgroup's time is proportional to its rows; the 192-row tile pays G8_EFF192 per flop (12 MFMAs
+// per phase against the same barriers, W fragment reads and DMA instructions as 16).  Measured: tools/bench_gemm8_tile.py, profiles/r5e_gemm8_tile/
+// (3072 rows: 0.85-0.88 of the 256-row tile's time on all four LLaMA-7B shapes; 3584 and 4096 rows: 1.19-1.49, one round more).
 constexpr double G8_EFF192 = 0.93;
 int gemm8_tile_rows(int M, int ntn) {
     const int forced = g_gemm8_tile.load();
     if (forced) return forced;
     auto cost = [&](int rows, double eff) {
-        const long tiles = (long)((M + rows - 1) / rows) * ntn;
-        return (double)((tiles + 255) / 256) * rows / eff;
+        const long tiles = (long)((M + rows - 1) / rows) * ntn, per_xcd = (tiles + 7) / 8;
+        return (double)((per_xcd + 31) / 32) * rows / eff;
     };
     return cost(192, G8_EFF192) < cost(256, 1.0) ? 192 : 256;
 }
@@ -328,6 +334,7 @@ int gemm8_dense_f16(const half_t *x, int64_t ldx, const half_t *wt, int64_t ldw,
     const bool mf32 = g_gemm8_mfma.load() == 32;
     const int rows = mf32 ? 256 : gemm8_tile_rows(M, p.ntn);
     p.ntm = (M + rows - 1) / rows;
+    p.per = (p.ntm * p.ntn + 7) / 8;
     if (mf32) return pair ? gemm8_launch<true, true, 64>(p, s) : gemm8_launch<false, true, 64>(p, s);
     if (rows == 192) return pair ? gemm8_launch<true, false, 48>(p, s) : gemm8_launch<false, false, 48>(p, s);
     return pair ? gemm8_launch<true, false, 64>(p, s) : gemm8_launch<false, false, 64>(p, s);

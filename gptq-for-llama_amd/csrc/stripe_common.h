@@ -23,10 +23,10 @@ int stripe_mm_dispatch_b3(const StripeParams &p, void *ws, size_t ws_bytes, int 
 int stripe_mm_dispatch_b4(const StripeParams &p, void *ws, size_t ws_bytes, int forced_slices, hipStream_t s);
 int stripe_mm_dispatch_b8(const StripeParams &p, void *ws, size_t ws_bytes, int forced_slices, hipStream_t s);
 // batches above 128 rows: 2-D tiled fused-dequantise MFMA GEMM on the stripe16 image (stripe_mm.inc, stripe_gemm_kernel)
-int stripe_gemm_dispatch_b3(const StripeParams &p, hipStream_t s);
-int stripe_gemm_dispatch_b4(const StripeParams &p, hipStream_t s);
-int stripe_gemm_dispatch_b8(const StripeParams &p, hipStream_t s);
-int stripe_gemm_dispatch_b2(const StripeParams &p, hipStream_t s);
+int stripe_gemm_dispatch_b3(const StripeParams &p, void *ws, size_t ws_bytes, hipStream_t s);
+int stripe_gemm_dispatch_b4(const StripeParams &p, void *ws, size_t ws_bytes, hipStream_t s);
+int stripe_gemm_dispatch_b8(const StripeParams &p, void *ws, size_t ws_bytes, hipStream_t s);
+int stripe_gemm_dispatch_b2(const StripeParams &p, void *ws, size_t ws_bytes, hipStream_t s);
 constexpr size_t STRIPE_MM_WS_BYTES = (size_t)64 << 20;   // counters + partial tiles of the largest supported launch
 
 }  // namespace gptq

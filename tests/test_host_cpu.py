@@ -531,7 +531,13 @@ def test_layer_route_table_is_host_logic():
     for K, N, ns in [(4096, 4096, 1), (4096, 12288, 1), (11008, 4096, 1), (4096, 11008, 2)]:
         assert route(1, K, N, nsets=ns) == DEC and route(4, K, N, nsets=ns) == DEC
         assert route(16, K, N, nsets=ns) == TILES and route(128, K, N, nsets=ns) == TILES
-        assert route(129, K, N, nsets=ns) == SGEMM and route(2048, K, N, nsets=ns) == SGEMM      # a prompt of up to 2048 tokens: weights stay packed
+        assert route(129, K, N, nsets=ns) == SGEMM and route(640, K, N, nsets=ns) == SGEMM        # a prompt: weights stay packed ...
+        # ... while the image route's 128 x 128 tiles fit the chip at once (512) or the batch is too short to pay for a dequantise pass; above, the
+        # dense route is the faster own kernel since gemm8 balances its tiles over the XCDs (round 5, profiles/r5e_gemm8_tile/)
+        wide = N * ns > 4096
+        assert route(2048, K, N, nsets=ns) == (OWN if wide else SGEMM)
+        assert route(768, K, N, nsets=ns) == (OWN if wide and ns == 1 else SGEMM) and route(1152, K, N, nsets=ns) == (OWN if wide and ns == 1 else SGEMM)
+        assert route(1280, K, N, nsets=ns) == (OWN if wide else SGEMM)
         assert route(2049, K, N, nsets=ns) == OWN and route(4095, K, N, nsets=ns) == OWN          # above: dequantise per call + the own tile GEMM
         assert route(65536, K, N, nsets=ns) == OWN                                                # BASELINE config 3
         for M in (1, 5, 64, 129, 1025, 1536, 2048, 3072, 4095, 65536):

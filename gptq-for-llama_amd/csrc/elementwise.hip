@@ -10,21 +10,31 @@
 namespace gptq {
 
 // ------------------------------------------------------------------------------ RMSNorm
-// One workgroup per row; the row stays in registers between the two passes.
+// One workgroup per row; the row stays in registers between the two passes.  The norm weight is requested WITH the row (round 5; rounds 1-4 loaded
+// it after the barrier: a second dependent memory round trip; same arithmetic, same bits).  Measured in the batched decode engine's 16-row step
+// (two launches per layer): 4.83 us per launch before and after, minimum 2.0 -- what rocprofv3 reports for a 16-workgroup launch inside a graph is
+// the kernel-to-kernel dependency (the 4.9 us of stripe_mm_reduce_kernel and the 4.1 us of a 64-byte copyBuffer say the same), not this code.
 template <int VPT>
 __global__ void __launch_bounds__(256) rmsnorm_kernel(const half_t *__restrict__ x, int64_t ldx,
                                                       const half_t *__restrict__ w, half_t *__restrict__ y,
                                                       int64_t ldy, int N, float eps) {
     const int row = blockIdx.x, tid = threadIdx.x;
     const half_t *xr = x + (size_t)row * ldx;
-    half8_t v[VPT];
+    half8_t v[VPT], wv[VPT];
     float ss = 0.f;
     const int nv = N / 8;
 #pragma unroll
     for (int i = 0; i < VPT; i++) {
         const int c = tid + i * 256;
         v[i] = (half8_t)(half_t)0;
-        if (c < nv) v[i] = *(const half8_t *)(xr + (size_t)c * 8);
+        wv[i] = (half8_t)(half_t)0;
+        if (c < nv) {
+            v[i] = *(const half8_t *)(xr + (size_t)c * 8);
+            wv[i] = *(const half8_t *)(w + (size_t)c * 8);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const float f = (float)v[i][j];
@@ -42,10 +52,9 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const half_t *__restrict__
     for (int i = 0; i < VPT; i++) {
         const int c = tid + i * 256;
         if (c < nv) {
-            const half8_t wv = *(const half8_t *)(w + (size_t)c * 8);
             half8_t o;
 #pragma unroll
-            for (int j = 0; j < 8; j++) o[j] = (half_t)((float)v[i][j] * rstd * (float)wv[j]);
+            for (int j = 0; j < 8; j++) o[j] = (half_t)((float)v[i][j] * rstd * (float)wv[i][j]);
             *(half8_t *)(yr + (size_t)c * 8) = o;
         }
     }

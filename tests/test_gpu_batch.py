@@ -83,6 +83,51 @@ def test_layer_decode_norm_and_residual(bits, K, N, gs, NS, M):
             assert rel_err(y, ref) < (2 * TOL if NS == 2 else TOL if not use_res else 1.5 * TOL), (use_norm, use_res, rel_err(y, ref))
 
 
+@pytest.mark.parametrize('M', [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize('bits,K,N,gs,NS', [(4, 4096, 12288, 128, 1),      # qkv of LLaMA-7B: 768 stripes = 256 workgroups x 3
+                                            (4, 512, 8224, 128, 1),        # 514 stripes: the last workgroup owns ONE stripe
+                                            (4, 1024, 8224, 128, 2),       # ... as a gate | up pair (two table pieces per thread)
+                                            (4, 512, 16384, 128, 1),       # 1024 stripes: four per workgroup
+                                            (4, 256, 20512, 128, 1),       # 1282 stripes: more than four per CU -> the one-stripe kernel
+                                            (3, 1152, 8256, 128, 1), (8, 1024, 8224, 64, 1), (4, 640, 8256, 32, 1), (4, 2560, 8224, -1, 1)])
+def test_decode_batches_on_wide_layers(bits, K, N, gs, NS, M):
+    """Round 5: layers with more than two stripes per CU run C consecutive stripes per workgroup (csrc/stripe_kernel.inc stripe_gemvc_kernel:
+    x staged and normalised once per workgroup, one weight stream across the stripe boundaries, an epilogue per stripe behind an LDS-only
+    barrier) -- 2 .. 4 rows in every variant, one row with the fused norm, 5 .. 8 rows of a gate | up pair; norm / residual / both against the
+    oracle, rows independent of their position in the batch, and the producer-side permutation of the output columns
+    (gptq_stripe_matvec_perm_out_f16) through the same kernel."""
+    Ls = [make_random_layer(bits, gs, K, N, seed=700 + bits + i) for i in range(NS)]
+    pl, _keep = _prepared(Ls, gs, K, N, bits)
+    rng = np.random.default_rng(K + N + M)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    nw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+    res = rng.standard_normal((M, N)).astype(np.float16)
+    got = {}
+    for use_norm in (False, True):
+        for use_res in ((False,) if NS == 2 else (False, True)):
+            y = _decode(pl, dev(x), M, N, norm=dev(nw) if use_norm else None, residual=dev(res) if use_res else None)
+            ref = _expect(x, Ls, bits, nw if use_norm else None, 1e-6, res if use_res else None)
+            assert np.isfinite(y.astype(np.float32)).all(), (use_norm, use_res)
+            assert rel_err(y, ref) < (2 * TOL if NS == 2 else TOL if not use_res else 1.5 * TOL), (use_norm, use_res, rel_err(y, ref))
+            got[(use_norm, use_res)] = y
+    # the rows in another order (and the batch padded to four rows by repeating one): the same bits per row
+    order = rng.permutation(M)
+    y2 = _decode(pl, dev(x[order]), M, N, norm=dev(nw))
+    assert np.array_equal(y2.view(np.uint16), got[(True, False)][order].view(np.uint16))
+    # the output columns through a permutation (the consumer's sorted order): the same values, elsewhere (against the same entry without one:
+    # gptq_layer_decode_f16 may take the 16-row tiles + a norm launch for 5 .. 8 rows, other roundings)
+    perm = torch.from_numpy(rng.permutation(N).astype(np.int32)).to(DEV)
+    out = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+    straight = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+    for o, pm in ((out, perm), (straight, None)):
+        quant.quant_linear.stripe_matvec(dev(x), pl.stripe, o, K, N, bits, K if gs == -1 else gs, nsets=NS, norm_weight=dev(nw), eps=1e-6, out_perm=pm)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, perm.long()], straight)
+    assert rel_err(straight.cpu().numpy(), _expect(x, Ls, bits, nw, 1e-6, None)) < (2 * TOL if NS == 2 else TOL)
+    if M <= 4:
+        assert np.array_equal(straight.cpu().numpy().view(np.uint16), got[(True, False)].view(np.uint16))
+
+
 def test_layer_decode_bias_and_residual_strided():
     """a layer WITH a bias and a residual (one add slot per launch: the bias rides, the residual is a second launch), strided x / residual
     rows, y into a wider buffer"""

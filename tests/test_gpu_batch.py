@@ -89,7 +89,7 @@ def test_layer_decode_norm_and_residual(bits, K, N, gs, NS, M):
                                             (4, 1024, 8224, 128, 2),       # ... as a gate | up pair (two table pieces per thread)
                                             (4, 512, 16384, 128, 1),       # 1024 stripes: four per workgroup
                                             (4, 256, 20512, 128, 1),       # 1282 stripes: more than four per CU -> the one-stripe kernel
-                                            (4, 512, 4144, 128, 1),        # 259 stripes: two per workgroup with the fused norm only (ragged)
+                                            (4, 512, 4160, 128, 1),        # 260 stripes: two per workgroup, with the fused norm only
                                             (3, 1152, 8256, 128, 1), (8, 1024, 8224, 64, 1), (4, 640, 8256, 32, 1), (4, 2560, 8224, -1, 1)])
 def test_decode_batches_on_wide_layers(bits, K, N, gs, NS, M):
     """Round 5: layers with more than two stripes per CU run C consecutive stripes per workgroup (csrc/stripe_kernel.inc stripe_gemvc_kernel:

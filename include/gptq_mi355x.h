@@ -85,7 +85,9 @@ int gptq_set_prefill_route(int route);
 int gptq_set_stripe_mm_pass_rows(int rows);
 /* Batches of 129 .. `rows` rows of a layer with a stripe16 image run the fused-dequantise tile GEMM on the image (csrc/stripe_mm.inc,
  * stripe_gemm_kernel: weights stay packed, no per-call dequantise pass) instead of the dense route; 0 = never (tests / A-B runs).
- * Returns the previous value. */
+ * Round 5: gptq_layer_forward keeps a trivial-g_idx layer on the image only while its 128 x 128 tiles fit the chip at once
+ * (ceil(M / 128) * N * nsets / 128 <= 512) or M <= 640 (gate | up pair: 1152); above, dequantise + the tile GEMM is the faster own kernel
+ * (gptq_layer_route_for_shape says which; gptq_stripe_matmul_f16 itself serves every M up to `rows`).  Returns the previous value. */
 int gptq_set_stripe_gemm_max_rows(int rows);
 /* which engine a dense product of this shape takes under the current switch: 1 = tile GEMM, 0 = hipBLASLt (host logic only;
  * nsets = 2: gate/up pair; trans = 1: the backward product) */
@@ -369,8 +371,9 @@ int gptq_stripe_matmul_partial_f32(const void *x, int64_t ldx, const void *strip
  * (gptq_query(GPTQ_Q_STRIPE_MM_WORKSPACE_BYTES), 256-byte aligned) is pure scratch for the partial tiles: no initialisation, no state
  * between launches; do not share it between launches that may overlap, nor with the zero-invariant split-K workspace of the
  * rowwave kernels.  129 <= M <= gptq_set_stripe_gemm_max_rows() (default 2048; groups of at least a row block, bits 3 / 4 / 8): ONE launch of
- * the 2-D tiled fused-dequantise GEMM (stripe_gemm_kernel: 128 x 128 tiles, weights stay packed, x through LDS) -- no workspace use,
- * no per-call dequantise pass.  Reference semantics:
+ * the 2-D tiled fused-dequantise GEMM (stripe_gemm_kernel: 128 x 128 tiles, weights stay packed, x through LDS) -- no per-call
+ * dequantise pass; round 5: while the tiles cover at most half the chip (N = 4096: up to 512 rows) K is sliced over the row tiles too
+ * (partial tiles in `workspace` + the reduce kernel, as below 129 rows).  Reference semantics:
  * quant/quant_linear.py:103-137, :415-419; nsets = 2: quant/fused_mlp.py:128-168 (no bias). */
 int gptq_stripe_matmul_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
                            int K, int N, int bits, int groupsize, int nsets, void *workspace, size_t workspace_bytes, gptq_stream_t stream);
@@ -445,9 +448,9 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
  * (quant/custom_autotune.py:76-102) by something a caller can read.  A kernel may still decline at launch (LDS limits) and hand the
  * batch to the next rung of the ladder.  kind: the value of gptq_layer_inspect(); has_image: an image was given to gptq_layer_prepare. */
 enum {
-    GPTQ_ROUTE_STRIPE_DECODE = 1,        /* stripe16 decode kernel (M = 1) / its row groups (2 .. 8 rows) */
+    GPTQ_ROUTE_STRIPE_DECODE = 1,        /* stripe16 decode kernel (M = 1) / its row groups (2 .. 8 rows); wide layers: C stripes per workgroup (round 5) */
     GPTQ_ROUTE_STRIPE_TILES = 2,         /* 16-row MFMA tiles on the image, up to 128 rows (csrc/stripe_mm.inc) */
-    GPTQ_ROUTE_STRIPE_GEMM = 3,          /* fused-dequantise tile GEMM on the image, 129 .. gptq_set_stripe_gemm_max_rows() rows */
+    GPTQ_ROUTE_STRIPE_GEMM = 3,          /* fused-dequantise tile GEMM on the image, 129 .. gptq_set_stripe_gemm_max_rows() rows (see there) */
     GPTQ_ROUTE_DENSE_TILE_GEMM = 4,      /* dequantise per call + the tile GEMM of csrc/gemm8.hip */
     GPTQ_ROUTE_DENSE_LIBRARY = 5,        /* dequantise per call + hipBLASLt */
     GPTQ_ROUTE_CHECKPOINT_KERNELS = 6    /* rowwave / stream / generic kernels on the checkpoint layout */

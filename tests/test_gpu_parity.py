@@ -1782,6 +1782,46 @@ def test_released_layer_prefill_straight_from_the_image(bits, gs, K, N, pair):
     assert rel_err(y1[:64].cpu().numpy(), ref) < (2 * TOL if pair else TOL)
 
 
+@pytest.mark.parametrize('pair', [False, True])
+def test_long_prompts_on_wide_layers_take_the_dense_route(pair):
+    """Round 5: gptq_layer_forward keeps a batch of 129 .. 2048 rows on the fused image GEMM only while its 128 x 128 tiles fit the chip at once
+    (at most 512) or the batch is too short to pay for a dequantise pass (640 rows; the gate | up pair: 1152) -- above, dequantise + the tile
+    GEMM of gemm8.hip (capi.hip image_gemm_wanted; measured in profiles/r5e_gemm8_tile/).  The host-side table says so, both routes meet the
+    oracle, a released layer takes its W^T straight from the image (same bits), and a caller who brings NO scratch stays on the image."""
+    lib = _native.lib()
+    bits, gs, K, N = 4, 128, 512, 8192
+    M = 1300 if pair else 1100                            # 11 / 9 row tiles x 128 (pair) / 64 column groups: more than 512 tiles
+    A = make_random_layer(bits, gs, K, N, seed=31)
+    B = make_random_layer(bits, gs, K, N, seed=32)
+    sets = tuple((dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx'])) for L in ((A, B) if pair else (A,)))
+    from quant.layer import PreparedLayer
+    pl = PreparedLayer(sets, None, bits, gs, K, N)
+    assert lib.gptq_layer_route_for(pl.handle, M) == 4 and lib.gptq_layer_route_for(pl.handle, 600) == 3        # DENSE_TILE_GEMM / STRIPE_GEMM
+    assert lib.gptq_layer_scratch_bytes(pl.handle, M) >= K * N * 2 * len(sets) and lib.gptq_layer_scratch_bytes(pl.handle, 600) == 0
+    x = dev((np.random.default_rng(6).standard_normal((M, K)) * 0.5).astype(np.float16))
+    y_dense = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+    pl.forward(x, y_dense)
+    # no scratch: the same call stays on the image (exact q - z and fp32 group scales: other roundings, same tolerance)
+    s = _native.stream_ptr(torch.device(DEV))
+    ws = _native.layer_workspace(torch.device(DEV), s)
+    y_image = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+    _native.check(lib.gptq_layer_forward(pl.handle, x.data_ptr(), x.stride(0), y_image.data_ptr(), y_image.stride(0), M, ws.data_ptr(), ws.numel(), None, 0, s),
+                  'gptq_layer_forward')
+    torch.cuda.synchronize()
+    rows = np.unique(np.concatenate([np.arange(0, M, 97), [127, 128, M - 1]]))
+    ta, tb = (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx'])
+    xs = x.cpu().numpy()[rows]
+    ref = oracle.fused_mlp(xs, ta, tb, bits) if pair else oracle.matmul248(xs, *ta, bits)
+    for y in (y_dense, y_image):
+        assert rel_err(y.cpu().numpy()[rows], ref) < (2 * TOL if pair else TOL)
+    assert not torch.equal(y_dense, y_image)              # (two different kernels did run)
+    assert pl.release()
+    y_rel = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+    pl.forward(x, y_rel)
+    torch.cuda.synchronize()
+    assert torch.equal(y_rel, y_dense)
+
+
 def test_released_layer_retries_with_the_fallback_scratch():
     """gptq_layer_scratch_bytes answers for the route the table picks; when that kernel declines at launch -- here the fused tile
     GEMM on the image refuses an x whose rows are 2^23 halves apart (its buffer descriptor ends at 2 GB) -- a released layer's fall-back

@@ -406,6 +406,8 @@ def test_prefill_route_selection_is_host_logic(monkeypatch):
         lib.gptq_set_prefill_route(2)
         assert rf(300, 4096, 4096, 1, 0) == 1 and rf(300, 4064, 4096, 1, 0) == 0
         assert lib.gptq_set_prefill_route(7) == -6
+        assert lib.gptq_set_gemm8_tile(100) == -6 and lib.gptq_set_gemm8_tile(0) == 0      # rows of the tile GEMM's workgroup tile: 0 (per launch) / 192 / 256
+        assert lib.gptq_set_gemm8_tile(192) == 0 and lib.gptq_set_gemm8_tile(0) == 192
     finally:
         lib.gptq_set_prefill_route(prev)
     assert lib.gptq_prefill_plan_count() == 0          # nothing planned without a GPU

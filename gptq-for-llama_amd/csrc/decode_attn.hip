@@ -195,17 +195,21 @@ __global__ void __launch_bounds__(ATT_HD) attn_combine_kernel(const float *__res
 // (write-through) stores, drained, and a per-head arrival ticket elects the last split to merge
 // them (MI355X_MICROARCH.md, "Valid forms": sc0 sc1 stores AND loads, flag behind vmcnt(0)).
 // ws = [batch][heads][nsplit][ATT_REC] floats followed by [batch][heads] uint32 tickets (zero between launches).
-// Round 5: blockIdx.z = row of a decode BATCH -- every row has its own position (sequences of different lengths; a left-padded prompt is
+// Round 5: blockIdx.y = row of a decode BATCH (blockIdx.z = split: see the note on the dispatch order below) -- every row has its own position (sequences of different lengths; a left-padded prompt is
 // stored without its pads, see quant/engine_hook.py), its own [t_max][heads * 128] slice of the K / V cache, its own qkv row (stride ldq)
 // and output row (stride ldo).  A negative position marks an idle row: nothing is read or written for it.
 // ---------------------------------------------------------------------------------------
+// Dispatch order (round 5): workgroups are issued x fastest, then y, then z.  With grid (heads, splits, rows) the ONE active split of a short
+// context sat between 15 idle ones per row -- a batch of 16 rows at t_max = 2048 issues 8 192 workgroups of which 7 680 load `pos` and leave, and row 15's
+// active workgroups came after 7 680 others (four rounds of resident workgroups, each a memory round trip: 8.1 us per launch at 16 rows against 5.1
+// at one).  Grid (heads, rows, splits): every row's FIRST split is issued first, the idle ones drain behind the work.
 __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__restrict__ qkv, const int64_t *__restrict__ pos_ptr,
                                                                 half_t *__restrict__ kc, half_t *__restrict__ vc,
                                                                 half_t *__restrict__ out, float *__restrict__ ws, int heads, int t_max,
                                                                 float inv_base, float scale, const float2 *__restrict__ rope_tab,
                                                                 u64_t *__restrict__ dbg, int ldq, int ldo, int ts_grid, const int32_t *__restrict__ out_perm) {
     {   // this workgroup's row of the batch
-        const int b = blockIdx.z;
+        const int b = blockIdx.y;
         const size_t hdz = (size_t)heads * ATT_HD;
         pos_ptr += b;
         qkv += (size_t)b * ldq;
@@ -214,8 +218,8 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
         vc += (size_t)b * t_max * hdz;
         if (b) dbg = nullptr;   // (development stamps: row 0 only)
     }
-    float *const ws_tickets = ws + (size_t)gridDim.z * heads * gridDim.y * ATT_REC;
-    ws += (size_t)blockIdx.z * heads * gridDim.y * ATT_REC;
+    float *const ws_tickets = ws + (size_t)gridDim.y * heads * gridDim.z * ATT_REC;
+    ws += (size_t)blockIdx.y * heads * gridDim.z * ATT_REC;
     u64_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u64_t sx_[4] = {0, 0, 0, 0};   // development stamps (gptq_set_debug_buffer, tools/timeline_attn.py)
     if (dbg) { st_[0] = stamp_realtime(); st_[1] = stamp_cycles(0); }
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     __shared__ float sc[ATT_TS];
     __shared__ float accs[4][ATT_HD];
     __shared__ int last_flag;
-    const int h = blockIdx.x, nsplit = gridDim.y;
+    const int h = blockIdx.x, nsplit = gridDim.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // out_perm (round 5): o_proj is an act-order layer whose image holds group-sorted rows -- element k of the attention output goes where its sorted
     // order wants it, so o_proj runs the trivial kernel.  Requested first: nothing depends on it until the store.
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     // decode_attn_ts_grid: measured, slower, off by default -- 64 for a batch-1 launch: twice the workgroups); with the 64-step grid a launch whose
     // context is at most ATT_LONG tokens folds two grid splits into one 128-step split (odd grid splits leave at once), a longer one keeps
     // 64-step splits: 24 workgroups per head stream K / V at 1500 tokens instead of 12.
-    int s = blockIdx.y, ts = ATT_TS;
+    int s = blockIdx.z, ts = ATT_TS;
     if (ts_grid == ATT_TS / 2) {
         if (len > ATT_LONG) ts = ATT_TS / 2;
         else if (s & 1) return;
@@ -395,7 +399,7 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned *ticket = (unsigned *)ws_tickets + (size_t)blockIdx.z * heads + h;
+    unsigned *ticket = (unsigned *)ws_tickets + (size_t)blockIdx.y * heads + h;
     if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (t == (unsigned)(nsp - 1));
@@ -461,7 +465,7 @@ int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, 
     const int ts_grid = decode_attn_ts_grid(t_max, batch);
     const int nsplit = (t_max + ts_grid - 1) / ts_grid;
     const float inv_base = -2.0f * logf(base) / (float)ATT_HD;
-    hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(heads, nsplit, batch), dim3(256), 0, s, qkv, pos, kc, vc, out, ws, heads, t_max, inv_base,
+    hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(heads, batch, nsplit), dim3(256), 0, s, qkv, pos, kc, vc, out, ws, heads, t_max, inv_base,
                        scale, (const float2 *)rope_table, dbg, (int)ldq, (int)ldo, ts_grid, out_perm);
     return (int)hipGetLastError();
 }

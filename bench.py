@@ -717,8 +717,9 @@ def decode_tokens_per_s(dev, tokens=64):
                        one-token forwards are answered by the hipGraph decode engine (quant/engine_hook.py)
       drop_in_generate model.generate(...) as llama_inference.py:119-127 calls it
       engine_graph     quant.decode.DecodeEngine driven directly (one hipGraph replay per token)
-      engine_graph_bN  DecodeEngine(batch=N): N sequences per replay, aggregate tokens/s"""
-    from quant.decode import build_random_llama, benchmark_decode, benchmark_decode_engine, benchmark_generate
+      engine_graph_bN  DecodeEngine(batch=N): N sequences per replay, aggregate tokens/s
+      engine_graph_[bN_]ctxT  the same engines with ~T tokens of history per row (round 6)"""
+    from quant.decode import build_random_llama, benchmark_decode, benchmark_decode_engine, benchmark_generate, benchmark_decode_engine_context
     import quant
     model = build_random_llama(dev)
     out = {'hf_eager': benchmark_decode(model, 24, engine_hook=False)}
@@ -740,9 +741,17 @@ def decode_tokens_per_s(dev, tokens=64):
     out['tokens_per_s'] = out['engine_graph']['tokens_per_s']
     # round 5: decode BATCHES -- B sequences per hipGraph replay (linears at M = B: the decode kernel's row groups / 16-row MFMA tiles with
     # norm and residual fused, per-row positions in the attention launch, ONE pass over the LM head for all rows); aggregate tokens/s
-    for B in (2, 4, 8, 16):
+    for B in (2, 4, 5, 8, 16):
         torch.cuda.empty_cache()
         out['engine_graph_b%d' % B] = benchmark_decode_engine(model, tokens=32, graph=True, batch=B)
+    # round 6: the same engines at DEPTH -- the reference's protocol steps through 2048 tokens and prints the median (llama.py:385-438), i.e. its
+    # median token sees ~1000 tokens of context; the legs above start from an empty cache.  engine_graph_ctx{512,1024,2047}: tokens/s with that
+    # much history per row (B = 1, and B = 4 rows).
+    for B in (1, 4):
+        torch.cuda.empty_cache()
+        ctx = benchmark_decode_engine_context(model, contexts=(512, 1024, 2047), batch=B)
+        for k in ('ctx512', 'ctx1024', 'ctx2047'):
+            out['engine_graph_%s%s' % ('' if B == 1 else 'b%d_' % B, k)] = dict(ctx[k], protocol=ctx['protocol'], attention=ctx['attention'])
     # ... and through the reference's own call site: generate on FOUR left-padded prompts -- [4, 1] steps with per-row positions, answered by the hook's
     # DecodeEngine(batch=4) (HF's per-step host work included)
     torch.cuda.empty_cache()

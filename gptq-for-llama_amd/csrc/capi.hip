@@ -868,7 +868,7 @@ int gptq_decode_attn_f16(const void *q, const void *k_cache, const void *v_cache
                          size_t workspace_bytes, int heads, int head_dim, int t_max, float scale, gptq_stream_t stream) {
     if (!q || !k_cache || !v_cache || !position || !out || !workspace) return GPTQ_E_NULL;
     if (heads <= 0 || head_dim != 128 || t_max <= 0) return GPTQ_E_SHAPE;
-    if (!aligned(q, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4)) return GPTQ_E_ALIGN;
+    if (!aligned(q, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 16)) return GPTQ_E_ALIGN;
     if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
     return decode_attn_launch((const half_t *)q, (const half_t *)k_cache, (const half_t *)v_cache, position, (half_t *)out,
                               (float *)workspace, heads, t_max, scale, (hipStream_t)stream);
@@ -879,10 +879,11 @@ int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k
                                gptq_stream_t stream) {
     if (!qkv || !k_cache || !v_cache || !position || !out || !workspace) return GPTQ_E_NULL;
     if (heads <= 0 || head_dim != 128 || t_max <= 0) return GPTQ_E_SHAPE;
-    if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4)) return GPTQ_E_ALIGN;
+    if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 16)) return GPTQ_E_ALIGN;
     if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
     return decode_attn_fused_launch((const half_t *)qkv, position, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out,
-                                    (float *)workspace, heads, t_max, base, scale, nullptr, (u64_t *)g_debug_buffer.load(), (hipStream_t)stream);
+                                    (float *)workspace, heads, t_max, base, scale, nullptr, (hipStream_t)stream, 1, 3 * (int64_t)heads * head_dim,
+                                    (int64_t)heads * head_dim);
 }
 
 int gptq_rope_table_f32(float *table, int t_max, int head_dim, float base, gptq_stream_t stream) {
@@ -897,10 +898,11 @@ int gptq_decode_attn_fused_table_f16(const void *qkv, const int64_t *position, v
                                      const float *rope_table, gptq_stream_t stream) {
     if (!qkv || !k_cache || !v_cache || !position || !out || !workspace || !rope_table) return GPTQ_E_NULL;
     if (heads <= 0 || head_dim != 128 || t_max <= 0) return GPTQ_E_SHAPE;
-    if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4) || !aligned(rope_table, 8)) return GPTQ_E_ALIGN;
+    if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 16) || !aligned(rope_table, 8)) return GPTQ_E_ALIGN;
     if (workspace_bytes < decode_attn_ws_bytes(heads, t_max)) return GPTQ_E_WORKSPACE;
     return decode_attn_fused_launch((const half_t *)qkv, position, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out,
-                                    (float *)workspace, heads, t_max, base, scale, rope_table, (u64_t *)g_debug_buffer.load(), (hipStream_t)stream);
+                                    (float *)workspace, heads, t_max, base, scale, rope_table, (hipStream_t)stream, 1, 3 * (int64_t)heads * head_dim,
+                                    (int64_t)heads * head_dim);
 }
 
 /* round 5: a decode BATCH -- row b has its own position (positions[b]; negative = idle row), qkv row (ldq apart), output row (ldo apart) and
@@ -917,12 +919,33 @@ int gptq_decode_attn_batch_f16(const void *qkv, int64_t ldq, const int64_t *posi
     if (out_perm && !aligned(out_perm, 4)) return GPTQ_E_ALIGN;
     if (batch <= 0 || batch > 65535 || heads <= 0 || head_dim != 128 || t_max <= 0 || ldq < 3 * (int64_t)heads * head_dim || ldo < (int64_t)heads * head_dim)
         return GPTQ_E_SHAPE;
-    if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 4) || (rope_table && !aligned(rope_table, 8)) ||
+    if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 16) || (rope_table && !aligned(rope_table, 8)) ||
         ldq % 8 != 0 || ldo % 8 != 0 || !aligned(out, 2))
         return GPTQ_E_ALIGN;
     if (workspace_bytes < decode_attn_ws_bytes(heads, t_max, batch)) return GPTQ_E_WORKSPACE;
     return decode_attn_fused_launch((const half_t *)qkv, positions, (half_t *)k_cache, (half_t *)v_cache, (half_t *)out, (float *)workspace, heads, t_max,
-                                    base, scale, rope_table, (u64_t *)g_debug_buffer.load(), (hipStream_t)stream, batch, ldq, ldo, out_perm);
+                                    base, scale, rope_table, (hipStream_t)stream, batch, ldq, ldo, out_perm);
+}
+
+/* round 6: the same launch, but every active split of a row leaves its record {M, den, num[128]} (fp32) in the workspace and NOTHING merges them here:
+ * the consumer is gptq_layer_decode_attn_f16 (o_proj's decode kernel stages x from the records).  tokens_per_split <= 0: the default. */
+int gptq_decode_attn_split_f16(const void *qkv, int64_t ldq, const int64_t *positions, void *k_cache, void *v_cache, void *workspace,
+                               size_t workspace_bytes, int batch, int heads, int head_dim, int t_max, float base, float scale, const float *rope_table,
+                               int tokens_per_split, gptq_stream_t stream) {
+    if (!qkv || !k_cache || !v_cache || !positions || !workspace) return GPTQ_E_NULL;
+    if (batch <= 0 || batch > 65535 || heads <= 0 || head_dim != 128 || t_max <= 0 || ldq < 3 * (int64_t)heads * head_dim) return GPTQ_E_SHAPE;
+    if (!aligned(qkv, 16) || !aligned(k_cache, 16) || !aligned(v_cache, 16) || !aligned(workspace, 16) || (rope_table && !aligned(rope_table, 8)) ||
+        ldq % 8 != 0)
+        return GPTQ_E_ALIGN;
+    if (workspace_bytes < decode_attn_ws_bytes(heads, t_max, batch)) return GPTQ_E_WORKSPACE;
+    return decode_attn_fused_launch((const half_t *)qkv, positions, (half_t *)k_cache, (half_t *)v_cache, nullptr, (float *)workspace, heads, t_max, base,
+                                    scale, rope_table, (hipStream_t)stream, batch, ldq, 0, nullptr, true, tokens_per_split);
+}
+
+/* splits per (row, head) of a launch's grid -- also the S of the workspace layout [batch][S][heads * 128] | [batch][S][heads][2] | tickets */
+int gptq_decode_attn_splits(int batch, int heads, int head_dim, int t_max) {
+    if (batch <= 0 || heads <= 0 || head_dim != 128 || t_max <= 0) return GPTQ_E_SHAPE;
+    return decode_attn_grid_splits(heads, t_max, batch);
 }
 
 // ---- stripe16: no-split-K decode GEMV on a load-time repacked copy (stripe*.hip) ----
@@ -947,7 +970,7 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
 static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, float *y32,
                          int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
                          gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false, int64_t ldb = 0,
-                         const int32_t *yperm = nullptr) {
+                         const int32_t *yperm = nullptr, const AttnMerge *att = nullptr) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
@@ -986,6 +1009,10 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.gq_shift = gq;
     p.bits = bits;
     p.progress = M == 1 ? stripe_progress_counter() : nullptr;
+    if (att && att->o16) {
+        if (M != 1 || mm_ws || y32 || yperm || perm || norm_weight || nsets != 1) return GPTQ_E_VARIANT;
+        p.att = *att;
+    }
     if (gemm_rows) {   // 2-D tiles, weights kept packed (stripe_gemm_kernel)
         int rc;
         switch (bits) {
@@ -1548,6 +1575,45 @@ int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx,
     const int rc = gptq_layer_forward(layer, xin, ldin, y, ldy, M, workspace, workspace_bytes, left ? sp : nullptr, left, stream);
     if (rc == 0 && residual) return add_rows_launch((half_t *)y, ldy, (const half_t *)residual, ldr, M, N, (hipStream_t)stream);
     return rc;
+}
+
+// ---- round 6: o_proj of a decode step whose attention left split records instead of an fp16 row ----
+// y = residual + layer(x), x = the merge of the records gptq_decode_attn_split_f16 wrote for this row (attn_split.h): the decode kernel stages x
+// from them, so the attention launch needs no cross-workgroup merge of its own.  One row (a batch-1 decode step), a layer with a trivial g_idx
+// and a stripe16 image, K = heads x 128; anything else: GPTQ_E_VARIANT (the caller then runs gptq_decode_attn_batch_f16 + gptq_layer_decode_f16).
+int gptq_layer_decode_attn_supported(const gptq_layer_t *layer, int batch, int heads, int head_dim) {
+    if (!layer) return GPTQ_E_NULL;
+    const gptq_layer &L = *layer;
+    if (batch != 1 || head_dim != 128 || heads <= 0 || L.K != heads * 128) return 0;
+    if (!L.stripe || L.kind != 0 || L.nsets != 1) return 0;
+    if (stripe_gq_shift(L.K, L.N, L.bits, L.groupsize) == -2) return 0;
+    const int bk = L.bits == 8 ? 64 : 128;
+    if ((L.K / bk + 7) / 8 > stripe_max_nu(L.bits)) return 0;
+    return 1;
+}
+
+int gptq_layer_decode_attn_f16(const gptq_layer_t *layer, const void *attn_workspace, size_t attn_workspace_bytes, const int64_t *positions, int batch,
+                               int heads, int head_dim, int t_max, int tokens_per_split, void *y, int64_t ldy, const void *residual, int64_t ldr,
+                               gptq_stream_t stream) {
+    if (!layer || !attn_workspace || !positions || !y) return GPTQ_E_NULL;
+    const gptq_layer &L = *layer;
+    if (batch <= 0 || heads <= 0 || head_dim != 128 || t_max <= 0 || ldy < L.N || (residual && ldr < L.N)) return GPTQ_E_SHAPE;
+    if (gptq_layer_decode_attn_supported(layer, batch, heads, head_dim) != 1) return GPTQ_E_VARIANT;
+    if (L.bias && residual) return GPTQ_E_VARIANT;                  // one add slot per launch
+    if (!aligned(attn_workspace, 16) || !aligned(y, 16) || ldy % 8 != 0 || (residual && (!aligned(residual, 16) || ldr % 8 != 0))) return GPTQ_E_ALIGN;
+    if (attn_workspace_bytes < decode_attn_ws_bytes(heads, t_max, batch)) return GPTQ_E_WORKSPACE;
+    const int S = decode_attn_grid_splits(heads, t_max, batch);
+    AttnMerge am{};
+    am.o16 = (const half_t *)attn_workspace;
+    am.md = (const float *)(am.o16 + (size_t)batch * S * heads * 128);
+    am.pos = positions;
+    am.S = S;
+    am.tps = tokens_per_split > 0 ? tokens_per_split : decode_attn_tps(true);
+    am.heads = heads;
+    am.t_max = t_max;
+    const void *add = residual ? residual : L.bias;
+    return stripe_matvec(attn_workspace, L.K, L.stripe, L.stripe_bytes, add, y, ldy, nullptr, 1, L.K, L.N, L.bits, L.groupsize, 1, nullptr, 0.f, nullptr, stream,
+                         nullptr, 0, false, residual ? ldr : 0, nullptr, &am);
 }
 
 // ---- GPTQ solver: the sequential loop of one column block (gptq_solver.hip) ----

@@ -6,14 +6,16 @@
 // a preallocated [t_max, heads*head_dim] buffer (no torch.cat, no shape change per token).
 //
 // HBM-bound elementwise / reduction work (K,V rows are read once per token): no MFMA.
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
+#include "attn_split.h"
 #include "gptq_device.h"
 #include "gptq_internal.h"
 
 namespace gptq {
 
-int decode_attn_ts_grid(int t_max, int batch);
 
 // Cross-lane reductions on the VALU (DPP row operations + gfx950 permlane swaps) instead of __shfl_xor, which hipcc lowers to
 // ds_bpermute_b32: ~120 cycles of LDS round trip per dependent step -- the per-wave stamps (tools/timeline_attn.py) showed 3500
@@ -91,7 +93,6 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(half_t *__restrict__ qkv, 
 // exit at once.  Partial = {max, sum, acc[128]} in fp32; attn_combine_kernel merges the splits.
 // ---------------------------------------------------------------------------------------
 constexpr int ATT_TS = 128;   // timesteps per split
-constexpr int ATT_LONG = 1024; // contexts above this many tokens run 64-step splits when the grid was launched for them (batch 1)
 constexpr int ATT_HD = 128;   // head_dim served
 constexpr int ATT_REC = ATT_HD + 2;
 
@@ -188,258 +189,318 @@ __global__ void __launch_bounds__(ATT_HD) attn_combine_kernel(const float *__res
 
 
 // ---------------------------------------------------------------------------------------
-// One launch per layer: RoPE(q, k) + KV append + single-query attention + split merge.
-// Every active split rotates q itself (128 values); the split that owns row `pos` also rotates k,
-// appends k,v to the cache and takes that row from LDS (no read-after-write through memory).
-// With more than one active split the partial records are published with system-scope
-// (write-through) stores, drained, and a per-head arrival ticket elects the last split to merge
-// them (MI355X_MICROARCH.md, "Valid forms": sc0 sc1 stores AND loads, flag behind vmcnt(0)).
-// ws = [batch][heads][nsplit][ATT_REC] floats followed by [batch][heads] uint32 tickets (zero between launches).
-// Round 5: blockIdx.y = row of a decode BATCH (blockIdx.z = split: see the note on the dispatch order below) -- every row has its own position (sequences of different lengths; a left-padded prompt is
-// stored without its pads, see quant/engine_hook.py), its own [t_max][heads * 128] slice of the K / V cache, its own qkv row (stride ldq)
-// and output row (stride ldo).  A negative position marks an idle row: nothing is read or written for it.
+// One launch per layer: RoPE(q, k) + KV append + single-query attention (fused_attn.py:126-155 as ONE kernel).
+//
+// Round 6: a STREAMING kernel.  grid = (heads, rows of the decode batch, S splits); the number of ACTIVE splits of a row and their ranges follow
+// from the row's length at run time (attn_split.h: tokens-per-split target `tps`, at most S) -- rounds 2-5 cut fixed 128-step splits, so every
+// context above 128 tokens paid the cross-workgroup merge (records published write-through, ticket, last arriver re-reads: 5.5 us per layer,
+// 925 -> 795 tok/s between 0 and 500 tokens of context).  Now a split walks its range in tiles of 32 NW timesteps:
+//   * K / V rows by buffer loads (16 bytes per lane: 16 lanes = one 256-byte head row, four rows per wave instruction); the descriptor ends at the
+//     split's last old row, so lanes past it read zeros without touching memory -- no clamps, no branches in the load phase; the NEXT tile is
+//     requested before the current one is used (two register sets, counted vmcnt across the loop);
+//   * every WAVE keeps its own online-softmax state {M, l, acc} for the timesteps it owns (scores summed over 16 lanes with DPP row operations, the
+//     tile maximum over the wave's four rows with permlane swaps): no LDS traffic and no barrier inside the loop; q . k and p . v are
+//     v_fma_mix_f32 (fp16 operand, fp32 accumulate: one VALU per multiply-add, no conversions); exponentials in the log2 domain (v_exp_f32);
+//   * the new token (k rotated here, v) is taken from LDS by wave 0 of the split that owns position `pos` and appended to the cache at the end;
+//   * the NW waves meet once, through LDS: {M, den, num[128]} of the split.
+// What happens to that record (template REC / run time):
+//   one active split, !REC  -> out = fp16(num / den), done (every context up to `tps` tokens; every decode batch of three or more rows);
+//   REC                     -> the record is stored (plain stores) for the NEXT launch to merge: o_proj's decode kernel stages x from the records
+//                              of up to ATT_MAX_SPLITS splits (stripe_kernel.inc, ATT instances) -- the kernel boundary is the hand-off;
+//   several splits, !REC    -> records go out with system-scope stores, an arrival ticket per (row, head) elects the last split, which merges
+//                              them (callers without a merging consumer; act-order o_proj with the producer-side permutation).
+// ws = [batch][S][heads * 128] fp16 partial outputs | [batch][S][heads] fp32 {M, den} | [batch][heads] uint32 tickets (zero between launches).
+// A negative position marks an idle row of the batch: nothing is read or written for it.
 // ---------------------------------------------------------------------------------------
-// Dispatch order (round 5): workgroups are issued x fastest, then y, then z.  With grid (heads, splits, rows) the ONE active split of a short
-// context sat between 15 idle ones per row -- a batch of 16 rows at t_max = 2048 issues 8 192 workgroups of which 7 680 load `pos` and leave, and row 15's
-// active workgroups came after 7 680 others (four rounds of resident workgroups, each a memory round trip: 8.1 us per launch at 16 rows against 5.1
-// at one).  Grid (heads, rows, splits): every row's FIRST split is issued first, the idle ones drain behind the work.
-__global__ void __launch_bounds__(256) attn_decode_fused_kernel(const half_t *__restrict__ qkv, const int64_t *__restrict__ pos_ptr,
-                                                                half_t *__restrict__ kc, half_t *__restrict__ vc,
-                                                                half_t *__restrict__ out, float *__restrict__ ws, int heads, int t_max,
-                                                                float inv_base, float scale, const float2 *__restrict__ rope_tab,
-                                                                u64_t *__restrict__ dbg, int ldq, int ldo, int ts_grid, const int32_t *__restrict__ out_perm) {
-    {   // this workgroup's row of the batch
-        const int b = blockIdx.y;
-        const size_t hdz = (size_t)heads * ATT_HD;
-        pos_ptr += b;
-        qkv += (size_t)b * ldq;
-        out += (size_t)b * ldo;
-        kc += (size_t)b * t_max * hdz;
-        vc += (size_t)b * t_max * hdz;
-        if (b) dbg = nullptr;   // (development stamps: row 0 only)
-    }
-    float *const ws_tickets = ws + (size_t)gridDim.y * heads * gridDim.z * ATT_REC;
-    ws += (size_t)blockIdx.y * heads * gridDim.z * ATT_REC;
-    u64_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u64_t sx_[4] = {0, 0, 0, 0};   // development stamps (gptq_set_debug_buffer, tools/timeline_attn.py)
-    if (dbg) { st_[0] = stamp_realtime(); st_[1] = stamp_cycles(0); }
+struct AttnArgs {
+    const half_t *qkv;
+    const int64_t *pos;
+    half_t *kc, *vc, *out;
+    half_t *o16;                 // records: [batch][S][heads * 128] fp16 partial outputs
+    float *md;                   //          [batch][S][heads] {M, den}
+    unsigned *tickets;
+    const float2 *rope_tab;
+    const int32_t *out_perm;
+    int heads, t_max, ldq, ldo, tps;
+    float inv_base, scale2;      // scale2 = softmax scale x log2(e): scores live in the log2 domain
+};
+
+GPTQ_DEV u32x4 att_load16(__amdgpu_buffer_rsrc_t r, int voff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
+template <int NW, bool REC>
+__global__ void __launch_bounds__(NW * 64) attn_stream_kernel(const AttnArgs a) {
+    constexpr int TILE = NW * 32, RP = NW * 4;   // timesteps per tile / per pass of the workgroup (16 lanes per timestep)
+    constexpr int NP = 8;                        // passes per tile = 16-byte K (and V) loads per lane and tile
     __shared__ float qs[ATT_HD];
     __shared__ __attribute__((aligned(16))) half_t knew[ATT_HD];
     __shared__ __attribute__((aligned(16))) half_t vnew[ATT_HD];
-    __shared__ float sc[ATT_TS];
-    __shared__ float accs[4][ATT_HD];
+    __shared__ __attribute__((aligned(16))) float accs[NW][ATT_HD];
+    __shared__ float mw[NW], lw[NW];
     __shared__ int last_flag;
-    const int h = blockIdx.x, nsplit = gridDim.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y, s = blockIdx.z, S = gridDim.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hd = a.heads * ATT_HD;
     // out_perm (round 5): o_proj is an act-order layer whose image holds group-sorted rows -- element k of the attention output goes where its sorted
     // order wants it, so o_proj runs the trivial kernel.  Requested first: nothing depends on it until the store.
-    const int ocol = (tid < ATT_HD) ? (out_perm ? out_perm[h * ATT_HD + tid] : h * ATT_HD + tid) : 0;
-    const int64_t pos = pos_ptr[0];
-    if (dbg) st_[2] = stamp_cycles((uint32_t)pos);
-    if (pos < 0 || pos >= t_max) return;
-    const int len = (int)pos + 1;
-    // Round 5: the split length can be chosen at RUN time.  The grid is fixed when the step is captured (ts_grid = 128, or -- an A/B knob, see
-    // decode_attn_ts_grid: measured, slower, off by default -- 64 for a batch-1 launch: twice the workgroups); with the 64-step grid a launch whose
-    // context is at most ATT_LONG tokens folds two grid splits into one 128-step split (odd grid splits leave at once), a longer one keeps
-    // 64-step splits: 24 workgroups per head stream K / V at 1500 tokens instead of 12.
-    int s = blockIdx.z, ts = ATT_TS;
-    if (ts_grid == ATT_TS / 2) {
-        if (len > ATT_LONG) ts = ATT_TS / 2;
-        else if (s & 1) return;
-        else s >>= 1;
+    const int ocol = (!REC && tid < ATT_HD) ? (a.out_perm ? a.out_perm[h * ATT_HD + tid] : h * ATT_HD + tid) : 0;
+    // this row's q / k / v halves of the head: they depend on nothing but the grid, so they are requested BEFORE the position is known (the
+    // row was written by the previous launch on other XCDs: a fabric round trip that now runs under the scalar load of `pos`)
+    const half_t *qrow = a.qkv + (size_t)b * a.ldq;
+    half_t q0 = (half_t)0, q1 = (half_t)0, k0 = (half_t)0, k1 = (half_t)0, nv0 = (half_t)0, nv1 = (half_t)0;
+    if (tid < ATT_HD / 2) {
+        const half_t *q = qrow + (size_t)h * ATT_HD + tid;
+        q0 = q[0]; q1 = q[ATT_HD / 2];
+        k0 = q[hd]; k1 = q[hd + ATT_HD / 2];
+        nv0 = q[2 * hd]; nv1 = q[2 * hd + ATT_HD / 2];
     }
-    const int t0 = s * ts;
-    if (t0 >= len) return;
-    const int nact = (len - t0) < ts ? (len - t0) : ts;
-    const int nsp = (len + ts - 1) / ts;                 // active splits of this head
-    const bool own_new = (int)pos >= t0 && (int)pos < t0 + ts;
-    const int hd = heads * ATT_HD;
-    const int tnew = own_new ? (int)pos - t0 : -1;
+    // (through the scalar cache: constant address space -- inside a by-value struct the pointer carries no noalias, and hipcc made it a vector load)
+    const int64_t pos64 = ((const __attribute__((address_space(4))) int64_t *)a.pos)[b];
+    if (pos64 < 0 || pos64 >= a.t_max) return;
+    const int pos = (int)pos64, len = pos + 1;
+    const AttnSplit sp = attn_split(len, S, a.tps);
+    if (s >= sp.nsp) return;
+    const int t0 = s * sp.chunk;
+    const int t_end = min(t0 + sp.chunk, len);   // this split attends to rows [t0, t_end)
+    const bool owner = t_end == len;             // ... the last of which is the new token: this split rotates k, appends k / v, takes that row from LDS
+    const int n_old = min(t_end, pos);           // cache rows of this split: [t0, n_old)
+    const int ntiles = (t_end - t0 + TILE - 1) / TILE;   // >= 1
     const int d8 = tid & 15, tsub = tid >> 4;
 
-    // every cache row this thread will need is requested NOW (they depend on nothing but pos), so the
-    // RoPE trig below and the two softmax barriers run under the memory latency instead of after it
-    half8_t kpre[ATT_TS / 16];
+    // descriptors over rows [0, n_old) of this (row, head): anything past the split's last cache row reads as zero, without a memory request
+    const size_t slice = ((size_t)b * a.t_max) * hd + (size_t)h * ATT_HD;
+    const int nrec = n_old > 0 ? ((n_old - 1) * hd + ATT_HD) * 2 : 0;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(a.kc + slice), 0, nrec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(a.vc + slice), 0, nrec, 0x00020000);
+    const int hd2 = hd * 2;
+    u32x4 KA[NP], VA[NP], KB[NP], VB[NP];
+    auto load = [&](u32x4 (&K)[NP], u32x4 (&V)[NP], int tb) {
+        const int vo = (tb + tsub) * hd2 + d8 * 16;
 #pragma unroll
-    for (int it = 0; it < ATT_TS / 16; it++) {
-        const int tl = it * 16 + tsub;
-        kpre[it] = (tl < nact && tl != tnew) ? *(const half8_t *)(kc + (size_t)(t0 + tl) * hd + (size_t)h * ATT_HD + d8 * 8)
-                                              : (half8_t)(half_t)0;
-    }
-    half8_t vpre[ATT_TS / 16];   // same (timestep, 8-dim slice) map as K: 16-byte loads, 4 rows per wave instruction
+        for (int it = 0; it < NP; it++) K[it] = att_load16(rk, vo + it * RP * hd2);
 #pragma unroll
-    for (int it = 0; it < ATT_TS / 16; it++) {
-        const int tl = it * 16 + tsub;
-        vpre[it] = (tl < nact && tl != tnew) ? *(const half8_t *)(vc + (size_t)(t0 + tl) * hd + (size_t)h * ATT_HD + d8 * 8)
-                                              : (half8_t)(half_t)0;
+        for (int it = 0; it < NP; it++) V[it] = att_load16(rv, vo + it * RP * hd2);
+    };
+    // a context of up to two passes (8 NW timesteps: the first tokens of a sequence) requests and computes two passes, not eight
+    const bool tiny = t_end - t0 <= 2 * RP;
+    if (tiny) {
+        const int vo = (t0 + tsub) * hd2 + d8 * 16;
+        KA[0] = att_load16(rk, vo);
+        KA[1] = att_load16(rk, vo + RP * hd2);
+        VA[0] = att_load16(rv, vo);
+        VA[1] = att_load16(rv, vo + RP * hd2);
+    } else {
+        load(KA, VA, t0);
     }
+    __builtin_amdgcn_sched_barrier(0);
 
-    half_t nk0 = (half_t)0, nk1 = (half_t)0, nv0 = (half_t)0, nv1 = (half_t)0;   // the new token's K / V halves of this thread
+    // ---- RoPE of q (every split) and of the new k (owner) under the latency of the first tile ----
+    half_t nk0 = (half_t)0, nk1 = (half_t)0;
     if (tid < ATT_HD / 2) {
         const int c = tid;
         float cs, sn;
-        if (rope_tab) {   // {cos, sin} of (pos, c) from the table rope_table_kernel filled with the SAME instructions: one load under
-            const float2 e = rope_tab[(size_t)pos * (ATT_HD / 2) + c];   // the K/V latency instead of ~1 us of accurate-libm range reduction
+        if (a.rope_tab) {   // {cos, sin} of (pos, c) from the table rope_table_kernel filled with the SAME instructions
+            const float2 e = a.rope_tab[(size_t)pos * (ATT_HD / 2) + c];
             cs = e.x;
             sn = e.y;
         } else {
-            const float freq = expf((float)c * inv_base) * (float)pos;
+            const float freq = expf((float)c * a.inv_base) * (float)pos;
             cs = cosf(freq);
             sn = sinf(freq);
         }
-        const half_t *q = qkv + (size_t)h * ATT_HD + c;
-        const float qx = (float)q[0], qy = (float)q[ATT_HD / 2];
-        qs[c] = (float)(half_t)(qx * cs - qy * sn);       // rounded to fp16 like the in-place reference RoPE
+        const float qx = (float)q0, qy = (float)q1;
+        qs[c] = (float)(half_t)(qx * cs - qy * sn);       // rounded to fp16 like the in-place reference RoPE (fused_attn.py:43-57)
         qs[c + ATT_HD / 2] = (float)(half_t)(qx * sn + qy * cs);
-        if (own_new) {
-            const half_t *k = qkv + hd + (size_t)h * ATT_HD + c;
-            const half_t *v = qkv + 2 * hd + (size_t)h * ATT_HD + c;
-            const float kx = (float)k[0], ky = (float)k[ATT_HD / 2];
-            const half_t k0 = (half_t)(kx * cs - ky * sn), k1 = (half_t)(kx * sn + ky * cs);
-            nk0 = k0; nk1 = k1; nv0 = v[0]; nv1 = v[ATT_HD / 2];
+        if (owner) {
+            const float kx = (float)k0, ky = (float)k1;
+            nk0 = (half_t)(kx * cs - ky * sn);
+            nk1 = (half_t)(kx * sn + ky * cs);
             knew[c] = nk0;
             knew[c + ATT_HD / 2] = nk1;
             vnew[c] = nv0;
             vnew[c + ATT_HD / 2] = nv1;
-            // the cache row itself is written AFTER the last load of this launch has been consumed (below): hipcc waits vmcnt(0)
-            // before every use of the prefetched rows (they sit behind branches), and a store in flight made each of those waits
-            // a full write latency -- 1500 of the launch's 8000 cycles (tools/timeline_attn.py)
         }
     }
     __syncthreads();
-    if (dbg) st_[3] = stamp_cycles(0);
     float qf[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) qf[j] = qs[d8 * 8 + j];
-    if (dbg) sx_[0] = stamp_cycles(__builtin_bit_cast(uint32_t, qf[7]));
-    const int nit = (nact + 15) / 16;   // 16-timestep groups that hold anything: a short context does not pay for 128 rows
-#pragma unroll
-    for (int it = 0; it < ATT_TS / 16; it++) {
-        const int tl = it * 16 + tsub;
-        if (it >= nit) {                // wave-uniform
-            if (d8 == 0) sc[tl] = -INFINITY;
-            continue;
-        }
-        float dot = 0.f;
-        if (tl < nact) {
-            half8_t k8 = kpre[it];
-            if (tl == tnew) k8 = *(const half8_t *)(knew + d8 * 8);
-#pragma unroll
-            for (int j = 0; j < 8; j++) dot += qf[j] * (float)k8[j];
-        }
-        dot = att_sum16(dot);
-        if (d8 == 0) sc[tl] = (tl < nact) ? dot * scale : -INFINITY;
-    }
-    if (dbg) sx_[1] = stamp_cycles(0);
-    __syncthreads();
-    if (dbg) st_[4] = stamp_cycles(0);
-    // softmax statistics WITHOUT another barrier (round 4; there were three more here: max through red[], the probabilities written back over
-    // sc[], their sum through red[]): every wave reads all ATT_TS scores (two per lane), reduces max and sum of exp on its own with DPP /
-    // permlane steps -- four redundant copies of 128 values cost less than one LDS round trip + barrier -- and the P V loop below turns the
-    // scores it needs into probabilities itself (eight v_exp per thread).  Empty slots hold -inf: exp -> 0.
-    const float s0 = sc[lane], s1 = sc[lane + 64];
-    const float m = att_wave_max(fmaxf(s0, s1));
-    const float l = att_wave_sum(__expf(s0 - m) + __expf(s1 - m));
-    if (dbg) st_[5] = stamp_cycles(__builtin_bit_cast(uint32_t, l));
 
-    float av[8];
+    // ---- the wave's running state: M (log2 domain), l and acc[8 dims of this lane] relative to M ----
+    float M = ATT_M_FLOOR, l = 0.f, av[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) av[j] = 0.f;
+    auto scores8 = [&](const u32x4 k) {
+        const half8_t k8 = __builtin_bit_cast(half8_t, k);
+        float dot = 0.f;
 #pragma unroll
-    for (int it = 0; it < ATT_TS / 16; it++) {
-        const int tl = it * 16 + tsub;
-        if (it < nit && tl < nact) {
-            half8_t v8 = vpre[it];
-            if (tl == tnew) v8 = *(const half8_t *)(vnew + d8 * 8);
-            const float pt = __expf(sc[tl] - m);
+        for (int j = 0; j < 8; j++) dot = __builtin_fmaf(qf[j], (float)k8[j], dot);
+        return att_sum16(dot) * a.scale2;
+    };
+    auto tile_full = [&](const u32x4 (&K)[NP], const u32x4 (&V)[NP]) {
+        float sc[NP];
 #pragma unroll
-            for (int j = 0; j < 8; j++) av[j] += pt * (float)v8[j];
+        for (int it = 0; it < NP; it++) sc[it] = scores8(K[it]);
+        float mt = sc[0];
+#pragma unroll
+        for (int it = 1; it < NP; it++) mt = fmaxf(mt, sc[it]);
+        mt = att_rows_max(mt);                                   // the wave's four rows: M stays wave-uniform
+        const float Mn = fmaxf(M, mt), alpha = __builtin_amdgcn_exp2f(M - Mn);
+        float p[NP], ps = 0.f;
+#pragma unroll
+        for (int it = 0; it < NP; it++) {
+            p[it] = __builtin_amdgcn_exp2f(sc[it] - Mn);
+            ps += p[it];
+        }
+        l = __builtin_fmaf(l, alpha, ps);
+#pragma unroll
+        for (int j = 0; j < 8; j++) av[j] *= alpha;
+#pragma unroll
+        for (int it = 0; it < NP; it++) {
+            const half8_t v8 = __builtin_bit_cast(half8_t, V[it]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) av[j] = __builtin_fmaf(p[it], (float)v8[j], av[j]);
+        }
+        M = Mn;
+    };
+    // the split's last tile (PASSES = NP), or a tiny context (PASSES = 2): rows past t_end are masked, and the lanes that hold position `pos`
+    // take that row's k / v from LDS (the new token is not in the cache yet).  Straight-line code: masks and selects, no branches.
+    auto tile_last = [&](const u32x4 (&K)[NP], const u32x4 (&V)[NP], int tb, auto passes) {
+        constexpr int PASSES = decltype(passes)::value;
+        u32x4 kn = u32x4{0u, 0u, 0u, 0u}, vn = u32x4{0u, 0u, 0u, 0u};
+        if (owner) {
+            kn = *(const u32x4 *)(knew + d8 * 8);
+            vn = *(const u32x4 *)(vnew + d8 * 8);
+        }
+        float sc[PASSES];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int it = 0; it < PASSES; it++) {
+            const int t = tb + it * RP + tsub;
+            const bool isnew = owner && t == pos;
+            const float v = scores8(isnew ? kn : K[it]);
+            sc[it] = t < t_end ? v : -INFINITY;
+            mt = fmaxf(mt, sc[it]);
+        }
+        mt = att_rows_max(mt);
+        const float Mn = fmaxf(M, mt), alpha = __builtin_amdgcn_exp2f(M - Mn);
+        float p[PASSES], ps = 0.f;
+#pragma unroll
+        for (int it = 0; it < PASSES; it++) {
+            p[it] = __builtin_amdgcn_exp2f(sc[it] - Mn);         // masked slots hold -inf: 0
+            ps += p[it];
+        }
+        l = __builtin_fmaf(l, alpha, ps);
+#pragma unroll
+        for (int j = 0; j < 8; j++) av[j] *= alpha;
+#pragma unroll
+        for (int it = 0; it < PASSES; it++) {
+            const bool isnew = owner && tb + it * RP + tsub == pos;
+            const half8_t v8 = __builtin_bit_cast(half8_t, isnew ? vn : V[it]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) av[j] = __builtin_fmaf(p[it], (float)v8[j], av[j]);
+        }
+        M = Mn;
+    };
+    auto tile = [&](const u32x4 (&K)[NP], const u32x4 (&V)[NP], int tb) {
+        if (tb + TILE <= n_old) tile_full(K, V);                 // all of its rows are cache rows of this split
+        else tile_last(K, V, tb, std::integral_constant<int, NP>());
+    };
+    if (tiny) {
+        tile_last(KA, VA, t0, std::integral_constant<int, 2>());
+    } else if (ntiles == 1) {    // every context up to a tile: one register set, no loop
+        tile(KA, VA, t0);
+    } else {
+        for (int i = 0; i < ntiles; i += 2) {
+            load(KB, VB, t0 + (i + 1) * TILE);                   // (past the split's rows: zeros, no traffic)
+            __builtin_amdgcn_sched_barrier(0);
+            tile(KA, VA, t0 + i * TILE);
+            __builtin_amdgcn_sched_barrier(0);
+            load(KA, VA, t0 + (i + 2) * TILE);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < ntiles) tile(KB, VB, t0 + (i + 1) * TILE);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (dbg) sx_[2] = stamp_cycles(__builtin_bit_cast(uint32_t, av[0]));
-    if (own_new && tid < ATT_HD / 2) {   // append the new token's row to the cache (nothing in this launch reads it back: it came from LDS)
-        half_t *kd = kc + (size_t)pos * hd + (size_t)h * ATT_HD + tid;
-        half_t *vd = vc + (size_t)pos * hd + (size_t)h * ATT_HD + tid;
+    if (owner && tid < ATT_HD / 2) {   // append the new token's row to the cache (nothing in this launch reads it back: it came from LDS), after
+        half_t *kd = a.kc + slice + (size_t)pos * hd + tid;   // the last cache load of this workgroup has been consumed
+        half_t *vd = a.vc + slice + (size_t)pos * hd + tid;
         kd[0] = nk0;
         kd[ATT_HD / 2] = nk1;
         vd[0] = nv0;
         vd[ATT_HD / 2] = nv1;
     }
-    // the 4 timestep groups of a wave (lane >> 4), then the 4 waves through LDS
+
+    // ---- the wave's four rows -> one, the NW waves -> one (LDS): {Mx, den, num[tid]} of the split ----
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        av[j] = att_rows_sum(av[j]);
-    }
+    for (int j = 0; j < 8; j++) av[j] = att_rows_sum(av[j]);
+    l = att_rows_sum(l);
     if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) accs[wave][lane * 8 + j] = av[j];
+        *(float4_t *)(&accs[wave][lane * 8]) = float4_t{av[0], av[1], av[2], av[3]};
+        *(float4_t *)(&accs[wave][lane * 8 + 4]) = float4_t{av[4], av[5], av[6], av[7]};
+    }
+    if (lane == 0) {
+        mw[wave] = M;
+        lw[wave] = l;
     }
     __syncthreads();
-    float acc = 0.f;
-    if (tid < ATT_HD) acc = accs[0][tid] + accs[1][tid] + accs[2][tid] + accs[3][tid];
-
-    if (nsp == 1) {  // short context: this workgroup is the whole head
-        if (tid < ATT_HD) out[ocol] = (half_t)(acc / l);
-        if (dbg && lane == 0) {
-            st_[6] = stamp_cycles(__builtin_bit_cast(uint32_t, acc));
-            const u64_t te = stamp_realtime();
-            u64_t *d = dbg + ((size_t)h * 4 + wave) * 10;
+    float Mx = mw[0];
 #pragma unroll
-            for (int i = 0; i < 7; i++) d[i] = st_[i];
-            d[8] = te;
-            d[7] = sx_[0] - st_[1]; d[9] = ((sx_[1] - st_[1]) << 32) | (uint32_t)(sx_[2] - st_[1]);
+    for (int w = 1; w < NW; w++) Mx = fmaxf(Mx, mw[w]);
+    float num = 0.f, den = 0.f;
+    if (tid < ATT_HD) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const float e = __builtin_amdgcn_exp2f(mw[w] - Mx);
+            num = __builtin_fmaf(e, accs[w][tid], num);
+            den = __builtin_fmaf(e, lw[w], den);
         }
+    }
+    const half_t o = attn_round_f16(num * __builtin_amdgcn_rcpf(den));   // the split's normalised output (one split: the row itself)
+    if constexpr (REC) {     // the consumer merges (also a single split: it always reads records)
+        if (tid < ATT_HD) a.o16[((size_t)b * S + s) * hd + h * ATT_HD + tid] = o;
+        if (tid == 0) *(float2 *)(a.md + (((size_t)b * S + s) * a.heads + h) * 2) = float2{Mx, den};
         return;
     }
-    float *rec = ws + ((size_t)h * nsplit + s) * ATT_REC;
-    if (tid < ATT_HD) __hip_atomic_store(rec + 2 + tid, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (sp.nsp == 1) {       // this workgroup is the whole head
+        if (tid < ATT_HD) a.out[(size_t)b * a.ldo + ocol] = o;
+        return;
+    }
+    // ---- several splits and no merging consumer: system-scope records, arrival ticket, the last split merges ----
+    half_t *ro = a.o16 + ((size_t)b * S) * hd + h * ATT_HD;
+    float *rmd = a.md + (((size_t)b * S) * a.heads + h) * 2;
+    if (tid < ATT_HD) __hip_atomic_store((uint16_t *)(ro + (size_t)s * hd + tid), __builtin_bit_cast(uint16_t, o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (tid == 0) {
-        __hip_atomic_store(rec + 0, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(rec + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(rmd + (size_t)s * a.heads * 2, Mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(rmd + (size_t)s * a.heads * 2 + 1, den, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    unsigned *ticket = (unsigned *)ws_tickets + (size_t)blockIdx.y * heads + h;
+    unsigned *ticket = a.tickets + (size_t)b * a.heads + h;
     if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (t == (unsigned)(nsp - 1));
+        const int last = (t == (unsigned)(sp.nsp - 1));
         if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = last;
     }
     __syncthreads();
     if (!last_flag) return;
-    if (tid < ATT_HD) {
-        // the records of up to 16 splits are requested TOGETHER (48 independent system-scope loads, one memory latency): fetched one
-        // after the other, as the first version did, the merge cost 2 nsp dependent round trips -- 13 us of the 18.6 us this launch
-        // took at 1500 tokens of context.  Running {max, num, den} rescaled between batches of 16 (t_max > 2048).
-        const float *base = ws + (size_t)h * nsplit * ATT_REC;
-        float Mx = -INFINITY, num = 0.f, den = 0.f;
-        for (int i0 = 0; i0 < nsp; i0 += 16) {
-            float mi[16], li[16], ai[16];
+    if (tid < ATT_HD) {      // the records of all splits requested together (one memory latency), merged in split order
+        float mi[ATT_MAX_SPLITS], di[ATT_MAX_SPLITS];
+        half_t oi[ATT_MAX_SPLITS];
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const float *r = base + (size_t)min(i0 + i, nsp - 1) * ATT_REC;
-                mi[i] = __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                li[i] = __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                ai[i] = __hip_atomic_load(r + 2 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            float mb = Mx;
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                if (i0 + i < nsp) mb = fmaxf(mb, mi[i]);
-            const float resc = __expf(Mx - mb);   // 0 for the first batch (Mx = -inf), then the usual running-softmax rescale
-            num *= resc;
-            den *= resc;
-            Mx = mb;
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                if (i0 + i < nsp) {
-                    const float w = __expf(mi[i] - Mx);
-                    num += w * ai[i];
-                    den += w * li[i];
-                }
+        for (int i = 0; i < ATT_MAX_SPLITS; i++) {
+            const int ii = min(i, sp.nsp - 1);
+            mi[i] = __hip_atomic_load(rmd + (size_t)ii * a.heads * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            di[i] = __hip_atomic_load(rmd + (size_t)ii * a.heads * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint16_t u = __hip_atomic_load((const uint16_t *)(ro + (size_t)ii * hd + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            oi[i] = __builtin_bit_cast(half_t, u);
         }
-        out[ocol] = (half_t)(num / den);
+        float c[ATT_MAX_SPLITS];
+        attn_merge_coeffs(mi, di, sp.nsp, c);
+        a.out[(size_t)b * a.ldo + ocol] = attn_round_f16(attn_merge_value(oi, c));
     }
 }
 
@@ -458,15 +519,46 @@ int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, cons
     return (int)hipGetLastError();
 }
 
+// S of a launch's grid: enough workgroups to stream K / V at the chip's rate once a context is long (about 128 of them: a CU keeps ~36 KB of loads
+// in flight, i.e. ~80 GB/s against a quiet HBM), never more than ATT_MAX_SPLITS (what a merging consumer reads) -- heads x rows x S ~ 128.
+// GPTQ_ATTN_SPLITS pins it (A/B).
+int decode_attn_grid_splits(int heads, int t_max, int batch) {
+    static const int pin = [] { const char *e = getenv("GPTQ_ATTN_SPLITS"); return e ? atoi(e) : 0; }();
+    static const int wgs = [] { const char *e = getenv("GPTQ_ATTN_WGS"); return e ? atoi(e) : 256; }();
+    int S = pin > 0 ? pin : wgs / std::max(1, heads * batch);
+    S = std::min(std::max(S, 1), ATT_MAX_SPLITS);
+    return std::min(S, (t_max + ATT_TILE - 1) / ATT_TILE);
+}
+
+// tokens a split owns at least.  With a merging consumer a further split costs one more record per x piece of o_proj's staging (~0.1 us): cut as
+// soon as a tile is full.  With the in-kernel merge it costs the ticket's dependent round trips (~4-5 us): one workgroup per head up to
+// ~768 tokens.  GPTQ_ATTN_TPS_REC / GPTQ_ATTN_TPS override (A/B).
+int decode_attn_tps(bool rec) {
+    static const int t_rec = [] { const char *e = getenv("GPTQ_ATTN_TPS_REC"); return e ? atoi(e) : 128; }();
+    static const int t_own = [] { const char *e = getenv("GPTQ_ATTN_TPS"); return e ? atoi(e) : 768; }();
+    return std::max(1, rec ? t_rec : t_own);
+}
+
+// rec: leave the records to the next launch (out is not written); tps <= 0: the default of the mode
 int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
-                             float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s, int batch, int64_t ldq, int64_t ldo,
-                             const int32_t *out_perm) {
-    // batch 1 and a cache that can hold a long context: a grid of 64-step splits (the kernel folds pairs of them below ATT_LONG tokens)
-    const int ts_grid = decode_attn_ts_grid(t_max, batch);
-    const int nsplit = (t_max + ts_grid - 1) / ts_grid;
-    const float inv_base = -2.0f * logf(base) / (float)ATT_HD;
-    hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(heads, batch, nsplit), dim3(256), 0, s, qkv, pos, kc, vc, out, ws, heads, t_max, inv_base,
-                       scale, (const float2 *)rope_table, dbg, (int)ldq, (int)ldo, ts_grid, out_perm);
+                             float base, float scale, const float *rope_table, hipStream_t s, int batch, int64_t ldq, int64_t ldo,
+                             const int32_t *out_perm, bool rec, int tps) {
+    const int S = decode_attn_grid_splits(heads, t_max, batch);
+    AttnArgs a{};
+    a.qkv = qkv; a.pos = pos; a.kc = kc; a.vc = vc; a.out = out;
+    a.o16 = (half_t *)ws;
+    a.md = (float *)((half_t *)ws + (size_t)batch * S * heads * ATT_HD);
+    a.tickets = (unsigned *)(a.md + (size_t)batch * S * heads * 2);
+    a.rope_tab = (const float2 *)rope_table;
+    a.out_perm = out_perm;
+    a.heads = heads; a.t_max = t_max; a.ldq = (int)ldq; a.ldo = (int)ldo;
+    a.tps = tps > 0 ? tps : decode_attn_tps(rec);
+    a.inv_base = -2.0f * logf(base) / (float)ATT_HD;   // reference fused_attn.py:91
+    a.scale2 = scale * 1.44269504088896340736f;
+    const dim3 grid(heads, batch, S);
+    // (four waves: eight -- two per SIMD, 256-step tiles -- measured the same within noise at every depth, gpurun_out r6a / r6b, and spill)
+    if (rec) hipLaunchKernelGGL((attn_stream_kernel<4, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_stream_kernel<4, false>), grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -484,18 +576,13 @@ int rope_table_launch(float *table, int t_max, int head_dim, float base, hipStre
     return (int)hipGetLastError();
 }
 
-int decode_attn_ts_grid(int t_max, int batch) {
-    // MEASURED AND OFF (gpurun_out r5f / profiles/r5*/engine_context.txt, tok/s of the 7B engine at 0 / 500 / 1000 / 1500 / 1900 tokens of context):
-    // 64-step splits 922 / 784 / 746 / 699 / 671 against 925 / 795 / 763 / 749 / 720 for 128-step splits -- twice the workgroups per head mean twice
-    // the records in the merge and twice the tickets, and the K / V stream of a head was not short of parallelism: the launch is bound by the
-    // dependent round trips of the merge, not by the splits.  GPTQ_ATTN_LONG_SPLITS=1 switches the 64-step grid on for A/B runs.
-    static const int long_splits = [] { const char *e = getenv("GPTQ_ATTN_LONG_SPLITS"); return e ? atoi(e) : 0; }();
-    return (batch == 1 && t_max > ATT_LONG && long_splits) ? ATT_TS / 2 : ATT_TS;
-}
-
+// records of the streaming kernel [batch][S][heads * 128] fp16 + [batch][S][heads][2] fp32 + tickets [batch][heads]; never less than the records of the two-launch
+// path above (batch 1: [heads][t_max / 128][130])
 size_t decode_attn_ws_bytes(int heads, int t_max, int batch) {
-    const int ts = decode_attn_ts_grid(t_max, batch);    // (the two-launch path below uses 128-step splits: never more records than this)
-    return (size_t)batch * ((size_t)heads * ((t_max + ts - 1) / ts) * ATT_REC * sizeof(float) + (size_t)heads * sizeof(unsigned));
+    const int S = decode_attn_grid_splits(heads, t_max, batch);
+    const size_t stream = (size_t)batch * ((size_t)S * heads * (ATT_HD * sizeof(half_t) + 2 * sizeof(float)) + (size_t)heads * sizeof(unsigned));
+    const size_t two = batch == 1 ? (size_t)heads * ((t_max + ATT_TS - 1) / ATT_TS) * ATT_REC * sizeof(float) : 0;
+    return std::max(stream, two);
 }
 
 }  // namespace gptq

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/gptq_mi355x.h"
+#include "attn_split.h"
 #include "gptq_device.h"
 
 #include <mutex>
@@ -125,6 +126,7 @@ struct StripeParams {
     int M, K, N, G, NS, gq_shift, bits;
     uint32_t *progress;    // non-NULL: the decode kernel adds 1 here when it starts (debug hook gptq_set_progress_counter)
     const int32_t *yperm;  // non-NULL: column n of y is stored at yperm[n] (the consumer's sorted order: decode kernel only)
+    AttnMerge att;         // att.o16 non-NULL (round 6): x is the decode attention's split records, merged while x is staged (M == 1, plain launch)
 };
 int stripe_gq_shift(int K, int N, int bits, int groupsize);            // log2(groupsize / (4 KPW)), -1 one group, -2 ineligible
 size_t stripe_tab_offset(int K, int N, int bits, int nsets);
@@ -152,9 +154,12 @@ int decode_attn_launch(const half_t *q, const half_t *kc, const half_t *vc, cons
                        int t_max, float scale, hipStream_t s);
 size_t decode_attn_ws_bytes(int heads, int t_max, int batch = 1);
 // batch rows: pos[batch], qkv rows ldq apart, out rows ldo apart, kc / vc [batch][t_max][heads * 128], ws of decode_attn_ws_bytes(heads, t_max, batch)
+// rec: the records {M, den, num[128]} of every active split are left in ws for the next launch to merge (out is not written); tps <= 0: default
 int decode_attn_fused_launch(const half_t *qkv, const int64_t *pos, half_t *kc, half_t *vc, half_t *out, float *ws, int heads, int t_max,
-                             float base, float scale, const float *rope_table, u64_t *dbg, hipStream_t s, int batch = 1, int64_t ldq = 0,
-                             int64_t ldo = 0, const int32_t *out_perm = nullptr);
+                             float base, float scale, const float *rope_table, hipStream_t s, int batch = 1, int64_t ldq = 0,
+                             int64_t ldo = 0, const int32_t *out_perm = nullptr, bool rec = false, int tps = 0);
+int decode_attn_grid_splits(int heads, int t_max, int batch);   // S of the launch grid (and of the workspace layout)
+int decode_attn_tps(bool rec);                                  // default tokens per split of the mode
 int rope_table_launch(float *table, int t_max, int head_dim, float base, hipStream_t s);
 
 }  // namespace gptq

@@ -129,6 +129,13 @@ _SIGNATURES = {
     'gptq_layer_inverse_perm': [c_void_p, c_void_p],
     'gptq_stripe_matvec_perm_out_f16': [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_float, c_void_p, c_void_p, c_void_p],
+    # round 6: streaming decode attention whose splits are merged by o_proj's decode kernel
+    'gptq_decode_attn_splits': [c_int, c_int, c_int, c_int],
+    'gptq_decode_attn_split_f16': [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_float, c_float,
+                                   c_void_p, c_int, c_void_p],
+    'gptq_layer_decode_attn_supported': [c_void_p, c_int, c_int, c_int],
+    'gptq_layer_decode_attn_f16': [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_int64,
+                                   c_void_p],
     'gptq_layer_decode_scratch_bytes': [c_void_p, c_int],
     'gptq_layer_decode_f16': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_size_t,
                               c_void_p, c_size_t, c_void_p],

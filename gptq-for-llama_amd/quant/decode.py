@@ -169,6 +169,9 @@ def benchmark_generate(model, prompt_len=16, new_tokens=128, seed=0, batch=1, le
 # The position lives in device memory and is advanced inside the graph.
 # ----------------------------------------------------------------------------------------------
 ROPE_TABLE = os.environ.get('GPTQ_ROPE_TABLE', '1') != '0'
+# round 6: the batch-1 attention launch leaves its split records to o_proj's decode kernel (gptq_decode_attn_split_f16 + gptq_layer_decode_attn_f16)
+# instead of merging them itself; 0: the self-merging launch of rounds 2-5 (A/B runs, and what every other configuration takes anyway)
+ATTN_RECORDS = os.environ.get('GPTQ_ATTN_RECORDS', '1') != '0'
 LM_HEAD_KERNEL = os.environ.get('GPTQ_LM_HEAD_KERNEL', '1') != '0'   # 0: final norm + torch.matmul (hipBLASLt) as in rounds 1-3 (A/B runs)
 
 
@@ -267,6 +270,10 @@ class DecodeEngine:
         self.ws = _native.workspace(dev)
         self.graph = None
         self.scratch = None
+        # batch 1: the attention's splits are merged by o_proj's decode kernel when every o_proj can (trivial g_idx, an image, no bias next to the residual)
+        self.attn_records = bool(ATTN_RECORDS and self.fuse_attn and B == 1 and all(
+            L['o']['st'] is not None and L['o']['bias'] is None and
+            self.lib.gptq_layer_decode_attn_supported(L['o']['_keep'].handle, 1, self.heads, self.head_dim) == 1 for L in self.layers))
         if B > 1:
             need = 0
             for L in self.layers:
@@ -498,8 +505,23 @@ class DecodeEngine:
             self._norm_gemv(self.x, L['ln1'], L['qkv'], self.qkvb, s)       # qkv = qkv_proj(rmsnorm(x))
             # producer-side permutation: o_proj / down_proj of an act-order checkpoint read x in their sorted order -- written that way by the attention /
             # gate-up launch when those are the stripe16 kernels (else: the in-kernel gather)
-            o_inv = L['o'].get('invperm') if (self.producer_perm and self.fuse_attn and L['o']['st'] is not None) else None
-            d_inv = L['down'].get('invperm') if (self.producer_perm and L['gate'].get('st2') is not None and L['down']['st'] is not None) else None
+            # (a consumer with a bias AND a residual goes through gptq_layer_decode_f16, which gathers x itself: no producer-side order for it -- ADVICE r5)
+            o_inv = L['o'].get('invperm') if (self.producer_perm and self.fuse_attn and L['o']['st'] is not None and L['o']['bias'] is None) else None
+            d_inv = L['down'].get('invperm') if (self.producer_perm and L['gate'].get('st2') is not None and L['down']['st'] is not None and
+                                                 L['down']['bias'] is None) else None
+            if self.attn_records:
+                tab = self._rope_table(L['theta'], s)
+                rc = lib.gptq_decode_attn_split_f16(self.qkvb.data_ptr(), self.qkvb.stride(0), self.pos.data_ptr(), self.kc[li].data_ptr(),
+                                                    self.vc[li].data_ptr(), self.attn_ws.data_ptr(), self.attn_ws.numel(), 1, self.heads, self.head_dim,
+                                                    self.t_max, L['theta'], scale, ptr(tab), 0, s)
+                self.native.check(rc, 'gptq_decode_attn_split_f16')
+                rc = lib.gptq_layer_decode_attn_f16(L['o']['_keep'].handle, self.attn_ws.data_ptr(), self.attn_ws.numel(), self.pos.data_ptr(), 1,
+                                                    self.heads, self.head_dim, self.t_max, 0, self.x2.data_ptr(), self.x2.stride(0), self.x.data_ptr(),
+                                                    self.x.stride(0), s)                                   # x2 = x + o_proj(merge(records))
+                self.native.check(rc, 'gptq_layer_decode_attn_f16')
+                self._norm_mlp(self.x2, L['ln2'], L['gate'], L['up'], self.cb, s, out_perm=d_inv)
+                self._gemv(self.cb, L['down'], self.x, s, residual=self.x2, x_sorted=d_inv is not None)
+                continue
             if self.fuse_attn:
                 tab = self._rope_table(L['theta'], s)
                 if o_inv is not None:
@@ -681,3 +703,35 @@ def benchmark_decode_engine(model, tokens=64, t_max=2048, seed=0, graph=True, fu
         res['median_s_per_step'] = res.pop('median_s_per_token')
         res.pop('launches_per_token')
     return res
+
+
+def benchmark_decode_engine_context(model, contexts=(512, 1024, 2047), tokens=16, t_max=2048, batch=1, seed=0):
+    """the same protocol at DEPTH: for every entry of `contexts` the engine's rows pretend to hold context - tokens cached tokens (random K / V
+    rows) and decode `tokens` more, so the median step sees ~context tokens of history -- the regime of the reference's own measurement, which
+    steps through --benchmark 2048 tokens and prints the median (llama.py:385-438; README.md:161).  ONE engine / graph for all depths."""
+    dev = next(model.parameters()).device
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
+    eng = DecodeEngine(model, t_max=t_max, batch=batch).capture()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    input_ids = torch.randint(0, model.config.vocab_size, (batch, tokens), device=dev, generator=gen)
+    eng.kcb.normal_(0, 0.5)
+    eng.vcb.normal_(0, 0.5)
+    out = {}
+    for ctx in contexts:
+        start = max(0, min(int(ctx), t_max) - tokens)
+        eng.pos.fill_(start)
+        times = []
+        for i in range(tokens):
+            torch.cuda.synchronize(dev)
+            tick = time.perf_counter()
+            eng.decode(input_ids[:, i])
+            torch.cuda.synchronize(dev)
+            times.append(time.perf_counter() - tick)
+        med = float(np.median(times[2:]))
+        out['ctx%d' % ctx] = {'positions': [start, start + tokens - 1], 'median_s_per_step': round(med, 6), 'tokens_per_s': round(batch / med, 1)}
+    out['protocol'] = 'llama.py:385-438 at depth: rows start with (context - %d) cached tokens, %d steps, sync per step, median' % (tokens, tokens)
+    out['batch'] = batch
+    out['attention'] = 'split records merged by o_proj' if eng.attn_records else 'self-merging launch'
+    return out

@@ -313,8 +313,10 @@ int gptq_decode_attn_f16(const void *q, const void *k_cache, const void *v_cache
                          int t_max, float scale, gptq_stream_t stream);
 
 /* gptq_decode_rope_kv_f16 + gptq_decode_attn_f16 as ONE launch (q is rotated internally, the qkv
- * buffer is left untouched); the workspace (same size query) must be zero on first use -- its
- * trailing [heads] uint32 arrival tickets are restored to zero by the kernel. */
+ * buffer is left untouched); the workspace (same size query; 16-byte aligned) must be zero on first use -- its
+ * trailing [heads] uint32 arrival tickets are restored to zero by the kernel.  Round 6: a streaming kernel -- one
+ * workgroup per head walks the whole history up to ~768 tokens (no merge at all), at most gptq_decode_attn_splits()
+ * splits with an arrival ticket beyond (see "round 6" below). */
 int gptq_decode_attn_fused_f16(const void *qkv, const int64_t *position, void *k_cache, void *v_cache, void *out,
                                void *workspace, size_t workspace_bytes, int heads, int head_dim, int t_max,
                                float base, float scale, gptq_stream_t stream);
@@ -495,6 +497,30 @@ int gptq_stripe_matvec_perm_out_f16(const void *x, int64_t ldx, const void *stri
 int gptq_dense_matmat_f16(const void *x, int64_t ldx, const void *weight, int64_t ldw, const void *bias, void *y, int64_t ldy, int M, int N,
                           int K, const void *norm_weight, float norm_eps, gptq_stream_t stream);
 int gptq_add_rows_f16(void *y, int64_t ldy, const void *r, int64_t ldr, int M, int N, gptq_stream_t stream);
+
+/* ---- round 6: the decode attention as a STREAMING launch whose splits are merged by the NEXT launch ------------------------------------------
+ * Replaces F.scaled_dot_product_attention over the grown cache (quant/fused_attn.py:142-155) for one new token per row.  The launch behind every
+ * gptq_decode_attn_* entry cuts a row's history into at most gptq_decode_attn_splits() ranges chosen from the row's length at run time; a split is
+ * one workgroup that walks its range with an online softmax and ends with a record per head: {M, den} in fp32 and its normalised partial
+ * output o[128] in fp16 (one split: o IS the output row).  The entries above merge
+ * the records themselves (one split: nothing to merge; several: arrival ticket, last split merges).  The pair below leaves them to the consumer:
+ *
+ * gptq_decode_attn_split_f16   RoPE + KV append + attention like gptq_decode_attn_batch_f16, but NO output row: the records stay in `workspace`
+ *                              ([batch][S][heads * 128] fp16 partial outputs | [batch][S][heads] fp32 {M, den}; S = gptq_decode_attn_splits()).
+ * gptq_layer_decode_attn_f16   y = residual + layer(x), where x is the merge of those records, formed while the decode kernel stages x (the
+ *                              kernel boundary is the hand-off between the splits' workgroups).  One row, a layer with a trivial g_idx and a
+ *                              stripe16 image, K = heads * 128 (o_proj of a batch-1 decode step); GPTQ_E_VARIANT otherwise --
+ *                              gptq_layer_decode_attn_supported() answers 1 / 0 ahead of time.  Bit-identical to
+ *                              gptq_decode_attn_batch_f16 + gptq_layer_decode_f16 at the same tokens_per_split.
+ * tokens_per_split <= 0: the library's default for the mode; both calls of a pair must pass the same value (and the same t_max / batch). */
+int gptq_decode_attn_splits(int batch, int heads, int head_dim, int t_max);
+int gptq_decode_attn_split_f16(const void *qkv, int64_t ldq, const int64_t *positions, void *k_cache, void *v_cache, void *workspace,
+                               size_t workspace_bytes, int batch, int heads, int head_dim, int t_max, float base, float scale, const float *rope_table,
+                               int tokens_per_split, gptq_stream_t stream);
+int gptq_layer_decode_attn_supported(const gptq_layer_t *layer, int batch, int heads, int head_dim);
+int gptq_layer_decode_attn_f16(const gptq_layer_t *layer, const void *attn_workspace, size_t attn_workspace_bytes, const int64_t *positions, int batch,
+                               int heads, int head_dim, int t_max, int tokens_per_split, void *y, int64_t ldy, const void *residual, int64_t ldr,
+                               gptq_stream_t stream);
 
 /* ---- GPTQ solver (the caller that PRODUCES the weights; reference gptq.py:128-228) -------------------------------
  * One column block [i1, i1 + count), count <= 128, of the sequential quantise / error-feedback loop (gptq.py:177-199)

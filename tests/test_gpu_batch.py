@@ -213,22 +213,38 @@ def test_decode_attention_batch_rows_equal_single_row_launches(B, pos):
         assert rel_err(out[b].float().cpu().numpy(), ref.cpu().numpy()) < 2e-3, b
 
 
-@pytest.mark.parametrize('pos', [5, 1023, 1024, 1025, 1500, 2047])
+def _attn_inputs(heads, t_max, seed, B=1):
+    hd = 128
+    H = heads * hd
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    qkv = torch.randn((B, 3 * H), device=DEV, generator=g).half()
+    kc = (torch.randn((B, t_max, H), device=DEV, generator=g) * 0.5).half()
+    vc = (torch.randn((B, t_max, H), device=DEV, generator=g) * 0.5).half()
+    tab = torch.empty((t_max, hd // 2, 2), dtype=torch.float32, device=DEV)
+    _native.check(_native.lib().gptq_rope_table_f32(tab.data_ptr(), t_max, hd, 10000.0, _native.stream_ptr(torch.device(DEV))), 'rope table')
+    return qkv, kc, vc, tab
+
+
+def _sdpa_ref(q_rot, k, v, T, heads, scale):
+    """fp32 softmax attention of the rotated q [heads, 128] over rows [0, T) of the (updated) cache slices k, v [t_max, heads * 128]"""
+    kk = k[:T].view(T, heads, 128).transpose(0, 1).float()
+    vv = v[:T].view(T, heads, 128).transpose(0, 1).float()
+    att = torch.softmax((q_rot[:, None, :] * kk).sum(-1) * scale, dim=-1)
+    return (att[:, :, None] * vv).sum(1).reshape(-1)
+
+
+@pytest.mark.parametrize('pos', [0, 5, 127, 128, 129, 767, 768, 1023, 1024, 1025, 1500, 1536, 1537, 2047])
 def test_decode_attention_long_context_splits(pos):
-    """a cache of 2048 tokens, batch 1: the launch has a grid of 64-step splits; up to 1024 tokens of context pairs of them fold into 128-step
-    splits, beyond they stay (24 workgroups per head at 1500 tokens).  Both regimes against fp32 softmax attention over the row's history and
+    """a cache of 2048 tokens, batch 1, through the self-merging entry (round 6: the streaming kernel): ONE workgroup per head walks the whole
+    history up to 768 tokens (no records, no ticket), two up to 1536, three beyond; against fp32 softmax attention over the row's history and
     against the two-launch path (RoPE + append, then 128-step partials + merge)."""
     lib = _native.lib()
     heads, hd, t_max = 4, 128, 2048
     H = heads * hd
     s = _native.stream_ptr(torch.device(DEV))
-    g = torch.Generator(device=DEV).manual_seed(pos)
-    qkv = torch.randn((1, 3 * H), device=DEV, generator=g).half()
-    kc = (torch.randn((t_max, H), device=DEV, generator=g) * 0.5).half()
-    vc = (torch.randn((t_max, H), device=DEV, generator=g) * 0.5).half()
+    qkv, kc, vc, tab = _attn_inputs(heads, t_max, pos)
+    kc, vc = kc[0], vc[0]
     p = torch.tensor([pos], dtype=torch.int64, device=DEV)
-    tab = torch.empty((t_max, hd // 2, 2), dtype=torch.float32, device=DEV)
-    _native.check(lib.gptq_rope_table_f32(tab.data_ptr(), t_max, hd, 10000.0, s), 'rope table')
     scale = 1.0 / np.sqrt(hd)
     nb = lib.gptq_decode_attn_workspace_bytes(heads, hd, t_max)
     ws = torch.zeros(nb, dtype=torch.uint8, device=DEV)
@@ -244,14 +260,110 @@ def test_decode_attention_long_context_splits(pos):
     _native.check(lib.gptq_decode_attn_f16(q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), p.data_ptr(), o2.data_ptr(), ws2.data_ptr(), nb, heads, hd, t_max, scale, s), 'attn')
     torch.cuda.synchronize()
     assert torch.equal(k1, k2) and torch.equal(v1, v2)                        # the appended row
+    assert torch.equal(k1[pos + 1:], kc[pos + 1:]) and torch.equal(k1[:pos], kc[:pos])      # ... and nothing else
     assert rel_err(out.float().cpu().numpy(), o2.float().cpu().numpy()) < 1e-3
-    T = pos + 1
-    qr = q2[0, :H].view(heads, hd).float()                                    # q2 was rotated in place by the two-launch path
-    kk = k1[:T].view(T, heads, hd).transpose(0, 1).float()
-    vv = v1[:T].view(T, heads, hd).transpose(0, 1).float()
-    att = torch.softmax((qr[:, None, :] * kk).sum(-1) * scale, dim=-1)
-    ref = (att[:, :, None] * vv).sum(1).reshape(-1)
+    ref = _sdpa_ref(q2[0, :H].view(heads, hd).float(), k1, v1, pos + 1, heads, scale)      # q2 was rotated in place by the two-launch path
     assert rel_err(out[0].float().cpu().numpy(), ref.cpu().numpy()) < 2e-3
+
+
+@pytest.mark.parametrize('tps', [128, 256, 768, 0])
+@pytest.mark.parametrize('pos', [0, 5, 127, 128, 129, 255, 256, 300, 511, 512, 767, 768, 1023, 1100, 1536, 2046, 2047])
+def test_attention_split_records_every_fold(pos, tps):
+    """gptq_decode_attn_split_f16: every (position, tokens-per-split) combination -- 1 .. 8 active splits of 128 .. 2048 tokens, ragged last tiles,
+    the owner of the new token with and without old rows of its own -- leaves records ({M, den} per head in fp32, the normalised partial outputs in fp16) whose merge (float64, on the host) is fp32 softmax
+    attention over the row's history; splits past the active ones are not touched; the cache gets exactly the new row."""
+    lib = _native.lib()
+    heads, hd, t_max = 4, 128, 2048
+    H = heads * hd
+    s = _native.stream_ptr(torch.device(DEV))
+    qkv, kc, vc, tab = _attn_inputs(heads, t_max, 1000 + pos)
+    p = torch.tensor([pos], dtype=torch.int64, device=DEV)
+    scale = 1.0 / np.sqrt(hd)
+    S = lib.gptq_decode_attn_splits(1, heads, hd, t_max)
+    assert S == 8
+    nb = lib.gptq_decode_attn_batch_workspace_bytes(1, heads, hd, t_max)
+    ws = torch.full((nb // 4 * 4,), 0xFF, dtype=torch.uint8, device=DEV).view(torch.float32)   # poisoned (NaN as fp16 and as fp32): inactive slots must stay untouched AND unread
+    k1, v1 = kc.clone(), vc.clone()
+    rc = lib.gptq_decode_attn_split_f16(qkv.data_ptr(), 3 * H, p.data_ptr(), k1.data_ptr(), v1.data_ptr(), ws.data_ptr(), nb, 1, heads, hd, t_max, 10000.0, scale,
+                                        tab.data_ptr(), tps, s)
+    _native.check(rc, 'gptq_decode_attn_split_f16')
+    torch.cuda.synchronize()
+    o16 = ws.view(torch.float16)[:S * H].view(S, H).double().cpu().numpy()              # [S][heads x 128] fp16 partial outputs
+    md = ws[S * H // 2:S * H // 2 + S * heads * 2].view(S, heads, 2).double().cpu().numpy()   # [S][heads] {M (log2 domain), den}
+    t_eff = tps if tps > 0 else 128
+    want = min(max(-(-(pos + 1) // t_eff), 1), S)
+    chunk = -(-(-(-(pos + 1) // want)) // 128) * 128
+    nsp = -(-(pos + 1) // chunk)
+    assert np.isfinite(o16[:nsp]).all() and np.isfinite(md[:nsp]).all()
+    assert np.isnan(o16[nsp:]).all() and np.isnan(md[nsp:]).all()
+    Mx = md[:nsp, :, 0].max(0)                                       # [heads]
+    c = np.exp2(md[:nsp, :, 0] - Mx[None]) * md[:nsp, :, 1]          # [nsp, heads]
+    c = c / c.sum(0)[None]
+    out = (c[:, :, None] * o16[:nsp].reshape(nsp, heads, hd)).sum(0).reshape(-1)
+    # reference: rotate q with the product's RoPE, softmax attention over rows [0, pos] of the UPDATED cache
+    q = qkv[0, :H].view(heads, hd)
+    qk = torch.stack([q, q]).view(1, 1, 2, heads, hd).contiguous()
+    quant.fused_attn.hip_rotate_half_(qk, p.view(1, 1))
+    ref = _sdpa_ref(qk[0, 0, 0].float(), k1[0], v1[0], pos + 1, heads, scale)
+    assert rel_err(out, ref.double().cpu().numpy()) < 1e-3, (pos, tps, nsp)
+    assert torch.equal(k1[0, :pos], kc[0, :pos]) and torch.equal(k1[0, pos + 1:], kc[0, pos + 1:]) and torch.equal(v1[0, :pos], vc[0, :pos])
+    assert not torch.equal(k1[0, pos], kc[0, pos])
+
+
+@pytest.mark.parametrize('heads,N,bits,gs', [(4, 256, 4, 128), (32, 4096, 4, 128), (8, 96, 8, 64), (9, 96, 3, 128)])
+def test_o_proj_merges_the_attention_records(heads, N, bits, gs):
+    """Round 6: gptq_decode_attn_split_f16 + gptq_layer_decode_attn_f16 (o_proj's decode kernel stages x from the split records) against the
+    self-merging launch + gptq_layer_decode_f16: BIT-IDENTICAL y at the self-merging launch's tokens-per-split (same split ranges, same merge
+    arithmetic -- attn_split.h), within the op-level bar of the oracle's o_proj on the merged row at every other fold; idle rows; twice in a row."""
+    lib = _native.lib()
+    hd, t_max = 128, 2048
+    K = heads * hd
+    L = make_random_layer(bits, gs, K, N, seed=900 + heads)
+    pl, _keep = _prepared([L], gs, K, N, bits)
+    assert lib.gptq_layer_decode_attn_supported(pl.handle, 1, heads, hd) == 1
+    assert lib.gptq_layer_decode_attn_supported(pl.handle, 2, heads, hd) == 0 and lib.gptq_layer_decode_attn_supported(pl.handle, 1, heads + 1, hd) == 0
+    s = _native.stream_ptr(torch.device(DEV))
+    scale = 1.0 / np.sqrt(hd)
+    nb = lib.gptq_decode_attn_batch_workspace_bytes(1, heads, hd, t_max)
+    lws = _native.layer_workspace(torch.device(DEV), s)
+    scratch = torch.empty(max(lib.gptq_layer_decode_scratch_bytes(pl.handle, 1), 256), dtype=torch.uint8, device=DEV)
+    rng = np.random.default_rng(heads)
+    res = dev(rng.standard_normal((1, N)).astype(np.float16))
+    for pos in ([0, 100, 128, 769, 1537, 2047] if heads != 32 else [0, 1200]):
+        qkv, kc, vc, tab = _attn_inputs(heads, t_max, 77 + pos)
+        p = torch.tensor([pos], dtype=torch.int64, device=DEV)
+        # (a) the self-merging launch, then the plain o_proj launch with the residual
+        wsa = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        ka, va = kc.clone(), vc.clone()
+        xa = torch.full((1, K), float('nan'), dtype=torch.float16, device=DEV)
+        _native.check(lib.gptq_decode_attn_batch_f16(qkv.data_ptr(), 3 * K, p.data_ptr(), ka.data_ptr(), va.data_ptr(), xa.data_ptr(), K, wsa.data_ptr(), nb, 1,
+                                                     heads, hd, t_max, 10000.0, scale, tab.data_ptr(), None, s), 'attn batch')
+        ya = torch.full((1, N), float('nan'), dtype=torch.float16, device=DEV)
+        _native.check(lib.gptq_layer_decode_f16(pl.handle, xa.data_ptr(), K, ya.data_ptr(), N, 1, None, 0.0, res.data_ptr(), N, lws.data_ptr(), lws.numel(),
+                                                scratch.data_ptr(), scratch.numel(), s), 'layer decode')
+        for tps in (768, 128, 300):
+            wsb = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+            kb, vb = kc.clone(), vc.clone()
+            yb = torch.full((1, N), float('nan'), dtype=torch.float16, device=DEV)
+            for rep in range(2):
+                _native.check(lib.gptq_decode_attn_split_f16(qkv.data_ptr(), 3 * K, p.data_ptr(), kb.data_ptr(), vb.data_ptr(), wsb.data_ptr(), nb, 1, heads, hd,
+                                                             t_max, 10000.0, scale, tab.data_ptr(), tps, s), 'attn split')
+                _native.check(lib.gptq_layer_decode_attn_f16(pl.handle, wsb.data_ptr(), nb, p.data_ptr(), 1, heads, hd, t_max, tps, yb.data_ptr(), N, res.data_ptr(), N,
+                                                             s), 'layer decode attn')
+            torch.cuda.synchronize()
+            assert torch.equal(ka, kb) and torch.equal(va, vb)
+            if tps == 768:
+                assert torch.equal(ya, yb), (pos, tps)
+            else:      # other split ranges: other roundings of x -- the oracle's o_proj on (a)'s merged row, two fp16 roundings apart
+                ref = _expect(xa.cpu().numpy(), [L], bits, None, 0.0, res.cpu().numpy())
+                assert rel_err(yb.cpu().numpy(), ref) < 2 * TOL, (pos, tps, rel_err(yb.cpu().numpy(), ref))
+    # an idle row (negative position): x = 0 -- y is the residual, nothing NaN
+    p = torch.tensor([-1], dtype=torch.int64, device=DEV)
+    wsb = torch.full((nb // 4 * 4,), 0xFF, dtype=torch.uint8, device=DEV).view(torch.float32)
+    yb = torch.full((1, N), float('nan'), dtype=torch.float16, device=DEV)
+    _native.check(lib.gptq_layer_decode_attn_f16(pl.handle, wsb.data_ptr(), nb, p.data_ptr(), 1, heads, hd, t_max, 0, yb.data_ptr(), N, res.data_ptr(), N, s), 'idle')
+    torch.cuda.synchronize()
+    assert torch.isfinite(yb.float()).all()
 
 
 @pytest.mark.parametrize('M', [1, 2, 3, 4, 7, 8, 13, 16])

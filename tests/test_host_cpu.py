@@ -79,7 +79,8 @@ def test_argument_validation_needs_no_gpu():
         _native.check(-1, 'x')
     with pytest.raises(RuntimeError):
         _native.check(-7, 'x')
-    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == 32 * (32 if os.environ.get('GPTQ_ATTN_LONG_SPLITS', '0') != '0' else 16) * 130 * 4 + 32 * 4
+    # (the two-launch path's records [heads][t_max / 128][130] are the larger need at batch 1; the streaming launch: test_attention_split_policy...)
+    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == 32 * 16 * 130 * 4
     assert lib.gptq_decode_attn_workspace_bytes(32, 64, 2048) == 0
 
 
@@ -308,10 +309,20 @@ def test_stripe_abi_validation_needs_no_gpu():
     assert lib.gptq_dense_matmat_f16(None, 256, one, 256, None, one, 64, 2, 64, 256, None, 0.0, None) == -4
     assert lib.gptq_add_rows_f16(one, 64, one, 32, 2, 64, None) == -2 and lib.gptq_add_rows_f16(one, 64, None, 64, 2, 64, None) == -4
     assert lib.gptq_add_rows_f16(one, 64, one, 64, 0, 64, None) == 0
-    rec = lambda heads, splits: heads * splits * 130 * 4 + heads * 4          # {max, sum, acc[128]} per (head, split) + one ticket per head
-    assert lib.gptq_decode_attn_batch_workspace_bytes(4, 32, 128, 2048) == 4 * rec(32, 16)        # a batch: 128-step splits
-    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == rec(32, 32 if os.environ.get('GPTQ_ATTN_LONG_SPLITS', '0') != '0' else 16)   # (64-step grid: an A/B knob, off)
-    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 1024) == rec(32, 8)
+    # round 6: the streaming launch keeps [batch][S][heads x 128] fp16 partial outputs + [batch][S][heads] fp32 {M, den} + one ticket per (row, head); S = splits of the
+    # grid: heads x rows x S ~ 256 workgroups, at most 8, at most one per 128 tokens of the cache
+    rec = lambda batch, heads, S: batch * (S * heads * (128 * 2 + 8) + heads * 4)
+    assert [lib.gptq_decode_attn_splits(b, 32, 128, 2048) for b in (1, 2, 3, 4, 16)] == [8, 4, 2, 2, 1]
+    assert lib.gptq_decode_attn_splits(1, 2, 128, 384) == 3 and lib.gptq_decode_attn_splits(1, 2, 128, 64) == 1
+    assert lib.gptq_decode_attn_splits(1, 32, 64, 2048) == -2
+    assert lib.gptq_decode_attn_batch_workspace_bytes(4, 32, 128, 2048) == rec(4, 32, 2) and lib.gptq_decode_attn_batch_workspace_bytes(16, 32, 128, 2048) == rec(16, 32, 1)
+    assert lib.gptq_decode_attn_batch_workspace_bytes(2, 32, 128, 2048) == rec(2, 32, 4)
+    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 2048) == max(rec(1, 32, 8), 32 * 16 * 130 * 4)    # (the two-launch path's records at batch 1)
+    assert lib.gptq_decode_attn_workspace_bytes(32, 128, 1024) == max(rec(1, 32, 8), 32 * 8 * 130 * 4)
+    assert lib.gptq_decode_attn_split_f16(one, 3 * 256, one, one, one, one, 16, 2, 2, 128, 64, 10000.0, 1.0, None, 0, None) == -5          # workspace too small
+    assert lib.gptq_decode_attn_split_f16(one, 3 * 256, one, one, one, None, 1 << 20, 2, 2, 128, 64, 10000.0, 1.0, None, 0, None) == -4
+    assert lib.gptq_layer_decode_attn_f16(None, one, 1 << 20, one, 1, 2, 128, 64, 0, one, 64, None, 0, None) == -4
+    assert lib.gptq_layer_decode_attn_supported(None, 1, 2, 128) == -4
     assert lib.gptq_decode_attn_batch_workspace_bytes(4, 32, 64, 2048) == 0
     assert lib.gptq_decode_attn_batch_f16(one, 3 * 256, one, one, one, one, 256, one, 16, 2, 2, 128, 64, 10000.0, 1.0, None, None, None) == -5    # workspace too small
     assert lib.gptq_decode_attn_batch_f16(one, 256, one, one, one, one, 256, one, 1 << 20, 2, 2, 128, 64, 10000.0, 1.0, None, None, None) == -2   # ldq < 3 * hidden

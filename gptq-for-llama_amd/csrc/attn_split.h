@@ -74,6 +74,9 @@ static __device__ inline __attribute__((always_inline)) void attn_merge_coeffs(c
 #pragma unroll
     for (int i = 0; i < ATT_MAX_SPLITS; i++) {
         c[i] = i < nsp ? __builtin_amdgcn_exp2f(M[i] - Mx) * den[i] : 0.f;
+        // (a compiler fence per product: with -ffast-math the backend contracts c[0] + c[1] into fma(w0, den0, c1) although the pragma above
+        // clears `contract` -- seen in the ISA of the consumer, not in the -ffp-contract=off unit of the producer: 1 ulp of D apart)
+        asm volatile("" : "+v"(c[i]));
         D += c[i];
     }
     const float r = __builtin_amdgcn_rcpf(D);

@@ -6,8 +6,11 @@
 Eagerly that is ~330 small launches per token and the host cannot keep up.  ``make_quant_attn``
 therefore installs this hook on the ``LlamaForCausalLM`` it is given: a forward with ONE new token, batch 1 and a
 KV cache is answered by ``quant.decode.DecodeEngine`` -- the same arithmetic as the module chain, issued as 5 launches
-per layer and replayed as one hipGraph -- and everything else (prefill, batches, training, beams, output_attentions ...)
-goes to the original forward untouched.  The caller keeps its API: HF ``generate`` with its own sampling, stopping
+per layer and replayed as one hipGraph -- and everything else (prefill, training, output_attentions ...) goes to the
+original forward untouched.  Beam search goes the eager way too (round 6): HF permutes the rows of the cache IN PLACE after
+every step (``cache.reorder_cache(beam_idx)``), which the engine's static per-row K/V cache would not follow -- ``generate(num_beams > 1)``
+switches the hook off for the call, and a tracked cache whose ``reorder_cache`` is called by anyone is completed, released and never
+tracked again.  The caller keeps its API: HF ``generate`` with its own sampling, stopping
 criteria and cache object.
 
 Cache protocol: the engine owns a static K/V cache.  The first decode step after a prefill copies the caller's cache
@@ -49,13 +52,18 @@ RELEASE_CHECKPOINT = os.environ.get('GPTQ_RELEASE_CHECKPOINT', '1') != '0'
 
 
 MAX_ENGINES = 4       # engines (one per batch size) kept alive per model; the least recently used one goes first
+# bytes of static K / V cache ONE engine may hold (layers x rows x t_max x hidden x 2 x fp16): t_max is sized from the request and grows on
+# demand up to min(max_position_embeddings, 8192, what this budget allows) -- a 7B engine of 16 rows at 4096 tokens would be 34 GB
+CACHE_BUDGET = int(float(os.environ.get('GPTQ_ENGINE_CACHE_GB', '16')) * (1 << 30))
 
 
 class _State:
-    __slots__ = ('engine', 'engines', 'declined', 'sig', 'cache_ref', 'hf_len', 'pos', 'steps', 'npad', 'released')
+    __slots__ = ('engine', 'engines', 'declined', 'sig', 'cache_ref', 'hf_len', 'pos', 'steps', 'npad', 'released', 'len_hint', 'reordered')
 
     def __init__(self):
         self.engine, self.sig, self.cache_ref, self.hf_len, self.pos, self.steps = None, None, None, 0, 0, 0
+        self.len_hint = 0         # tokens the running generate() call may reach (prompt + max_new_tokens), 0 = unknown
+        self.reordered = None     # weakref of a cache whose rows its caller permutes (beam search): the engine stays away from it
         self.engines = {}         # batch size -> DecodeEngine (insertion order = recency)
         self.declined = set()     # batch sizes the model has no engine route for
         self.npad = None          # per row of the tracked batch: pads of the caller's left-padded cache (host ints)
@@ -111,10 +119,33 @@ def _sync_back(st, upto=None):
     st.hf_len = b
 
 
+def _watch_reorder(st, cache):
+    """beam search permutes the rows of the cache in place after every step (HF: cache.reorder_cache(beam_idx)); the engine's rows would keep
+    attending to another beam's history.  A tracked cache therefore gets its reorder_cache wrapped: the engine's tokens are appended first (in
+    the order the caller knows), the cache is released, and the engine never tracks this object again (copying every row back in per step
+    would cost more than the eager step)."""
+    if getattr(cache, '_gptq_reorder_watched', False) or not hasattr(cache, 'reorder_cache'):
+        return
+    orig = cache.reorder_cache
+
+    def reorder_cache(*a, **k):
+        if st.cache_ref is not None and st.cache_ref() is cache:
+            _sync_back(st)
+            st.cache_ref = None
+        st.reordered = weakref.ref(cache)
+        return orig(*a, **k)
+    try:
+        cache.reorder_cache = reorder_cache
+        cache._gptq_reorder_watched = True
+    except Exception:         # (a cache type that refuses attributes: generate()'s num_beams check still covers HF's own beam search)
+        pass
+
+
 def _sync_in(st, cache, T, npad=None):
     """copy the caller's cache (T entries per row, the first npad[r] of row r being pads) into the engine's static cache."""
     from .decode import _cache_layer_kv
     eng = st.engine
+    _watch_reorder(st, cache)
     npad = [0] * eng.batch if npad is None else npad
     if T:
         for li in range(len(eng.layers)):
@@ -150,8 +181,18 @@ def _left_pads(attention_mask, T):
     return [int(n) for n in flat[:-1]]
 
 
-def _engine_for(model, st, B, sig):
-    """the engine of this batch size (built and captured on first use), or None when the model has no route for it"""
+def _t_max_cap(model, B):
+    """longest static cache an engine of B rows may hold: the model's positions, 8192, and the byte budget"""
+    cfg = model.config
+    per_token = len(model.model.layers) * B * cfg.hidden_size * 2 * 2            # K and V, fp16, all layers, all rows
+    by_budget = max(256, CACHE_BUDGET // per_token // 128 * 128)
+    return int(min(max(getattr(cfg, 'max_position_embeddings', 2048), 256), 8192, by_budget))
+
+
+def _engine_for(model, st, B, sig, need=0):
+    """the engine of this batch size (built and captured on first use), or None when the model has no route for it.  need: tokens the
+    engine's cache must hold NOW (the row length + 1); the cache is sized for max(need, the running generate()'s length hint) rounded up to 256,
+    at least 512, at most _t_max_cap -- and rebuilt larger when a sequence outgrows it (grow on demand)."""
     from .decode import DecodeEngine
     if st.sig != sig:
         st.engines.clear()
@@ -163,17 +204,46 @@ def _engine_for(model, st, B, sig):
         return None, sig
     if B in st.declined:
         return None, sig
+    cap = _t_max_cap(model, B)
+    if need > cap:
+        return None, sig
     eng = st.engines.get(B)
+    grown = 0
+    if eng is not None and need > eng.t_max:      # the sequence outgrew this engine's cache: one twice as long takes over (the caller re-syncs)
+        grown = 2 * eng.t_max
+        if st.engine is eng:
+            _sync_back(st)
+            st.engine, st.cache_ref = None, None
+        del st.engines[B]
+        eng = None
+        torch.cuda.empty_cache()
     if eng is None:
         if RELEASE_CHECKPOINT and not st.released:      # memory mode: from the first decode step on ONE copy of the packed weights
             from . import release_checkpoint
             release_checkpoint(model)
             st.released = True
             sig = _signature(model)     # the placeholders are new tensor objects
-        t_max = int(min(max(getattr(model.config, 'max_position_embeddings', 2048), 256), 8192))
+        want = max(need + 256, st.len_hint, grown, 512)
+        t_max = int(min(cap, -(-want // 256) * 256))
+
+        def evict_others():
+            for old in [k for k in st.engines if k != B]:
+                if st.engines[old] is st.engine:
+                    _sync_back(st)
+                    st.engine, st.cache_ref = None, None
+                del st.engines[old]
+            torch.cuda.empty_cache()
         try:
-            eng = DecodeEngine(model, t_max=t_max, batch=B).capture()
-        except NotImplementedError:
+            try:
+                eng = DecodeEngine(model, t_max=t_max, batch=B).capture()
+            except torch.cuda.OutOfMemoryError:
+                #  the eager path would have worked: drop the other engines, try once more, else this batch size goes eager
+                eng = None
+                evict_others()
+                eng = DecodeEngine(model, t_max=t_max, batch=B).capture()
+        except (NotImplementedError, torch.cuda.OutOfMemoryError):
+            eng = None
+            torch.cuda.empty_cache()
             st.declined.add(B)
             st.sig = sig
             return None, sig
@@ -193,14 +263,21 @@ def _engine_for(model, st, B, sig):
 def _engine_forward(model, st, input_ids, cache, attention_mask, position_ids, kw):
     """one token per row through the DecodeEngine of this batch size, or None when this call has to go the eager way."""
     B = input_ids.shape[0]
-    eng, sig = _engine_for(model, st, B, _signature(model))
-    if eng is None:
-        return None
+    if st.reordered is not None and st.reordered() is cache:
+        return None          # its caller permutes the rows in place (beam search): eager
     T = _cache_len(cache)
     if T is None:
         return None
-    tracked = st.engine is eng and st.cache_ref is not None and st.cache_ref() is cache and T == st.hf_len
+    was = st.engine
+    tracked = was is not None and st.cache_ref is not None and st.cache_ref() is cache and T == st.hf_len and was.batch == B
     pos = st.pos if tracked else T
+    eng, sig = _engine_for(model, st, B, _signature(model), need=pos + 1)
+    if eng is None:
+        return None
+    if tracked and st.engine is not eng:         # a rebuilt, larger engine: the tracked cache was completed and released -- start from it again
+        tracked = False
+        T = _cache_len(cache)
+        pos = T
     if attention_mask is not None and (attention_mask.dim() != 2 or attention_mask.shape[0] != B or attention_mask.shape[-1] != pos + 1):
         return None          # a mask that is not "everything so far" (4-D masks, other lengths): eager
     if pos + 1 > eng.t_max:
@@ -268,9 +345,22 @@ def install_decode_engine(model):
         orig_generate = model.generate
 
         def generate(self, *args, **kwargs):
+            gc = kwargs.get('generation_config') or getattr(self, 'generation_config', None)
+            pick = lambda name, default: kwargs[name] if kwargs.get(name) is not None else (getattr(gc, name, None) if gc is not None else None) or default
+            beams = int(pick('num_beams', 1) or 1)
+            # how far this call can get: the engine sizes (or grows) its static K / V cache for it instead of for max_position_embeddings
+            ids = args[0] if args and torch.is_tensor(args[0]) else kwargs.get('input_ids', kwargs.get('inputs'))
+            plen = int(ids.shape[-1]) if torch.is_tensor(ids) and ids.dim() == 2 else 0
+            new = pick('max_new_tokens', 0)
+            st.len_hint = plen + int(new) + 1 if new else int(pick('max_length', 0) or 0) + 1
+            was_off = getattr(self, '_gptq_engine_disabled', False)
+            if beams > 1:                     # beams: the cache is permuted in place after every step -- eager (see the module docstring)
+                self._gptq_engine_disabled = True
             try:
                 return orig_generate(*args, **kwargs)
             finally:
+                self._gptq_engine_disabled = was_off
+                st.len_hint = 0
                 flush_decode_engine(self)     # the cache handed back to the caller holds every generated token
 
         model._gptq_orig_generate = orig_generate

@@ -524,6 +524,107 @@ def test_batched_generate_goes_through_the_batched_engine():
         assert agree >= 0.75, agree
 
 
+def test_beam_search_goes_the_eager_way():
+    """HF beam search permutes the rows of the cache IN PLACE after every step (cache.reorder_cache(beam_idx)); the engine's
+    static per-row K/V would keep attending to another beam's history.  generate(num_beams > 1) therefore answers with the eager chain -- the
+    same sequences as a model whose hook is off -- and a hand-written loop that reorders a TRACKED cache gets its engine tokens appended
+    first and is left to the eager chain from then on."""
+    from transformers.cache_utils import DynamicCache
+    from quant.engine_hook import engine_steps
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=15, fused=True, **HOOK_CFG)
+    ids = torch.randint(1, 512, (2, 6), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    kw = dict(do_sample=False, num_beams=3, max_new_tokens=10, min_new_tokens=10, pad_token_id=0, attention_mask=torch.ones_like(ids))
+    before = engine_steps(model)
+    with torch.no_grad():
+        got = model.generate(ids, **kw)
+        assert engine_steps(model) == before                     # [6, 1] steps would fit the engine: it must stay away
+        model._gptq_engine_disabled = True
+        ref = model.generate(ids, **kw)
+        model._gptq_engine_disabled = False
+    assert torch.equal(got, ref)
+    # a greedy generate afterwards uses the engine again
+    with torch.no_grad():
+        model.generate(ids[:1], do_sample=False, max_new_tokens=4, min_new_tokens=4, pad_token_id=0)
+    assert engine_steps(model) == before + 3
+    # hand-written: three rows step through the engine, then the caller permutes the rows of the cache
+    ids3 = torch.randint(1, 512, (3, 12), device=DEV, generator=torch.Generator(device=DEV).manual_seed(6))
+    perm = torch.tensor([2, 0, 0], device=DEV)
+
+    def run(hook):
+        model._gptq_engine_disabled = not hook
+        cache = DynamicCache(config=model.config)
+        outs = []
+        with torch.no_grad():
+            model(ids3[:, :5], past_key_values=cache, use_cache=True)
+            for i in range(5, 8):
+                outs.append(model(ids3[:, i:i + 1], past_key_values=cache, use_cache=True).logits[:, -1])
+            cache.reorder_cache(perm)                                # rows 0, 1, 2 <- old rows 2, 0, 0
+            for i in range(8, 11):
+                outs.append(model(ids3[perm][:, i:i + 1], past_key_values=cache, use_cache=True).logits[:, -1])
+        model._gptq_engine_disabled = False
+        return torch.stack(outs).float().cpu().numpy(), cache.get_seq_length()
+    ref, len_e = run(False)
+    s0 = engine_steps(model)
+    got, len_h = run(True)
+    assert engine_steps(model) == s0 + 3                         # the three steps before the reorder only
+    assert len_e == len_h == 11
+    within('hook_reorder', np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), HOOK_TOL)
+
+
+def test_engine_cache_is_sized_from_the_request_and_grows():
+    """the hook's engines size their static K/V cache from the request (the length hint of generate(), else what the
+    row needs + 256, at least 512 tokens) instead of max_position_embeddings, stay inside GPTQ_ENGINE_CACHE_GB, and a sequence that outgrows
+    the cache gets an engine twice as long (re-synchronised from the caller's cache) -- same logits as a run without the engine."""
+    from transformers.cache_utils import DynamicCache
+    import quant.engine_hook as EH
+    cfg = dict(HOOK_CFG, max_position_embeddings=2048)
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=16, fused=True, **cfg)
+    st = model._gptq_engine_state
+    ids = torch.randint(0, 512, (1, 530), device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+
+    def run(hook):
+        model._gptq_engine_disabled = not hook
+        cache = DynamicCache(config=model.config)
+        outs, tmaxes = [], []
+        with torch.no_grad():
+            model(ids[:, :500], past_key_values=cache, use_cache=True)
+            for i in range(500, 530):
+                outs.append(model(ids[:, i:i + 1], past_key_values=cache, use_cache=True).logits[:, -1])
+                if hook:
+                    tmaxes.append(st.engine.t_max)
+        model._gptq_engine_disabled = False
+        return torch.cat(outs).float().cpu().numpy(), tmaxes
+    ref, _ = run(False)
+    got, tmaxes = run(True)
+    assert tmaxes[0] == 768 and tmaxes[-1] == 768                # 500 + 1 + 256 rounded up to 256: no growth needed, no 2048-token cache
+    within('hook_sized_cache', np.abs(got - ref).max() / max(1.0, np.abs(ref).max()), HOOK_TOL)
+    # a budget that only allows 512 tokens: the 501st token still fits, and growth stops at the cap (the hook then answers eagerly)
+    EH.drop_decode_engines(model)
+    old = EH.CACHE_BUDGET
+    try:
+        per_token = len(model.model.layers) * 1 * model.config.hidden_size * 4
+        EH.CACHE_BUDGET = per_token * 520
+        assert EH._t_max_cap(model, 1) == 512
+        got2, tm2 = run(True)
+        within('hook_capped_cache', np.abs(got2 - ref).max() / max(1.0, np.abs(ref).max()), HOOK_TOL)
+        assert max(tm2) == 512
+    finally:
+        EH.CACHE_BUDGET = old
+        EH.drop_decode_engines(model)
+    # growth: start short (an engine of 512 tokens built at a short prefix), then run past it
+    model._gptq_engine_disabled = False
+    cache = DynamicCache(config=model.config)
+    seen = []
+    with torch.no_grad():
+        model(ids[:, :200], past_key_values=cache, use_cache=True)
+        outs = []
+        for i in range(200, 530):
+            outs.append(model(ids[:, i:i + 1], past_key_values=cache, use_cache=True).logits[:, -1])
+            seen.append(st.engine.t_max)
+    assert seen[0] == 512 and seen[-1] == 1024 and sorted(set(seen)) == [512, 1024]
+    within('hook_grown_cache', np.abs(torch.cat(outs[300:]).float().cpu().numpy() - ref).max() / max(1.0, np.abs(ref).max()), HOOK_TOL)
+
+
 def test_engine_hook_keeps_the_callers_cache_consistent():
     """tokens only the engine has seen are appended to the caller's cache before any eager call touches it: a multi-token
     forward after engine steps gives the logits of a run that never used the engine."""

@@ -1311,13 +1311,23 @@ int gptq_layer_unpack_checkpoint(const gptq_layer_t *layer, int set, int32_t *qw
 //  -- and 8 for a wide gate | up pair the C-stripes kernel serves (round 5, stripe_kernel.inc stripe_launch_c: more than 512 stripes,
 // at most five row blocks per wave, not 2-bit).  A/B knobs (read once): GPTQ_DECODE_ROWS_WIDE = rows on wider single layers, GPTQ_DECODE_ROWS_PAIR =
 // rows of a wide gate/up pair.
-static int decode_rows_max(int K, int N, int nsets, int bits) {
+static int decode_rows_max(int K, int N, int nsets, int bits, int groupsize) {
     static const int wide = [] { const char *e = getenv("GPTQ_DECODE_ROWS_WIDE"); return e ? atoi(e) : 4; }();
     static const int pair = [] { const char *e = getenv("GPTQ_DECODE_ROWS_PAIR"); return e ? atoi(e) : -1; }();
+    static const int mf8 = [] { const char *e = getenv("GPTQ_DECODE_MF8"); return e ? atoi(e) : 1; }();
+    const int bk = bits == 8 ? 64 : 128;     // k per row block of the image (stripe_unpack.inc BK)
+    // round 6: 5 .. 8 rows through the 16x16x16 inner product of the decode kernel (stripe_kernel.inc, MF) cost what four rows cost -- every
+    // shape it serves keeps eight rows in the decode launch: groups that span a row block, not 2-bit, eight rows of x in LDS (K <= 9216; at
+    // most five row blocks per wave when a workgroup walks several stripes), or a single set on a K up to 12288 (x in two halves)
+    if (mf8 && bits != 2) {
+        const int gq = stripe_gq_shift(K, N, bits, groupsize);
+        const int nu = (K / bk + 7) / 8;
+        if ((gq == -1 || gq >= 2) && ((N / 16 <= 256 && nu * 8 * bk <= 9216) || (N / 16 > 256 && nu <= 5) || (nsets == 1 && nu * 8 * bk > 9216 && nu * 8 * bk <= 12288)))
+            return 8;
+    }
     if (N <= 4608) return 8;
     if (nsets != 2) return wide;
     if (pair >= 0) return pair;
-    const int bk = bits == 8 ? 64 : 128;     // k per row block of the image (stripe_unpack.inc BK)
     return (bits != 2 && N / 16 > 512 && K <= 5 * 8 * bk) ? 8 : 4;
 }
 
@@ -1380,7 +1390,7 @@ int gptq_layer_route_for_shape(int M, int K, int N, int bits, int groupsize, int
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     const int gq = stripe_gq_shift(K, N, bits, groupsize);
     const bool image = has_image && gq != -2 && kind != 2;
-    const int rows_max = decode_rows_max(K, N, nsets, bits);
+    const int rows_max = decode_rows_max(K, N, nsets, bits, groupsize);
     if (image && (kind == 0 || M == 1) && M <= rows_max && (M <= 4 || K <= 9216 || (K <= 12288 && nsets == 1))) return GPTQ_ROUTE_STRIPE_DECODE;
     if (image && M > 1) {
         if (M <= rows_max && kind == 1 && (M <= 4 || K <= 9216 || (K <= 12288 && nsets == 1))) return GPTQ_ROUTE_STRIPE_DECODE;       // after one gather of x
@@ -1408,7 +1418,7 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
     if (!workspace || !aligned(workspace, 256) || workspace_bytes < gptq_layer_workspace_bytes()) return GPTQ_E_WORKSPACE;
     void *mm_ws = (char *)workspace + WS_BYTES;
     const int K = L.K, N = L.N, bits = L.bits, gs = L.groupsize, ns = L.nsets;
-    const int rows_max = decode_rows_max(K, N, ns, bits);    // row groups only while ONE round of workgroups covers N
+    const int rows_max = decode_rows_max(K, N, ns, bits, gs);    // row groups only while ONE round of workgroups covers N
     // ---- 1. decode and small batches on the stripe16 image ----
     if (L.stripe && L.kind == 0) {
         if (M <= rows_max) {
@@ -1531,7 +1541,7 @@ int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx,
     if (scratch && !aligned(scratch, 256)) return GPTQ_E_ALIGN;
     void *mm_ws = (char *)workspace + WS_BYTES;
     const int K = L.K, N = L.N, bits = L.bits, gs = L.groupsize, ns = L.nsets;
-    const int rows_max = decode_rows_max(K, N, ns, bits);
+    const int rows_max = decode_rows_max(K, N, ns, bits, gs);
     const bool add_fused = !(L.bias && residual);                   // one add slot per launch: bias OR residual
     const void *add = residual && add_fused ? residual : L.bias;
     const int64_t ldb = residual && add_fused ? ldr : 0;

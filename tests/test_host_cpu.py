@@ -555,7 +555,10 @@ def test_layer_route_table_is_host_logic():
         assert route(65536, K, N, nsets=ns) == OWN                                                # BASELINE config 3
         for M in (1, 5, 64, 129, 1025, 1536, 2048, 3072, 4095, 65536):
             assert route(M, K, N, nsets=ns) != LIBR and route(M, K, N, nsets=ns, image=0) != LIBR  # the library is off the default route (K % 128 == 0)
-    assert route(8, 4096, 4096) == DEC and route(8, 4096, 12288) == TILES        # row groups only while one round of workgroups covers N
+    # round 6: 5 .. 8 rows stay in the decode launch wherever its 16x16x16 inner product serves the layer (groups spanning a row block, not 2-bit);
+    # before: row groups only while one round of workgroups covers N
+    assert route(8, 4096, 4096) == DEC and route(8, 4096, 12288) == DEC and route(9, 4096, 12288) == TILES and route(8, 4096, 11008, nsets=2) == DEC
+    assert route(8, 4096, 12288, gs=32) == TILES and route(8, 4096, 12288, bits=2) == TILES and route(8, 8192, 24576) == TILES
     assert route(8, 11008, 4096) == DEC and route(9, 11008, 4096) == TILES     # round 5: eight rows of x in two K halves (stripe_gemv2p_kernel); round 4: TILES
     assert route(8, 16384, 4096) == TILES                                       # ... up to K = 12288
     assert route(300, 4000 // 128 * 128 + 32, 4096, image=0) == LIBR             # K % 128 != 0: no own dense kernel -> the library

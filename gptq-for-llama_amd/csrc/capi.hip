@@ -423,6 +423,8 @@ const char *gptq_strerror(int code) {
 int gptq_set_gemv_variant(int variant) { return g_force_variant.exchange(variant); }
 int gptq_set_split_k(int split_k) { return g_force_split_k.exchange(split_k); }
 void *gptq_set_debug_buffer(void *buf) { return g_debug_buffer.exchange(buf); }
+/* test support (tests/test_gpu_soak.py): one launch that overwrites the whole LDS of every CU with pattern ^ index */
+int gptq_debug_dirty_lds(uint32_t pattern, gptq_stream_t stream) { return dirty_lds_launch(pattern, (hipStream_t)stream); }
 int gptq_set_gemm_kernel(int version) {
     return (version == 2 || version == 3 || (version >= 100 && version <= 104)) ? gemm_set_version(version) : GPTQ_E_VARIANT;
 }

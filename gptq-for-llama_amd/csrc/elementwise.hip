@@ -565,4 +565,20 @@ int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int 
     return (int)hipGetLastError();
 }
 
+// ---- test support: overwrite every CU's LDS (soak tests: a decode launch must not depend on what the previous kernel left there) ----
+__global__ void __launch_bounds__(256) dirty_lds_kernel(uint32_t pattern, uint32_t *sink, int words) {
+    extern __shared__ uint32_t lds_all[];
+    for (int i = threadIdx.x; i < words; i += 256) lds_all[i] = pattern ^ (uint32_t)i;
+    __syncthreads();
+    if (sink && lds_all[(threadIdx.x * 97) % words] == 0x12345678u) sink[0] = 1;   // (keeps the stores alive)
+}
+
+int dirty_lds_launch(uint32_t pattern, hipStream_t s) {
+    constexpr int BYTES = 160 * 1024 - 256;
+    static LdsOptIn opt_in;
+    if (int rc = opt_in.ensure((const void *)dirty_lds_kernel, BYTES)) return rc;
+    hipLaunchKernelGGL(dirty_lds_kernel, dim3(1024), dim3(256), BYTES, s, pattern, (uint32_t *)nullptr, BYTES / 4);   // one workgroup per CU at a time: four rounds
+    return (int)hipGetLastError();
+}
+
 }  // namespace gptq

@@ -107,6 +107,7 @@ int silu_mul_launch(const half_t *g, int64_t ldg, const half_t *u, int64_t ldu, 
 int silu_mul_f32_launch(const float *g, int64_t ldg, const float *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
 int gather_cols_launch(const half_t *x, int64_t ldx, const int32_t *perm, half_t *xg, int64_t ldg, int M, int K, hipStream_t s);   // xg = x[:, perm]
 int add_rows_launch(half_t *y, int64_t ldy, const half_t *r, int64_t ldr, int M, int N, hipStream_t s);   // y = fp16(y + r)
+int dirty_lds_launch(uint32_t pattern, hipStream_t s);   // test support: every CU's LDS overwritten
 int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
 

@@ -28,6 +28,7 @@ _SIGNATURES = {
     'gptq_set_gemv_variant': [c_int],
     'gptq_set_split_k': [c_int],
     'gptq_set_debug_buffer': [c_void_p],
+    'gptq_debug_dirty_lds': [ctypes.c_uint32, c_void_p],
     'gptq_set_gemm_kernel': [c_int],
     'gptq_set_prefill_route': [c_int],
     'gptq_set_stripe_mm_pass_rows': [c_int],

@@ -104,6 +104,9 @@ int gptq_prefill_plan_count(void);
 /* Development aid: when non-NULL, the decode kernels write per-wave s_memtime checkpoints
  * ([block][wave][8] uint64) into this device buffer.  Returns the previous pointer. */
 void *gptq_set_debug_buffer(void *device_buffer);
+/* Test support: one launch that overwrites all 160 KB of LDS on every CU with (pattern ^ word index) -- the soak test interleaves it with the decode
+ * launches: no kernel of this library may read LDS it has not written (tests/test_gpu_soak.py). */
+int gptq_debug_dirty_lds(uint32_t pattern, gptq_stream_t stream);
 /* debug hook: device uint32 that every stripe16 decode launch (M = 1) increments (one relaxed device-scope add) when it starts; NULL
  * (default) = no tick.  Used by tools/warmlab.hip to pace a run-ahead prefetcher on a second stream (measured, loses: DESIGN 3.6). */
 int gptq_set_progress_counter(void *device_u32);

@@ -1,0 +1,150 @@
+"""Soak of the decode path (round 6): every launch the LLaMA-7B engine dispatches -- the four linears of a block at 1 .. 16 rows
+with the norm / residual they carry, the attention launches (self-merging, and split records + the merging o_proj) at several depths -- repeated
+thousands of times with the same inputs, every result compared BIT FOR BIT with the first one, while between the launches
+  (i)   a kernel overwrites all 160 KB of LDS of every CU (gptq_debug_dirty_lds),
+  (ii)  everything the path hands to C as scratch -- the tail of the layer workspace behind its zero-initialised split-K words, the
+        gptq_layer_decode_f16 scratch, the attention records (not its tickets: those are state, "zero between launches") -- is overwritten with 0xFF
+        bytes (NaN as fp16 and as fp32), and
+  (iii) fresh processes whose FIRST launch of the library is the decode launch are compared with a torch product (tools/first_launch_probe.py).
+A kernel that reads LDS, scratch or records it has not written in the same launch, or that depends on its predecessor, shows up as a differing
+launch.  (Background: one unexplained 27 % mismatch of the first test of a process on one box in round 5)
+
+GPTQ_SOAK_LAUNCHES (default 20000) launches per instance."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from quant import _native
+from quant.layer import prepared
+from util import make_random_layer
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+LAUNCHES = int(os.environ.get('GPTQ_SOAK_LAUNCHES', '20000'))
+RING = 50          # launches between two comparisons (and two rounds of dirtying)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+class Dirt:
+    """the three kinds of stale state, refreshed with a pattern that changes from round to round"""
+
+    def __init__(self, scratch_bytes):
+        self.lib = _native.lib()
+        self.s = _native.stream_ptr(torch.device(DEV))
+        self.lws = _native.layer_workspace(torch.device(DEV), self.s)
+        self.zeroed = self.lib.gptq_query(3)                      # split-K words: zero on first use, left zero by every launch (a contract, not scratch)
+        self.scratch = torch.empty(max(scratch_bytes, 256), dtype=torch.uint8, device=DEV)
+        self.n = 0
+
+    def __call__(self, extra=()):
+        self.n += 1
+        _native.check(self.lib.gptq_debug_dirty_lds(0x7FC00000 ^ (self.n * 0x9E3779B1 & 0xFFFFFFFF), self.s), 'dirty lds')
+        self.lws[self.zeroed:].fill_(0xFF)
+        self.scratch.fill_(0xFF)
+        for t in extra:
+            t.fill_(0xFF)
+
+
+def soak(launch, out_shape, dirt, extra=(), launches=LAUNCHES):
+    """launch(y): one launch into y.  The first result is the reference; then blocks of RING launches into a ring of outputs, dirt between the blocks"""
+    ref = torch.full(out_shape, float('nan'), dtype=torch.float16, device=DEV)
+    dirt(extra)
+    launch(ref)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref.float()).all()
+    ring = torch.empty((RING,) + tuple(out_shape), dtype=torch.float16, device=DEV)
+    done = 0
+    while done < launches:
+        ring.fill_(float('nan'))
+        dirt(extra)
+        for i in range(RING):
+            launch(ring[i])
+            if i % 10 == 9:                     # ... and in the middle of a block: different predecessors for the same launch
+                dirt(extra)
+        same = (ring.view(torch.int16) == ref.view(torch.int16).unsqueeze(0)).flatten(1).all(1)
+        assert bool(same.all()), ('launch %d of %d differs from the first' % (done + int((~same).nonzero()[0]), launches),
+                                  int((ring[int((~same).nonzero()[0])] != ref).sum()))
+        done += RING
+
+
+LINEARS = [('qkv + norm', 4096, 12288, 1, True, False), ('o_proj + residual', 4096, 4096, 1, False, True),
+           ('gate | up + norm', 4096, 11008, 2, True, False), ('down_proj + residual', 11008, 4096, 1, False, True)]
+
+
+@pytest.mark.parametrize('M', [1, 2, 4, 5, 8, 9, 16])
+@pytest.mark.parametrize('name,K,N,NS,norm,res', LINEARS)
+def test_soak_decode_linears(name, K, N, NS, norm, res, M):
+    bits, gs = 4, 128
+    Ls = [make_random_layer(bits, gs, K, N, seed=40 + i) for i in range(NS)]
+    sets = tuple((dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx'])) for L in Ls)
+    pl = prepared(sets, None, bits, gs, K, N)
+    lib = _native.lib()
+    rng = np.random.default_rng(M + N)
+    x = dev(rng.standard_normal((M, K)).astype(np.float16))
+    nw = dev((1 + 0.1 * rng.standard_normal(K)).astype(np.float16))
+    r = dev(rng.standard_normal((M, N)).astype(np.float16))
+    dirt = Dirt(lib.gptq_layer_decode_scratch_bytes(pl.handle, M))
+
+    def launch(y):
+        rc = lib.gptq_layer_decode_f16(pl.handle, x.data_ptr(), K, y.data_ptr(), N, M, nw.data_ptr() if norm else None, 1e-6, r.data_ptr() if res else None,
+                                       N if res else 0, dirt.lws.data_ptr(), dirt.lws.numel(), dirt.scratch.data_ptr(), dirt.scratch.numel(), dirt.s)
+        assert rc == 0, rc
+    soak(launch, (M, N), dirt)
+
+
+@pytest.mark.parametrize('B,pos', [(1, 0), (1, 100), (1, 700), (1, 2040), (4, 900), (16, 300)])
+def test_soak_attention(B, pos):
+    """the attention launch of the engine: self-merging (tickets must return to zero: checked after every block) and, at batch 1, the split records
+    consumed by o_proj's decode kernel -- the records region is scribbled between the launches"""
+    lib = _native.lib()
+    heads, hd, t_max = 32, 128, 2048
+    H = heads * hd
+    s = _native.stream_ptr(torch.device(DEV))
+    g = torch.Generator(device=DEV).manual_seed(pos + B)
+    qkv = torch.randn((B, 3 * H), device=DEV, generator=g).half()
+    kc = (torch.randn((B, t_max, H), device=DEV, generator=g) * 0.5).half()
+    vc = (torch.randn((B, t_max, H), device=DEV, generator=g) * 0.5).half()
+    p = torch.tensor([max(pos - 37 * b, 0) for b in range(B)], dtype=torch.int64, device=DEV)
+    tab = torch.empty((t_max, hd // 2, 2), dtype=torch.float32, device=DEV)
+    _native.check(lib.gptq_rope_table_f32(tab.data_ptr(), t_max, hd, 10000.0, s), 'rope table')
+    scale = 1.0 / np.sqrt(hd)
+    nb = lib.gptq_decode_attn_batch_workspace_bytes(B, heads, hd, t_max)
+    S = lib.gptq_decode_attn_splits(B, heads, hd, t_max)
+    rec_bytes = B * S * heads * (hd * 2 + 8)                      # records; the tickets behind them are state
+    ws = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+    dirt = Dirt(256)
+    n = max(LAUNCHES // 4, RING)
+
+    def launch(y):
+        rc = lib.gptq_decode_attn_batch_f16(qkv.data_ptr(), 3 * H, p.data_ptr(), kc.data_ptr(), vc.data_ptr(), y.data_ptr(), H, ws.data_ptr(), nb, B, heads, hd, t_max,
+                                            10000.0, scale, tab.data_ptr(), None, s)
+        assert rc == 0, rc
+    soak(launch, (B, H), dirt, extra=(ws[:rec_bytes],), launches=n)
+    assert not bool(ws[rec_bytes:].any())                           # every ticket back at zero
+    if B == 1:
+        L = make_random_layer(4, 128, H, H, seed=7)
+        pl = prepared(((dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx'])),), None, 4, 128, H, H)
+        res = torch.randn((1, H), device=DEV, generator=g).half()
+
+        def launch2(y):
+            rc = lib.gptq_decode_attn_split_f16(qkv.data_ptr(), 3 * H, p.data_ptr(), kc.data_ptr(), vc.data_ptr(), ws.data_ptr(), nb, 1, heads, hd, t_max, 10000.0, scale,
+                                                tab.data_ptr(), 0, s)
+            assert rc == 0, rc
+            rc = lib.gptq_layer_decode_attn_f16(pl.handle, ws.data_ptr(), nb, p.data_ptr(), 1, heads, hd, t_max, 0, y.data_ptr(), H, res.data_ptr(), H, s)
+            assert rc == 0, rc
+        soak(launch2, (1, H), dirt, extra=(ws[:rec_bytes],), launches=n)
+
+
+def test_soak_first_launch_of_a_fresh_process():
+    """(iii): the decode launch as the first kernel launch of the library in a process, twice, against a torch product -- several processes"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for seed in range(int(os.environ.get('GPTQ_SOAK_PROCESSES', '6'))):
+        out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'first_launch_probe.py'), str(seed)], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and 'OK' in out.stdout and 'MISMATCH' not in out.stdout, (out.stdout[-400:], out.stderr[-400:])

@@ -462,6 +462,41 @@ int gptq_matmul248_f16(const void *x, int64_t ldx, const int32_t *qweight, const
     return run_auto(q, (hipStream_t)stream);
 }
 
+/* round 6: the fp32 partial product of a ROW SHARD of a layer with any g_idx (an act-order layer cut for tensor parallelism: the shard's k range
+ * is fixed by the heads / by gate-up's columns, its rows point into ALL groups of the layer) -- y32[M][ldy] = x[M][K] . W[rows of the shard],
+ * the sums unrounded: the caller's all-reduce adds the ranks' partials and rounds ONCE (north_star: fp32 partials, one rounding per layer).
+ * qweight: the shard's K / 32 * bits packed rows; scales [n_groups][N] / qzeros [n_groups][N / 32 * bits]: the WHOLE layer's tables;
+ * g_idx [K]: the group of each of the shard's rows (required).  The weight is dequantised as the reference does (quant_linear.py:128). */
+int gptq_matmul248_partial_f32(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *g_idx, float *y32,
+                               int64_t ldy, int M, int K, int N, int bits, int n_groups, gptq_stream_t stream) {
+    if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
+    if (M < 0 || K <= 0 || N <= 0 || n_groups <= 0 || n_groups > 65535 || K % 32 != 0 || N % 32 != 0 || ldx < K || ldy < N) return GPTQ_E_SHAPE;
+    if (!x || !qweight || !scales || !qzeros || !g_idx || !y32) return GPTQ_E_NULL;
+    if (!aligned(x, 2) || !aligned(qweight, 16) || !aligned(scales, 2) || !aligned(qzeros, 4) || !aligned(g_idx, 4) || !aligned(y32, 4)) return GPTQ_E_ALIGN;
+    for (int m0 = 0; m0 < M;) {
+        int mr = M - m0 >= 4 ? 4 : (M - m0 >= 2 ? 2 : 1);
+        int nl = 16;
+        auto need = [&](int mr_, int nl_) { return (size_t)mr_ * K * 2 + (size_t)K * 2 + 16 + (size_t)n_groups * 4 * nl_ * 4; };
+        if (need(mr, nl) > 150 * 1024 || (N / 64) < 128) nl = 4;
+        while (mr > 1 && need(mr, nl) > 150 * 1024) mr >>= 1;
+        if (need(mr, nl) > 150 * 1024) return GPTQ_E_SHAPE;
+        GemvParams p{};
+        p.x = (const half_t *)x + (size_t)m0 * ldx;
+        p.ldx = ldx;
+        p.qw[0] = (const uint32_t *)qweight; p.sc[0] = (const half_t *)scales; p.qz[0] = qzeros; p.gi[0] = g_idx;
+        p.y32 = y32 + (size_t)m0 * ldy;
+        p.ldy = ldy;
+        p.M = mr; p.K = K; p.N = N; p.G = n_groups; p.groupsize = 1;
+        p.ntiles = (N + 4 * nl - 1) / (4 * nl);
+        p.split_k = 1;
+        p.nchunks = K / 32;
+        p.chunks_per_slice = K / 32;
+        if (int rc = gemv_generic_dispatch(bits, false, nl, p, (hipStream_t)stream)) return rc;
+        m0 += mr;
+    }
+    return GPTQ_OK;
+}
+
 int gptq_gemv_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros,
                   const int32_t *g_idx, const void *bias, void *y, int64_t ldy, int M, int K, int N, int bits,
                   int groupsize, void *workspace, size_t workspace_bytes, gptq_stream_t stream) {
@@ -1333,6 +1368,25 @@ static int decode_rows_max(int K, int N, int nsets, int bits, int groupsize) {
     return (bits != 2 && N / 16 > 512 && K <= 5 * 8 * bk) ? 8 : 4;
 }
 
+// round 6: 9 .. 16 rows in the decode launch (stripe_gemvc_kernel, MF with sixteen distinct A rows): K <= 4096, groups that span a row block, not
+// 2-bit; the launch itself declines when the tables do not fit LDS next to sixteen rows of x.  Returns a mask: 1 = launches with the fused norm,
+// 2 = plain launches.  Measured (profiles/r6h_mf16/, us per launch at 16 rows, this kernel / 16-row tiles): gate | up pair plain 13.5 / 15.3 -- but
+// with the norm fused 17.3 / 17.6 (tiles + the stand-alone norm launch): every one of the 230 workgroups normalises all 16 x 4096 elements itself,
+// ~330 VALU instructions per thread, more than the launch boundary of the 16-workgroup norm kernel costs; qkv plain 9.4 / 9.5, fused norm 13.2 / 12.1;
+// o_proj plain 6.5 / 5.4.  So: the pair takes this kernel PLAIN behind the norm launch (16.0 against 17.6), single sets stay on the tiles.
+// GPTQ_DECODE_MF16 = mask pins it for every shape (A/B).
+static int decode_rows_mf16(int K, int N, int nsets, int bits, int groupsize) {
+    static const int mode = [] { const char *e = getenv("GPTQ_DECODE_MF16"); return e ? atoi(e) : -1; }();
+    static const int mf8 = [] { const char *e = getenv("GPTQ_DECODE_MF8"); return e ? atoi(e) : 1; }();
+    if (!mode || !mf8 || bits == 2) return 0;
+    const int bk = bits == 8 ? 64 : 128;
+    const int gq = stripe_gq_shift(K, N, bits, groupsize);
+    const int nu = (K / bk + 7) / 8;
+    if (!(gq == -1 || gq >= 2) || nu * 8 * bk > 4096 || (N / 16 > 256 && nu > 5) || N / 16 > 1024) return 0;
+    if (mode > 0) return mode;
+    return nsets == 2 ? 2 : 0;
+}
+
 // Round 5: 129 .. gptq_set_stripe_gemm_max_rows() rows -- the fused tile GEMM on the image, or dequantise + the tile GEMM of gemm8.hip?  Once gemm8 gave
 // every XCD the same number of tiles (gemm8.hip, round 5) the dense route became the faster OWN kernel where the image route's 128 x 128 tiles no
 // longer fit the chip at once (two workgroups per CU = 512 tiles; beyond that its time steps up: 4096 x 12288 at 640 / 768 rows 84.6 / 118.9 us
@@ -1392,7 +1446,8 @@ int gptq_layer_route_for_shape(int M, int K, int N, int bits, int groupsize, int
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     const int gq = stripe_gq_shift(K, N, bits, groupsize);
     const bool image = has_image && gq != -2 && kind != 2;
-    const int rows_max = decode_rows_max(K, N, nsets, bits, groupsize);
+    int rows_max = decode_rows_max(K, N, nsets, bits, groupsize);
+    if (M > 8 && M <= 16 && (decode_rows_mf16(K, N, nsets, bits, groupsize) & 2)) rows_max = std::max(rows_max, 16);   // round 6: sixteen A rows (the pair)
     if (image && (kind == 0 || M == 1) && M <= rows_max && (M <= 4 || K <= 9216 || (K <= 12288 && nsets == 1))) return GPTQ_ROUTE_STRIPE_DECODE;
     if (image && M > 1) {
         if (M <= rows_max && kind == 1 && (M <= 4 || K <= 9216 || (K <= 12288 && nsets == 1))) return GPTQ_ROUTE_STRIPE_DECODE;       // after one gather of x
@@ -1420,7 +1475,8 @@ int gptq_layer_forward(const gptq_layer_t *layer, const void *x, int64_t ldx, vo
     if (!workspace || !aligned(workspace, 256) || workspace_bytes < gptq_layer_workspace_bytes()) return GPTQ_E_WORKSPACE;
     void *mm_ws = (char *)workspace + WS_BYTES;
     const int K = L.K, N = L.N, bits = L.bits, gs = L.groupsize, ns = L.nsets;
-    const int rows_max = decode_rows_max(K, N, ns, bits, gs);    // row groups only while ONE round of workgroups covers N
+    int rows_max = decode_rows_max(K, N, ns, bits, gs);    // row groups only while ONE round of workgroups covers N
+    if (M > 8 && M <= 16 && (decode_rows_mf16(K, N, ns, bits, gs) & 2)) rows_max = std::max(rows_max, 16);   // round 6: sixteen A rows (the pair)
     // ---- 1. decode and small batches on the stripe16 image ----
     if (L.stripe && L.kind == 0) {
         if (M <= rows_max) {
@@ -1552,8 +1608,9 @@ int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx,
         return rc;
     };
     const bool image = L.stripe != nullptr && L.kind != 2;
+    const int mf16 = M > 8 && M <= 16 ? decode_rows_mf16(K, N, ns, bits, gs) : 0;
     // 1. everything in the decode kernel's launch
-    if (image && M <= rows_max && (L.kind == 0 || M == 1)) {
+    if (image && (M <= rows_max || (norm_weight ? (mf16 & 1) : (mf16 & 2))) && (L.kind == 0 || M == 1)) {
         const int rc = stripe_matvec(x, ldx, L.stripe, L.stripe_bytes, add, y, ldy, nullptr, M, K, N, bits, gs, ns, norm_weight, norm_eps,
                                      L.kind == 1 ? L.perm16 : nullptr, stream, nullptr, 0, false, ldb);
         if (rc != GPTQ_E_VARIANT) return finish(rc);
@@ -1572,7 +1629,7 @@ int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx,
         sp += nb; left -= nb;
     }
     if (image && L.kind == 0) {
-        if (M <= rows_max && norm_weight) {   // (the decode kernel declined WITH the norm -- LDS -- but may take the rows without it)
+        if ((M <= rows_max || (mf16 & 2)) && norm_weight) {   // (the decode kernel declined WITH the norm -- LDS -- but may take the rows without it)
             const int rc = stripe_matvec(xin, ldin, L.stripe, L.stripe_bytes, add, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, nullptr, 0,
                                          false, ldb);
             if (rc != GPTQ_E_VARIANT) return finish(rc);

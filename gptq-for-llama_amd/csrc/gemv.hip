@@ -522,6 +522,12 @@ __global__ void __launch_bounds__(WAVES * 64) gemv_generic_kernel(const GemvPara
             }
             float v = a[0];
             if constexpr (FUSED2) v = a[0] * (1.0f / (1.0f + __expf(-a[0]))) * a[1];
+            if constexpr (!FUSED2) {
+                if (p.y32) {   // a row shard's partial product: rounded once, by whoever sums the shards (tensor parallel act-order layers)
+                    p.y32[(size_t)m * p.ldy + n] = v;
+                    continue;
+                }
+            }
             half_t h = (half_t)v;
             if (p.bias) h = (half_t)((float)h + (float)p.bias[n]);
             p.y[(size_t)m * p.ldy + n] = h;

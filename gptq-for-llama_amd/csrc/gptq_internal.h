@@ -63,6 +63,7 @@ struct GemvParams {
     const half_t *norm_w;  // non-NULL: RMS-normalise x on the fly with this weight (M == 1 rowwave only)
     float norm_eps;
     u64_t *dbg;  // optional timeline buffer [blocks][waves][8] (tools/timeline.py), else nullptr
+    float *y32 = nullptr;  // generic kernel only (round 6): the fp32 sums leave unrounded, [M][ldy] -- the partial product of a ROW shard (no bias, single set)
 };
 
 int gemv_fast_dispatch(int bits, bool fused2, int u, const GemvParams &p, hipStream_t s);

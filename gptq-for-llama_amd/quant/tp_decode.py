@@ -24,7 +24,8 @@ Round 5:
     module chain's rounding order (fp16(fp16(sum) + bias), then + residual).
   * act-order: column shards (qkv, gate / up) take the group-sorted image + in-kernel gather of a regular act-order layer; a ROW shard
     of an act-order layer touches every group irregularly (its k range is fixed by the heads / by gate-up's columns), so it runs the
-    generic g_idx kernel on the checkpoint rows (correct, slower, and its fp16 partial adds one rounding per rank).
+    generic g_idx kernel on the checkpoint rows with the whole layer's scale / zero tables (correct, slower) -- round 6: with an fp32
+    partial like every other shard (gptq_matmul248_partial_f32): fp32 partials, one all-reduce, ONE rounding per linear.
 """
 import numpy as np
 import torch
@@ -288,7 +289,6 @@ class TPDecodeEngine:
         self.x, self.x2, self.h = torch.zeros((1, H), **f16), torch.zeros((1, H), **f16), torch.zeros((1, H), **f16)
         self.qkvb, self.ab, self.cb = torch.zeros((1, 3 * self.Hl), **f16), torch.zeros((1, self.Hl), **f16), torch.zeros((1, self.Il_max), **f16)
         self.part = torch.zeros((1, H), **f32)
-        self.y16 = torch.zeros((1, H), **f16)
         self.logits = torch.zeros((1, self.lm_head.shape[0]), **f16)
         nl = len(self.layers)
         self.kc, self.vc = torch.zeros((nl, self.t_max, self.Hl), **f16), torch.zeros((nl, self.t_max, self.Hl), **f16)
@@ -322,18 +322,13 @@ class TPDecodeEngine:
             rc = self.lib.gptq_stripe_matvec_partial_f32(x.data_ptr(), st.data_ptr(), st.numel(), self.part.data_ptr(), K, N, bits, gs, 1, None, s)
             self.native.check(rc, 'gptq_stripe_matvec_partial_f32')
             return
-        # a row shard of an act-order layer: generic g_idx kernel on the checkpoint rows, fp16 out, widened (one extra rounding per rank).
-        # The shard's rows point into ALL groups of the layer: the kernel sizes its {scale, zero} table from ceil(K / groupsize) and looks
-        # groups up through g_idx only, so it is told a group size small enough for the table to hold every group of the full layer.
+        # a row shard of an act-order layer: its rows point into ALL groups of the layer -- the generic g_idx kernel on the checkpoint rows with
+        # the whole layer's {scale, zero} tables, fp32 sums out (round 6: like every other shard -- fp32 partials, ONE rounding after the exchange;
+        # until round 5 this launch stored fp16 and cost one extra rounding per rank)
         qw, sc, qz, gi = generic
-        gfull = sc.shape[0]
-        gs_tab = max(1, K // gfull)
-        if (K + gs_tab - 1) // gs_tab < gfull:
-            raise NotImplementedError('TPDecodeEngine: act-order row shard shorter than the number of groups')
-        rc = self.lib.gptq_matmul248_f16(x.data_ptr(), K, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), gi.data_ptr(), None, self.y16.data_ptr(), N, 1, K, N, bits,
-                                         gs_tab, self.ws.data_ptr(), self.ws.numel(), s)
-        self.native.check(rc, 'gptq_matmul248_f16')
-        self.part.copy_(self.y16)
+        rc = self.lib.gptq_matmul248_partial_f32(x.data_ptr(), K, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), gi.data_ptr(), self.part.data_ptr(), N, 1, K, N, bits,
+                                                 sc.shape[0], s)
+        self.native.check(rc, 'gptq_matmul248_partial_f32')
 
     def _step(self):
         lib, H = self.lib, self.hidden

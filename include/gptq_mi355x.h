@@ -124,6 +124,16 @@ int gptq_matmul248_f16(const void *x, int64_t ldx, const int32_t *qweight, const
                        int64_t ldy, int M, int K, int N, int bits, int groupsize, void *workspace,
                        size_t workspace_bytes, gptq_stream_t stream);
 
+/* Round 6: the fp32 partial product of a ROW SHARD of a layer with ANY g_idx -- what a tensor-parallel rank computes for o_proj / down_proj of an
+ * act-order checkpoint (the reference has no tensor parallelism: llama.py:328-382 places whole layers; north_star: K-shards, fp32 partials, ONE
+ * all-reduce and ONE fp16 rounding per linear).  The shard's k range is fixed by the rank's heads / gate-up columns, so its rows point into all
+ * groups of the layer: qweight = the shard's K / 32 * bits packed rows, scales [n_groups][N] / qzeros [n_groups][N / 32 * bits] = the WHOLE
+ * layer's tables, g_idx [K] = the group of each of the shard's rows (required).  y32[M][ldy] = x[M][K] . dequant(W shard), sums left in fp32
+ * (weights dequantised as matmul_248_kernel does, quant_linear.py:128; fp32 accumulate).  Replaces the fp16-output generic launch that cost one
+ * extra rounding per rank. */
+int gptq_matmul248_partial_f32(const void *x, int64_t ldx, const int32_t *qweight, const void *scales, const int32_t *qzeros, const int32_t *g_idx,
+                               float *y32, int64_t ldy, int M, int K, int N, int bits, int n_groups, gptq_stream_t stream);
+
 /* Same contract, forcing one kernel family (tests and benchmarks). */
 int gptq_gemv_f16(const void *x, int64_t ldx, const int32_t *qweight, const void *scales,
                   const int32_t *qzeros, const int32_t *g_idx, const void *bias, void *y,

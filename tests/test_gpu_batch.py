@@ -83,7 +83,7 @@ def test_layer_decode_norm_and_residual(bits, K, N, gs, NS, M):
             assert rel_err(y, ref) < (2 * TOL if NS == 2 else TOL if not use_res else 1.5 * TOL), (use_norm, use_res, rel_err(y, ref))
 
 
-@pytest.mark.parametrize('M', [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize('M', [1, 2, 3, 4, 5, 8, 9, 13, 16])          # 9 .. 16 (round 6): sixteen A rows of the 16x16x16 inner product, one deferred epilogue
 @pytest.mark.parametrize('bits,K,N,gs,NS', [(4, 4096, 12288, 128, 1),      # qkv of LLaMA-7B: 768 stripes = 256 workgroups x 3
                                             (4, 512, 8224, 128, 1),        # 514 stripes: the last workgroup owns ONE stripe
                                             (4, 1024, 8224, 128, 2),       # ... as a gate | up pair (two table pieces per thread)

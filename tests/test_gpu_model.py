@@ -1010,8 +1010,8 @@ def _tp_variants_worker(rank, world, port, ret, variant):
                 eng.capture()
             got = np.stack([eng.decode(ids[0, i]).float().cpu().numpy()[0] for i in range(9)])
             err = np.abs(got - expect).max() / np.abs(expect).max()
-            # (act-order row shards run the generic kernel with fp16 partials: one more rounding per rank)
-            ok = ok and np.isfinite(got).all() and err < (ENGINE_TOL if variant == 'bias' else 2 * ENGINE_TOL) and eng.status() == 0
+            # (round 6: act-order row shards leave as fp32 partials like every other shard -- the same bar as the trivial-g_idx engine)
+            ok = ok and np.isfinite(got).all() and err < ENGINE_TOL and eng.status() == 0
         if variant == 'bias' and rank == 0:      # the single-GPU engine takes bias + residual too (one launch for the matvec + bias, one for the add)
             e1 = D.DecodeEngine(model, t_max=64).capture()
             g1 = np.stack([e1.decode(ids[0, i]).float().cpu().numpy()[0] for i in range(9)])

@@ -445,6 +445,68 @@ def test_act_order_and_3bit(bits, M):
     check_forward(x, L)
 
 
+@pytest.mark.parametrize('bits', [4, 8, 3])
+@pytest.mark.parametrize('world,M', [(8, 1), (4, 3), (2, 1)])
+def test_act_order_row_shards_fp32_partials_one_rounding(bits, world, M):
+    """Round 6: a tensor-parallel rank's ROW shard of an act-order layer -- rows k0 .. k1 of the checkpoint, whose g_idx points
+    into all groups of the layer -- leaves as an fp32 partial (gptq_matmul248_partial_f32), like every other shard: the ranks' partials are summed
+    in fp32 and rounded ONCE (north_star).  Simulated for `world` ranks on one GPU: (a) every partial is the float64 sum of its shard (weights
+    dequantised as the reference does) to fp32 accuracy; (b) fp16(sum of the partials in rank order) is the correctly rounded result up to that
+    fp32 noise -- equal to the rounded float64 sum or its neighbour, and within half an ulp + the noise; (c) the round-5 way (an fp16 output per
+    rank, widened and summed) is measurably worse on the same data."""
+    K, N, gs = 2048, 512, 128
+    L = make_random_layer(bits, gs, K, N, act_order=True, seed=60 + bits)
+    rng = np.random.default_rng(world + M)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    lib = _native.lib()
+    s = _native.stream_ptr(torch.device(DEV))
+    ws = _native.workspace(torch.device(DEV))
+    W = oracle.np_dequant(L['qweight'], L['qzeros'], L['scales'], L['g_idx'], bits, faithful=True).astype(np.float64)      # [K, N], the reference's fp16 weight
+    sc, qz = dev(L['scales']), dev(L['qzeros'])
+    G = L['scales'].shape[0]
+    Ks = K // world
+    parts, parts16, exact = [], [], np.zeros((M, N))
+    for r in range(world):
+        k0, k1 = r * Ks, (r + 1) * Ks
+        qw = dev(L['qweight'][k0 * bits // 32:k1 * bits // 32])
+        gi = dev(L['g_idx'][k0:k1])
+        xs = dev(x[:, k0:k1])
+        y32 = torch.full((M, N), float('nan'), dtype=torch.float32, device=DEV)
+        rc = lib.gptq_matmul248_partial_f32(xs.data_ptr(), xs.stride(0), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), gi.data_ptr(), y32.data_ptr(), N, M, Ks, N,
+                                            bits, G, s)
+        assert rc == 0, rc
+        e = x[:, k0:k1].astype(np.float64) @ W[k0:k1]
+        mag = np.abs(x[:, k0:k1].astype(np.float64)) @ np.abs(W[k0:k1])
+        got = y32.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all()
+        assert (np.abs(got - e) <= mag * 2.0**-20).all(), np.abs(got - e).max()            # (a)
+        parts.append(y32)
+        exact += e
+        # round 5's launch: the generic kernel with an fp16 output (told a group size that makes its table hold every group of the layer)
+        y16 = torch.empty((M, N), dtype=torch.float16, device=DEV)
+        rc = lib.gptq_matmul248_f16(xs.data_ptr(), xs.stride(0), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), gi.data_ptr(), None, y16.data_ptr(), N, M, Ks, N, bits,
+                                    max(1, Ks // G), ws.data_ptr(), ws.numel(), s)
+        assert rc == 0, rc
+        parts16.append(y16.float())
+    total = parts[0].clone()
+    total16 = parts16[0].clone()
+    for r in range(1, world):
+        total += parts[r]                      # rank order, fp32: what the one-shot exchange does (csrc/p2p.hip)
+        total16 += parts16[r]
+    y = total.half().cpu().numpy()
+    y_old = total16.half().cpu().numpy()
+    best = exact.astype(np.float16)             # the correctly rounded result
+    ulp = np.spacing(np.abs(best).astype(np.float16)).astype(np.float64)
+    err, err_old = np.abs(y.astype(np.float64) - exact), np.abs(y_old.astype(np.float64) - exact)
+    assert (err <= 0.5 * ulp + np.abs(exact) * 2.0**-18 + 1e-7).all()                          # (b): one rounding
+    assert (y == best).mean() > 0.995
+    if world > 2:
+        assert err_old.max() > err.max() and (err_old > 0.5 * ulp + np.abs(exact) * 2.0**-18 + 1e-7).any()      # (c): one rounding per rank shows
+    # error paths: a missing g_idx / table, a K that is no multiple of 32
+    assert lib.gptq_matmul248_partial_f32(dev(x).data_ptr(), K, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, total.data_ptr(), N, M, Ks, N, bits, G, s) < 0
+    assert lib.gptq_matmul248_partial_f32(dev(x).data_ptr(), K, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), gi.data_ptr(), total.data_ptr(), N, M, Ks - 8, N, bits, G, s) < 0
+
+
 @pytest.mark.parametrize('bits,gs', [(4, 128), (4, 32), (8, 64), (2, 128)])
 @pytest.mark.parametrize('M', [1, 2, 70])
 def test_act_order_sorted_fast_path(bits, gs, M):

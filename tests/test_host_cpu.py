@@ -543,7 +543,8 @@ def test_layer_route_table_is_host_logic():
         return lib.gptq_layer_route_for_shape(M, K, N, bits, gs, nsets, kind, image)
     for K, N, ns in [(4096, 4096, 1), (4096, 12288, 1), (11008, 4096, 1), (4096, 11008, 2)]:
         assert route(1, K, N, nsets=ns) == DEC and route(4, K, N, nsets=ns) == DEC
-        assert route(16, K, N, nsets=ns) == TILES and route(128, K, N, nsets=ns) == TILES
+        # (round 6: 9 .. 16 rows of the gate | up pair stay in the decode launch -- sixteen A rows of its 16x16x16 inner product; single sets: 16-row tiles)
+        assert route(16, K, N, nsets=ns) == (DEC if ns == 2 else TILES) and route(17, K, N, nsets=ns) == TILES and route(128, K, N, nsets=ns) == TILES
         assert route(129, K, N, nsets=ns) == SGEMM and route(640, K, N, nsets=ns) == SGEMM        # a prompt: weights stay packed ...
         # ... while the image route's 128 x 128 tiles fit the chip at once (512) or the batch is too short to pay for a dequantise pass; above, the
         # dense route is the faster own kernel since gemm8 balances its tiles over the XCDs (round 5, profiles/r5e_gemm8_tile/)

@@ -1004,10 +1004,19 @@ int gptq_stripe_repack(const int32_t *qweight, const void *scales, const int32_t
                                 (const half_t *)scales_up, qzeros_up, stripes, K, N, bits, groupsize, (hipStream_t)stream);
 }
 
+// round 6: "also write h = rmsnorm(y) * w" (gptq_layer_decode_next_norm_f16); *done is set by the route that did
+struct NextNorm {
+    const void *w;
+    float eps;
+    void *h;
+    int64_t ldh;
+    int *done;
+};
+
 static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, float *y32,
                          int M, int K, int N, int bits, int groupsize, int nsets, const void *norm_weight, float norm_eps, const uint16_t *perm,
                          gptq_stream_t stream, void *mm_ws = nullptr, size_t mm_ws_bytes = 0, bool gemm_only_above_128 = false, int64_t ldb = 0,
-                         const int32_t *yperm = nullptr, const AttnMerge *att = nullptr) {
+                         const int32_t *yperm = nullptr, const AttnMerge *att = nullptr, const NextNorm *nn = nullptr) {
     if (bits != 2 && bits != 3 && bits != 4 && bits != 8) return GPTQ_E_BITS;
     if (M < 0 || K <= 0 || N <= 0 || groupsize <= 0 || K % 32 != 0 || N % 32 != 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
     if (!x || !stripes || (!y && !y32)) return GPTQ_E_NULL;
@@ -1046,6 +1055,9 @@ static int stripe_matvec(const void *x, int64_t ldx, const void *stripes, size_t
     p.gq_shift = gq;
     p.bits = bits;
     p.progress = M == 1 ? stripe_progress_counter() : nullptr;
+    if (nn && nn->w && mm_ws && M <= 16) {   // (16-row tiles: the slices' combine launch may write the next norm's rows too)
+        p.next_norm_w = (const half_t *)nn->w; p.next_norm_eps = nn->eps; p.h = (half_t *)nn->h; p.ldh = nn->ldh; p.next_norm_done = nn->done;
+    }
     if (att && att->o16) {
         if (M != 1 || mm_ws || y32 || yperm || perm || norm_weight || nsets != 1) return GPTQ_E_VARIANT;
         p.att = *att;
@@ -1582,9 +1594,9 @@ size_t gptq_layer_decode_scratch_bytes(const gptq_layer_t *layer, int M) {
     return a256((size_t)M * layer->K * 2) + gptq_layer_scratch_bytes(layer, M);
 }
 
-int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, const void *norm_weight, float norm_eps,
-                          const void *residual, int64_t ldr, void *workspace, size_t workspace_bytes, void *scratch, size_t scratch_bytes,
-                          gptq_stream_t stream) {
+static int layer_decode(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, const void *norm_weight, float norm_eps,
+                        const void *residual, int64_t ldr, void *workspace, size_t workspace_bytes, void *scratch, size_t scratch_bytes,
+                        gptq_stream_t stream, const NextNorm *nn) {
     if (!layer) return GPTQ_E_NULL;
     const gptq_layer &L = *layer;
     if (M < 0 || ldx < L.K || ldy < L.N || (residual && ldr < L.N)) return GPTQ_E_SHAPE;
@@ -1634,9 +1646,9 @@ int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx,
                                          false, ldb);
             if (rc != GPTQ_E_VARIANT) return finish(rc);
         }
-        if (M > 4) {                           // 16-row MFMA tiles, the residual in their epilogue
+        if (M > 4) {                           // 16-row MFMA tiles, the residual in their epilogue (and, with K slices, the next norm: nn)
             const int rc = stripe_matvec(xin, ldin, L.stripe, L.stripe_bytes, add, y, ldy, nullptr, M, K, N, bits, gs, ns, nullptr, 0.f, nullptr, stream, mm_ws,
-                                         STRIPE_MM_WS_BYTES, true, ldb);
+                                         STRIPE_MM_WS_BYTES, true, ldb, nullptr, nullptr, add_fused ? nn : nullptr);
             if (rc != GPTQ_E_VARIANT) return finish(rc);
         }
     }
@@ -1644,6 +1656,29 @@ int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx,
     const int rc = gptq_layer_forward(layer, xin, ldin, y, ldy, M, workspace, workspace_bytes, left ? sp : nullptr, left, stream);
     if (rc == 0 && residual) return add_rows_launch((half_t *)y, ldy, (const half_t *)residual, ldr, M, N, (hipStream_t)stream);
     return rc;
+}
+
+int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, const void *norm_weight, float norm_eps,
+                          const void *residual, int64_t ldr, void *workspace, size_t workspace_bytes, void *scratch, size_t scratch_bytes,
+                          gptq_stream_t stream) {
+    return layer_decode(layer, x, ldx, y, ldy, M, norm_weight, norm_eps, residual, ldr, workspace, workspace_bytes, scratch, scratch_bytes, stream, nullptr);
+}
+
+/* round 6: gptq_layer_decode_f16 + "leave the NEXT RMSNorm's rows behind if that is free": when this batch's route combines K slices in a launch of
+ * its own (9 .. 16 rows of a long-K layer: LLaMA's down_proj), that launch owns whole rows of y and also writes h[M][ldh] = rmsnorm(y) * next_norm_weight
+ * -- bit for bit what gptq_rmsnorm_f16 would write -- and *h_written = 1: the consumer (the next block's qkv) runs without its norm, one launch less
+ * per decoder block.  Every other route leaves h untouched and *h_written = 0 (the consumer keeps its fused / stand-alone norm). */
+int gptq_layer_decode_next_norm_f16(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, const void *norm_weight, float norm_eps,
+                                    const void *residual, int64_t ldr, const void *next_norm_weight, float next_norm_eps, void *h, int64_t ldh, int *h_written,
+                                    void *workspace, size_t workspace_bytes, void *scratch, size_t scratch_bytes, gptq_stream_t stream) {
+    if (!h_written) return GPTQ_E_NULL;
+    *h_written = 0;
+    if (!layer) return GPTQ_E_NULL;
+    static const int on = [] { const char *e = getenv("GPTQ_NEXT_NORM"); return e ? atoi(e) : 1; }();
+    if (!on || !next_norm_weight || !h || ldh < layer->N || M < 1 || M > 16)
+        return layer_decode(layer, x, ldx, y, ldy, M, norm_weight, norm_eps, residual, ldr, workspace, workspace_bytes, scratch, scratch_bytes, stream, nullptr);
+    NextNorm nn{next_norm_weight, next_norm_eps, h, ldh, h_written};
+    return layer_decode(layer, x, ldx, y, ldy, M, norm_weight, norm_eps, residual, ldr, workspace, workspace_bytes, scratch, scratch_bytes, stream, &nn);
 }
 
 // ---- round 6: o_proj of a decode step whose attention left split records instead of an fp16 row ----

@@ -103,6 +103,82 @@ int rmsnorm_launch(const half_t *x, int64_t ldx, const half_t *w, half_t *y, int
     return (int)hipGetLastError();
 }
 
+// ---- round 6: K slices' combine + residual + the NEXT RMSNorm in one launch (16-row tiles, stripe_mm.inc) ----
+// A decode batch of 9 .. 16 rows runs LLaMA's down_proj as K slices + a combine launch, and the next block starts with a stand-alone RMSNorm launch
+// of the same rows (at 16 rows the norm fused into the qkv launch costs more than a launch: every workgroup would normalise all 16 x 4096 elements
+// itself).  Here the combine owns whole ROWS -- one workgroup per row, the slices' partials arrive as fp32 rows [S][16][N] -- so it also writes
+// h = rmsnorm(y) * w for the consumer: one launch less per decoder block.  Arithmetic: the slices are added in slice order and the residual / bias is
+// added to the rounded sum exactly as stripe_mm_reduce_kernel does; the norm is rmsnorm_kernel's, thread for thread (same pieces per thread, same
+// order of the sum of squares, this file's strict floating-point flags): y and h are the bits the two launches produce.
+template <int VPT>
+__global__ void __launch_bounds__(256) slices_combine_norm_kernel(const float *__restrict__ partials, int S, int N, const half_t *__restrict__ add, int64_t ldb,
+                                                                  half_t *__restrict__ y, int64_t ldy, const half_t *__restrict__ nw, float eps,
+                                                                  half_t *__restrict__ h, int64_t ldh) {
+    const int row = blockIdx.x, tid = threadIdx.x, nv = N / 8;
+    half8_t v[VPT], wv[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+        const int c = tid + i * 256;
+        v[i] = (half8_t)(half_t)0;
+        wv[i] = (half8_t)(half_t)0;
+        if (c < nv) {
+            const float *first = partials + (size_t)row * N + (size_t)c * 8;
+            wv[i] = *(const half8_t *)(nw + (size_t)c * 8);
+            half8_t av = (half8_t)(half_t)0;
+            if (add) av = *(const half8_t *)(add + (ldb ? (size_t)row * ldb : (size_t)0) + (size_t)c * 8);
+            float4_t lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < S; sl++) {
+                lo += *(const float4_t *)(first + (size_t)sl * 16 * N);
+                hi += *(const float4_t *)(first + (size_t)sl * 16 * N + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                half_t hh = (half_t)(j < 4 ? lo[j & 3] : hi[j & 3]);
+                if (add) hh = (half_t)((float)hh + (float)av[j]);
+                v[i][j] = hh;
+            }
+            *(half8_t *)(y + (size_t)row * ldy + (size_t)c * 8) = v[i];
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float f = (float)v[i][j];
+            ss += f * f;
+        }
+    }
+    ss = wave_sum_xor(ss, 1);
+    __shared__ float part[4];
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    const float var = (part[0] + part[1] + part[2] + part[3]) / (float)N;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < VPT; i++) {
+        const int c = tid + i * 256;
+        if (c < nv) {
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (half_t)((float)v[i][j] * rstd * (float)wv[i][j]);
+            *(half8_t *)(h + (size_t)row * ldh + (size_t)c * 8) = o;
+        }
+    }
+}
+
+int slices_combine_norm_launch(const float *partials, int S, int M, int N, const half_t *add, int64_t ldb, half_t *y, int64_t ldy, const half_t *nw, float eps,
+                               half_t *h, int64_t ldh, hipStream_t s) {
+    const int nv = N / 8;
+    dim3 grid(M), block(256);
+    if (nv <= 256) hipLaunchKernelGGL(slices_combine_norm_kernel<1>, grid, block, 0, s, partials, S, N, add, ldb, y, ldy, nw, eps, h, ldh);
+    else if (nv <= 512) hipLaunchKernelGGL(slices_combine_norm_kernel<2>, grid, block, 0, s, partials, S, N, add, ldb, y, ldy, nw, eps, h, ldh);
+    else if (nv <= 1024) hipLaunchKernelGGL(slices_combine_norm_kernel<4>, grid, block, 0, s, partials, S, N, add, ldb, y, ldy, nw, eps, h, ldh);
+    else if (nv <= 2048) hipLaunchKernelGGL(slices_combine_norm_kernel<8>, grid, block, 0, s, partials, S, N, add, ldb, y, ldy, nw, eps, h, ldh);
+    else hipLaunchKernelGGL(slices_combine_norm_kernel<16>, grid, block, 0, s, partials, S, N, add, ldb, y, ldy, nw, eps, h, ldh);
+    return (int)hipGetLastError();
+}
+
 // --------------------------------------------------------------------------------- RoPE
 // One workgroup per (batch, position) row.  A thread owns VW adjacent rotary columns: it
 // computes their cos/sin once (fp32, accurate expf/cosf/sinf like the reference's libdevice

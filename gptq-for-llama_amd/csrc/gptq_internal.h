@@ -108,6 +108,8 @@ int silu_mul_launch(const half_t *g, int64_t ldg, const half_t *u, int64_t ldu, 
 int silu_mul_f32_launch(const float *g, int64_t ldg, const float *u, int64_t ldu, half_t *c, int64_t ldc, int M, int N, hipStream_t s);
 int gather_cols_launch(const half_t *x, int64_t ldx, const int32_t *perm, half_t *xg, int64_t ldg, int M, int K, hipStream_t s);   // xg = x[:, perm]
 int add_rows_launch(half_t *y, int64_t ldy, const half_t *r, int64_t ldr, int M, int N, hipStream_t s);   // y = fp16(y + r)
+int slices_combine_norm_launch(const float *partials, int S, int M, int N, const half_t *add, int64_t ldb, half_t *y, int64_t ldy, const half_t *nw, float eps,
+                               half_t *h, int64_t ldh, hipStream_t s);   // round 6: [S][16][N] fp32 rows -> y (+ residual / bias), h = rmsnorm(y) * nw
 int dirty_lds_launch(uint32_t pattern, hipStream_t s);   // test support: every CU's LDS overwritten
 int act_order_repack_launch(const uint32_t *qw, const int32_t *perm, int K, int N, int bits, uint32_t *out, hipStream_t s);
 int gidx_trivial_launch(const int32_t *g_idx, int K, int groupsize, int32_t *out, hipStream_t s);
@@ -129,6 +131,13 @@ struct StripeParams {
     uint32_t *progress;    // non-NULL: the decode kernel adds 1 here when it starts (debug hook gptq_set_progress_counter)
     const int32_t *yperm;  // non-NULL: column n of y is stored at yperm[n] (the consumer's sorted order: decode kernel only)
     AttnMerge att;         // att.o16 non-NULL (round 6): x is the decode attention's split records, merged while x is staged (M == 1, plain launch)
+    // round 6 (16-row tiles with K slices, <= 16 rows, one set): the combine launch also writes h[M][ldh] = rmsnorm(y) * next_norm_w and sets
+    // *next_norm_done = 1; any other route ignores these fields (the caller then runs the norm itself)
+    const half_t *next_norm_w;
+    float next_norm_eps;
+    half_t *h;
+    int64_t ldh;
+    int *next_norm_done;
 };
 int stripe_gq_shift(int K, int N, int bits, int groupsize);            // log2(groupsize / (4 KPW)), -1 one group, -2 ineligible
 size_t stripe_tab_offset(int K, int N, int bits, int nsets);

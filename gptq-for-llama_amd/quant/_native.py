@@ -141,6 +141,8 @@ _SIGNATURES = {
     'gptq_layer_decode_scratch_bytes': [c_void_p, c_int],
     'gptq_layer_decode_f16': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_size_t,
                               c_void_p, c_size_t, c_void_p],
+    'gptq_layer_decode_next_norm_f16': [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_float, c_void_p,
+                                        c_int64, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p],
 }
 
 

@@ -460,6 +460,18 @@ class DecodeEngine:
                                             self.scratch.data_ptr(), self.scratch.numel(), s)
         self.native.check(rc, 'gptq_layer_decode_f16')
 
+    def _lin_next_norm(self, w, x, y, s, lws, residual, next_norm, h):
+        """y = residual + layer(x) and, when the launch that combines this batch's K slices can do it for free, h = rmsnorm(y) * next_norm
+        (gptq_layer_decode_next_norm_f16) -- returns whether h was written (decided on the host, per shape and batch: the same in every replay)"""
+        import ctypes
+        pl = w['_keep']
+        done = ctypes.c_int(0)
+        rc = self.lib.gptq_layer_decode_next_norm_f16(pl.handle, x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), x.shape[0], None, self.eps,
+                                                      residual.data_ptr(), residual.stride(0), next_norm.data_ptr(), self.eps, h.data_ptr(), h.stride(0),
+                                                      ctypes.byref(done), lws.data_ptr(), lws.numel(), self.scratch.data_ptr(), self.scratch.numel(), s)
+        self.native.check(rc, 'gptq_layer_decode_next_norm_f16')
+        return bool(done.value)
+
     def _step_batch(self):
         lib = self.lib
         s = self.native.stream_ptr(self.dev)
@@ -467,8 +479,11 @@ class DecodeEngine:
         B, H = self.batch, self.hidden
         torch.index_select(self.embed, 0, self.ids, out=self.x)
         scale = 1.0 / float(np.sqrt(self.head_dim))
+        normed = False          # self.h holds rmsnorm(x) * ln1 of this block already (written by the previous block's down_proj: round 6)
         for li, L in enumerate(self.layers):
-            if self.fuse_norm:
+            if normed:
+                self._lin(L['qkv'], self.h, self.qkvb, s, lws)
+            elif self.fuse_norm:
                 self._lin(L['qkv'], self.x, self.qkvb, s, lws, norm=L['ln1'])                   # qkv = qkv_proj(rmsnorm(x))
             else:
                 self._norm_rows(self.x, L['ln1'], self.h, s)
@@ -485,7 +500,11 @@ class DecodeEngine:
             else:
                 self._norm_rows(self.x2, L['ln2'], self.h, s)
                 self._lin(L['gate'], self.h, self.cb, s, lws)
-            self._lin(L['down'], self.cb, self.x, s, lws, residual=self.x2)                    # x = x2 + down(c)
+            if self.fuse_norm and li + 1 < len(self.layers):                                   # x = x2 + down(c) (+ the next block's input norm)
+                normed = self._lin_next_norm(L['down'], self.cb, self.x, s, lws, self.x2, self.layers[li + 1]['ln1'], self.h)
+            else:
+                self._lin(L['down'], self.cb, self.x, s, lws, residual=self.x2)
+                normed = False
         self._lm_head(s)
         self.pos.add_(1)
 

@@ -494,6 +494,16 @@ size_t gptq_layer_decode_scratch_bytes(const gptq_layer_t *layer, int M);
 int gptq_layer_decode_f16(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, const void *norm_weight,
                           float norm_eps, const void *residual, int64_t ldr, void *workspace, size_t workspace_bytes, void *scratch,
                           size_t scratch_bytes, gptq_stream_t stream);
+/* Round 6: gptq_layer_decode_f16 that leaves the NEXT RMSNorm's rows behind when that is free.  A decode batch of 9 .. 16 rows runs a long-K
+ * layer (LLaMA's down_proj) as K slices of the 16-row tiles + a combine launch; that launch owns whole rows of y, so it also writes
+ * h[M][ldh] = rmsnorm(y) * next_norm_weight -- bit for bit what gptq_rmsnorm_f16 writes (triton_norm.py:22-39 between down_proj and the next block's
+ * qkv_proj: llama modeling's input_layernorm) -- and sets *h_written = 1: the consumer runs without its norm, one launch less per decoder block
+ * (at 16 rows the norm fused into the consumer's launch costs more than a launch: every workgroup would normalise all rows itself).  Every
+ * other route behaves exactly like gptq_layer_decode_f16, leaves h untouched and sets *h_written = 0.  1 <= M <= 16 for the fusion. */
+int gptq_layer_decode_next_norm_f16(const gptq_layer_t *layer, const void *x, int64_t ldx, void *y, int64_t ldy, int M, const void *norm_weight,
+                                    float norm_eps, const void *residual, int64_t ldr, const void *next_norm_weight, float next_norm_eps, void *h,
+                                    int64_t ldh, int *h_written, void *workspace, size_t workspace_bytes, void *scratch, size_t scratch_bytes,
+                                    gptq_stream_t stream);
 size_t gptq_decode_attn_batch_workspace_bytes(int batch, int heads, int head_dim, int t_max);
 int gptq_decode_attn_batch_f16(const void *qkv, int64_t ldq, const int64_t *positions, void *k_cache, void *v_cache, void *out, int64_t ldo,
                                void *workspace, size_t workspace_bytes, int batch, int heads, int head_dim, int t_max, float base, float scale,

@@ -83,6 +83,59 @@ def test_layer_decode_norm_and_residual(bits, K, N, gs, NS, M):
             assert rel_err(y, ref) < (2 * TOL if NS == 2 else TOL if not use_res else 1.5 * TOL), (use_norm, use_res, rel_err(y, ref))
 
 
+@pytest.mark.parametrize('M', [5, 9, 13, 16])
+@pytest.mark.parametrize('bits,K,N,gs', [(4, 11008, 4096, 128), (4, 11008, 256, 128), (4, 4096, 4096, 128), (8, 5632, 512, 64), (3, 6144, 512, 128)])
+def test_layer_decode_leaves_the_next_norm_behind(bits, K, N, gs, M):
+    """Round 6: gptq_layer_decode_next_norm_f16 -- when a batch's route combines K slices in a launch of its own (9 .. 16 rows of a long K: LLaMA's
+    down_proj), that launch also writes h = rmsnorm(y) * w for the next block's qkv_proj.  y must be the bits gptq_layer_decode_f16 writes, h the bits
+    gptq_rmsnorm_f16 writes from them; every other route reports h_written = 0, leaves h alone and still computes y."""
+    Ls = [make_random_layer(bits, gs, K, N, seed=900 + bits)]
+    pl, _keep = _prepared(Ls, gs, K, N, bits)
+    lib = _native.lib()
+    s = _native.stream_ptr(torch.device(DEV))
+    ws = _native.layer_workspace(torch.device(DEV), s)
+    rng = np.random.default_rng(K + M)
+    x = dev(rng.standard_normal((M, K)).astype(np.float16))
+    res = dev(rng.standard_normal((M, N)).astype(np.float16))
+    nw = dev((1 + 0.1 * rng.standard_normal(N)).astype(np.float16))
+    scratch = torch.empty(max(lib.gptq_layer_decode_scratch_bytes(pl.handle, M), 256), dtype=torch.uint8, device=DEV)
+    y0 = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+    rc = lib.gptq_layer_decode_f16(pl.handle, x.data_ptr(), K, y0.data_ptr(), N, M, None, 1e-6, res.data_ptr(), N, ws.data_ptr(), ws.numel(), scratch.data_ptr(),
+                                   scratch.numel(), s)
+    assert rc == 0, rc
+    h0 = torch.empty_like(y0)
+    assert lib.gptq_rmsnorm_f16(y0.data_ptr(), N, nw.data_ptr(), h0.data_ptr(), N, M, N, 1e-6, s) == 0
+    for with_res in (True, False):
+        y = torch.full((M, N + 8), float('nan'), dtype=torch.float16, device=DEV)         # (strided outputs)
+        h = torch.full((M, N + 16), 7.0, dtype=torch.float16, device=DEV)
+        done = ctypes.c_int(-1)
+        rc = lib.gptq_layer_decode_next_norm_f16(pl.handle, x.data_ptr(), K, y.data_ptr(), y.stride(0), M, None, 1e-6, res.data_ptr() if with_res else None,
+                                                 N if with_res else 0, nw.data_ptr(), 1e-6, h.data_ptr(), h.stride(0), ctypes.byref(done), ws.data_ptr(), ws.numel(),
+                                                 scratch.data_ptr(), scratch.numel(), s)
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        assert done.value in (0, 1)
+        if with_res:
+            assert torch.equal(y[:, :N], y0)
+            want_h = h0
+        else:
+            yr = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+            assert lib.gptq_layer_decode_f16(pl.handle, x.data_ptr(), K, yr.data_ptr(), N, M, None, 1e-6, None, 0, ws.data_ptr(), ws.numel(), scratch.data_ptr(),
+                                             scratch.numel(), s) == 0
+            assert torch.equal(y[:, :N], yr)
+            want_h = torch.empty_like(yr)
+            assert lib.gptq_rmsnorm_f16(yr.data_ptr(), N, nw.data_ptr(), want_h.data_ptr(), N, M, N, 1e-6, s) == 0
+        torch.cuda.synchronize()
+        if done.value == 1:
+            assert torch.equal(h[:, :N], want_h) and bool((h[:, N:] == 7.0).all())
+        else:
+            assert bool((h == 7.0).all())
+        if K >= 11008 and M > 8 and bits == 4:
+            assert done.value == 1           # LLaMA-7B's down_proj at 9 .. 16 rows: the route this entry exists for
+        if K == 4096:
+            assert done.value == 0           # one launch, no combine: nothing to hang the norm on
+
+
 @pytest.mark.parametrize('M', [1, 2, 3, 4, 5, 8, 9, 13, 16])          # 9 .. 16 (round 6): sixteen A rows of the 16x16x16 inner product, one deferred epilogue
 @pytest.mark.parametrize('bits,K,N,gs,NS', [(4, 4096, 12288, 128, 1),      # qkv of LLaMA-7B: 768 stripes = 256 workgroups x 3
                                             (4, 512, 8224, 128, 1),        # 514 stripes: the last workgroup owns ONE stripe

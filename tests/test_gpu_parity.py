@@ -465,7 +465,7 @@ def test_act_order_row_shards_fp32_partials_one_rounding(bits, world, M):
     sc, qz = dev(L['scales']), dev(L['qzeros'])
     G = L['scales'].shape[0]
     Ks = K // world
-    parts, parts16, exact = [], [], np.zeros((M, N))
+    parts, parts16, exact, noise = [], [], np.zeros((M, N)), np.zeros((M, N))
     for r in range(world):
         k0, k1 = r * Ks, (r + 1) * Ks
         qw = dev(L['qweight'][k0 * bits // 32:k1 * bits // 32])
@@ -482,6 +482,7 @@ def test_act_order_row_shards_fp32_partials_one_rounding(bits, world, M):
         assert (np.abs(got - e) <= mag * 2.0**-20).all(), np.abs(got - e).max()            # (a)
         parts.append(y32)
         exact += e
+        noise += mag * 2.0**-20
         # round 5's launch: the generic kernel with an fp16 output (told a group size that makes its table hold every group of the layer)
         y16 = torch.empty((M, N), dtype=torch.float16, device=DEV)
         rc = lib.gptq_matmul248_f16(xs.data_ptr(), xs.stride(0), qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), gi.data_ptr(), None, y16.data_ptr(), N, M, Ks, N, bits,
@@ -498,10 +499,11 @@ def test_act_order_row_shards_fp32_partials_one_rounding(bits, world, M):
     best = exact.astype(np.float16)             # the correctly rounded result
     ulp = np.spacing(np.abs(best).astype(np.float16)).astype(np.float64)
     err, err_old = np.abs(y.astype(np.float64) - exact), np.abs(y_old.astype(np.float64) - exact)
-    assert (err <= 0.5 * ulp + np.abs(exact) * 2.0**-18 + 1e-7).all()                          # (b): one rounding
-    assert (y == best).mean() > 0.995
+    noise += np.abs(exact) * 2.0**-21                    # (+ the fp32 additions of the exchange)
+    assert (err <= 0.5 * ulp + noise).all()                                                    # (b): one rounding
+    assert (y == best).mean() > 0.99
     if world > 2:
-        assert err_old.max() > err.max() and (err_old > 0.5 * ulp + np.abs(exact) * 2.0**-18 + 1e-7).any()      # (c): one rounding per rank shows
+        assert err_old.max() > err.max() and (err_old > 0.5 * ulp + noise).any()      # (c): one rounding per rank shows
     # error paths: a missing g_idx / table, a K that is no multiple of 32
     assert lib.gptq_matmul248_partial_f32(dev(x).data_ptr(), K, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, total.data_ptr(), N, M, Ks, N, bits, G, s) < 0
     assert lib.gptq_matmul248_partial_f32(dev(x).data_ptr(), K, qw.data_ptr(), sc.data_ptr(), qz.data_ptr(), gi.data_ptr(), total.data_ptr(), N, M, Ks - 8, N, bits, G, s) < 0

@@ -683,10 +683,9 @@ namespace {
 // tile GEMM loses on a partial round of tiles (0.6-0.7x the library at 1025 rows) is only paid by layers WITHOUT a stripe16 image
 // (2-bit batches above 128 rows, groups smaller than a row block, irregular act-order, GPTQ_STRIPE=0): everything else runs the fused
 // tile GEMM on the image up to gptq_set_stripe_gemm_max_rows().
-bool gemm8_wanted(int M, int N, bool pair) {
-    (void)M; (void)N; (void)pair;
-    return g_prefill_route.load() != 0;
-}
+// (round 6: no per-shape decision lives here any more -- the tile choice is gemm8.hip's, image against dense is image_gemm_wanted's: this is the
+// route switch alone, gptq_set_prefill_route(0) = library only)
+bool own_dense_route() { return g_prefill_route.load() != 0; }
 constexpr size_t PREFILL_LIB_WS = (size_t)76 << 20;      // what the library may use for itself (split / stream-K algorithms)
 constexpr int PREFILL_CHUNK_M = 8192;                    // rows of the transient FP32 [rows, 2N] gate | up product
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -715,7 +714,7 @@ int gptq_prefill_matmul_f16(const void *x, int64_t ldx, const int32_t *qweight, 
     if (!workspace || (uintptr_t)workspace % 256 != 0 || workspace_bytes < gptq_prefill_workspace_bytes(M, K, N, 1)) return GPTQ_E_WORKSPACE;
     half_t *W = (half_t *)workspace;
     char *lib_ws = (char *)workspace + align256((size_t)K * N * 2);
-    if (gemm8_wanted(M, N, false) && K % 128 == 0 && (!bias || (uintptr_t)bias % 8 == 0)) {
+    if (own_dense_route() && K % 128 == 0 && (!bias || (uintptr_t)bias % 8 == 0)) {
         // own route: Wt[N][K] (k contiguous) + the LDS-DMA / MFMA tile GEMM; no library, no transient beyond the weight itself
         if (int rc = dequant_t_launch((const uint32_t *)qweight, (const half_t *)scales, qzeros, g_idx, K, N, n_groups(K, groupsize), groupsize, bits, W,
                                       K, (hipStream_t)stream))
@@ -745,7 +744,7 @@ int gptq_prefill_transpose_matmul248_f16(const void *dy, int64_t lddy, const int
         return rc;
     // dx[M, K] = dy[M, N] . W[K, N]^T: the "K" of this product is N, its "N" is K, W is stored [out, in] -- which IS the k-contiguous
     // operand layout of gemm8 (reference transpose_matmul_248_kernel, quant_linear.py:191-258): same tile engine, roles exchanged
-    if (gemm8_wanted(M, K, false) && N % 128 == 0) {
+    if (own_dense_route() && N % 128 == 0) {
         const int rc = gemm8_dense_f16((const half_t *)dy, lddy, W, N, nullptr, (half_t *)dx, lddx, M, N, K, false, (hipStream_t)stream);
         if (rc != GPTQ_E_VARIANT) return rc;
     }
@@ -767,7 +766,7 @@ int gptq_prefill_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweigh
     float *prod = (float *)(lib_ws + PREFILL_LIB_WS);                                      // [rows, 2N] fp32: the reference applies SiLU to the
                                                                                            // fp32 accumulators (fused_mlp.py:160-165), not to rounded products
     const int G = n_groups(K, groupsize);
-    if (gemm8_wanted(M, N, true) && K % 128 == 0) {
+    if (own_dense_route() && K % 128 == 0) {
         // own route: gate and up stacked as Wt[2N][K]; ONE launch computes both products per tile and applies SiLU to the fp32
         // accumulators in its epilogue (fused_mlp.py:160-165) -- no [M, 2N] intermediate at all
         half_t *Wt = (half_t *)workspace;
@@ -797,8 +796,8 @@ int gptq_prefill_fused_mlp_f16(const void *x, int64_t ldx, const int32_t *qweigh
  * (pure host logic; nsets = 2: the gate/up pair, trans = 1: the backward product dx[M, K] = dy[M, N] . W^T) */
 int gptq_prefill_route_for(int M, int K, int N, int nsets, int trans) {
     if (M <= 0 || K <= 0 || N <= 0 || nsets < 1 || nsets > 2) return GPTQ_E_SHAPE;
-    if (trans) return (gemm8_wanted(M, K, false) && N % 128 == 0) ? 1 : 0;
-    return (gemm8_wanted(M, N, nsets == 2) && K % 128 == 0) ? 1 : 0;
+    if (trans) return (own_dense_route() && N % 128 == 0) ? 1 : 0;
+    return (own_dense_route() && K % 128 == 0) ? 1 : 0;
 }
 int gptq_set_library_enabled(int on) { return dense_gemm_set_enabled(on); }
 int gptq_set_gemm8_mfma(int shape) { return gemm8_set_mfma(shape); }
@@ -1409,7 +1408,7 @@ static int decode_rows_mf16(int K, int N, int nsets, int bits, int groupsize) {
 // Act-order layers keep the image route (their dense route rebuilds the checkpoint order first; not measured).
 static bool image_gemm_wanted(int M, int K, int N, int nsets, int kind) {
     if (M > g_stripe_gemm_max_rows.load()) return false;
-    if (kind != 0 || K % 128 != 0 || !gemm8_wanted(M, N, nsets == 2)) return true;   // the alternative would not be the tile GEMM
+    if (kind != 0 || K % 128 != 0 || !own_dense_route()) return true;   // the alternative would not be the tile GEMM
     const long tiles = (long)((M + 127) / 128) * (((long)N * nsets + 127) / 128);
     return tiles <= 512 || M <= (nsets == 2 ? 1152 : 640);
 }
@@ -1419,7 +1418,7 @@ size_t gptq_layer_workspace_bytes(void) { return WS_BYTES + STRIPE_MM_WS_BYTES; 
 
 // a released layer whose dense route needs no checkpoint layout: trivial g_idx, an image, a product the tile GEMM of gemm8.hip takes
 static bool layer_dense_from_image(const gptq_layer &L, int M) {
-    return L.released && L.kind == 0 && L.stripe && L.K % 128 == 0 && gemm8_wanted(M, L.N, L.nsets == 2) && (L.nsets == 2 || !L.bias || aligned(L.bias, 8));
+    return L.released && L.kind == 0 && L.stripe && L.K % 128 == 0 && own_dense_route() && (L.nsets == 2 || !L.bias || aligned(L.bias, 8));
 }
 
 /* transient scratch that gives forward(M) its fast route: the gathered x of an act-order batch, the per-call dequantised weight */
@@ -1467,7 +1466,7 @@ int gptq_layer_route_for_shape(int M, int K, int N, int bits, int groupsize, int
         if (image_gemm_wanted(M, K, N, nsets, kind) && bits != 2 && (gq == -1 || gq >= 2)) return GPTQ_ROUTE_STRIPE_GEMM;       // groups of at least a row block
     }
     if (M >= LAYER_PREFILL_MIN_M)
-        return (gemm8_wanted(M, N, nsets == 2) && K % 128 == 0) ? GPTQ_ROUTE_DENSE_TILE_GEMM : GPTQ_ROUTE_DENSE_LIBRARY;
+        return (own_dense_route() && K % 128 == 0) ? GPTQ_ROUTE_DENSE_TILE_GEMM : GPTQ_ROUTE_DENSE_LIBRARY;
     return GPTQ_ROUTE_CHECKPOINT_KERNELS;
 }
 

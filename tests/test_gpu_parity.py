@@ -1653,11 +1653,13 @@ def test_config4_full_size_batch1(K, N, variant):
     assert np.array_equal(y.view(np.uint16), y2.view(np.uint16))       # no atomics on these routes: bit-reproducible
 
 
-def test_prefill_config3_65536_rows_vs_oracle_on_sampled_rows():
-    """BASELINE config 3 as benchmarked: batch 32 x seq 2048 = 65 536 rows, 4096 x 4096, 4-bit g128, through the product's call site
-    (gptq_layer_forward -> the prefill tile GEMM); 100+ rows spread over every 1024-row band + the tile edges against the CPU oracle."""
-    M, K, N = 65536, 4096, 4096
-    L = make_random_layer(4, 128, K, N, seed=65536)
+@pytest.mark.parametrize('K,N', [(4096, 4096), (4096, 11008), (11008, 4096)])
+def test_prefill_config3_65536_rows_vs_oracle_on_sampled_rows(K, N):
+    """BASELINE config 3 as benchmarked: batch 32 x seq 2048 = 65 536 rows, 4-bit g128, through the product's call site
+    (gptq_layer_forward -> the prefill tile GEMM); 100+ rows spread over every 1024-row band + the tile edges against the CPU oracle.
+    Round 6: the MLP shapes of LLaMA-7B next to 4096 x 4096 (a ragged last column tile at N = 11008, the long K of down_proj)."""
+    M = 65536
+    L = make_random_layer(4, 128, K, N, seed=65536 + N)
     g = torch.Generator(device=DEV)
     g.manual_seed(65536)
     x = torch.randn((M, K), device=DEV, generator=g, dtype=torch.float16)

@@ -101,8 +101,14 @@ def test_tiny_llama_batched_decode_matches_dense_twin(batch):
     assert np.isfinite(a).all() and a.shape == c.shape == (4, batch, TINY['vocab_size'])
     # the maximum runs over batch x vocab x steps logits of a random two-layer model: at batch 100 the fp16 twin itself sits 0.9-2.4e-2
     # from its own fp32 copy (measured), so the bound there is the model's fp16 noise, not a kernel tolerance (per-op parity at
-    # these M: test_stripe_mm_vs_oracle / test_stripe_mm_fused_mlp, 1e-3 / 2e-3 against the oracle)
-    within('twin_batched_%d' % batch, np.abs(a - c).max() / scale, TWIN_TOL if batch <= 40 else TWIN_TOL_100)
+    # these M: test_stripe_mm_vs_oracle / test_stripe_mm_fused_mlp, 1e-3 / 2e-3 against the oracle).  Round 6: measured instead of assumed -- this
+    # seed's batch of 8 is such a case (the fp16 twin 2.65e-2 from its fp32 copy; the drop-in model 0.5e-2 / 1.4e-2 from the fp16 twin with the 4x4x4 /
+    # 16x16x16 inner product, tools/debug/twin_noise.py, profiles/r6l_twin_noise): the bar is the larger of the fixed one and the twin's own distance
+    # from its fp32 copy on the same tokens.
+    exact = run_steps(ref.float(), ids, 5)
+    noise = np.abs(c - exact).max() / scale
+    ref.half()
+    within('twin_batched_%d' % batch, np.abs(a - c).max() / scale, max(TWIN_TOL if batch <= 40 else TWIN_TOL_100, noise))
 
 
 def test_benchmark_decode_protocol_runs():

@@ -960,14 +960,24 @@ def test_stripe_small_batch_rows(K, N, gs, M, bias):
 @pytest.mark.parametrize('M', [5, 8, 9, 13, 16])
 @pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 4096, 128), (4, 4096, 11008, 128), (4, 2176, 96, 64), (8, 2048, 288, 128), (2, 4096, 64, 128), (3, 4096, 96, -1)])
 def test_stripe_row_groups_m5_to_16(bits, K, N, gs, M):
-    """5 <= M <= 16: two / four MFMA row groups on the same unpacked words, M rows of x in LDS; every row against the oracle
-    and bit-identical to the M = 1 launch of that row"""
+    """5 <= M <= 16 in the decode launch: every row against the oracle.  Rounds 2-5 ran two / four 4x4x4 row groups on the same unpacked words, whose
+    rows were bit-identical to the M = 1 launch; since round 6 these batches go through v_mfma_f32_16x16x16_f16 wherever the group spans a row
+    block (the matrix core sums the four k quads of a row block, the x sums are per row block): another summation order than the one-row
+    launch, so a row equals its M = 1 result to the op-level bar, not bit for bit -- what still holds bit for bit is that a row's result does not
+    depend on WHERE it sits in the batch, nor on the other rows."""
     L = make_random_layer(bits, gs, K, N, seed=K + N + M)
     x = np.random.default_rng(M).standard_normal((M, K)).astype(np.float16)
     y, ref = check_forward(x, L, family='stripe')
     for m in (0, M // 2, M - 1):
         y1 = hip_forward(x[m:m + 1], L, family='stripe')
-        assert np.array_equal(y1.view(np.uint16), y[m:m + 1].view(np.uint16))
+        assert rel_err(y1, y[m:m + 1]) < TOL
+    perm = np.random.default_rng(2).permutation(M)
+    yp = hip_forward(np.ascontiguousarray(x[perm]), L, family='stripe')
+    assert np.array_equal(yp.view(np.uint16), y[perm].view(np.uint16))
+    x2 = x.copy()
+    x2[1:] = np.random.default_rng(3).standard_normal((M - 1, K)).astype(np.float16)      # other neighbours, the same row 0
+    y2 = hip_forward(x2, L, family='stripe')
+    assert np.array_equal(y2[:1].view(np.uint16), y[:1].view(np.uint16))
 
 
 @pytest.mark.parametrize('M', [5, 16, 17, 33, 48, 64, 65, 100, 128])
@@ -1036,8 +1046,12 @@ def test_stripe_gemm_fused_mlp_and_bias(bits, K, N, gs, M):
     ref = oracle.fused_mlp(x, sets[0], sets[1], bits)
     assert rel_err(c, ref) < TOL
     assert_not_worse_than_reference(c, ref, oracle.fused_mlp_exact(x, sets[0], sets[1], bits))
-    c2 = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs).cpu().numpy()     # the default dispatch takes the same kernel
-    assert np.array_equal(c.view(np.uint16), c2.view(np.uint16))
+    c2 = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs).cpu().numpy()     # the default dispatch takes the same kernel ...
+    if M > 16:
+        assert np.array_equal(c.view(np.uint16), c2.view(np.uint16))
+    else:       # ... except for 9 .. 16 rows of a pair (round 6): the decode launch with sixteen A rows where it serves the shape -- the same bars
+        assert rel_err(c2, ref) < TOL
+        assert_not_worse_than_reference(c2, ref, oracle.fused_mlp_exact(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits))
     bias = (np.random.default_rng(3).standard_normal(N) * 0.1).astype(np.float16)
     yb, _ = check_forward(x, A, bias=bias)
     yf, _ = check_forward(x, A, bias=bias, family='stripe_mm')
@@ -1087,8 +1101,12 @@ def test_stripe_mm_fused_mlp(bits, K, N, gs, M):
     ref = oracle.fused_mlp(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits)
     assert rel_err(c, ref) < TOL
     assert_not_worse_than_reference(c, ref, oracle.fused_mlp_exact(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits))
-    c2 = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs).cpu().numpy()     # the default dispatch takes the same kernel
-    assert np.array_equal(c.view(np.uint16), c2.view(np.uint16))
+    c2 = quant.fused_mlp.fused_gate_up(dev(x), gate, up, bits, gs).cpu().numpy()     # the default dispatch takes the same kernel ...
+    if M > 16:
+        assert np.array_equal(c.view(np.uint16), c2.view(np.uint16))
+    else:       # ... except for 9 .. 16 rows of a pair (round 6): the decode launch with sixteen A rows where it serves the shape -- the same bars
+        assert rel_err(c2, ref) < TOL
+        assert_not_worse_than_reference(c2, ref, oracle.fused_mlp_exact(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits))
 
 
 def test_stripe_long_k_small_batch():

@@ -99,6 +99,29 @@ def test_soak_decode_linears(name, K, N, NS, norm, res, M):
     soak(launch, (M, N), dirt)
 
 
+@pytest.mark.parametrize('M', [9, 16])
+def test_soak_down_proj_with_the_next_norm(M):
+    """round 6: down_proj at 9 .. 16 rows -- K slices + the combine launch that also writes the next block's RMSNorm rows
+    (gptq_layer_decode_next_norm_f16): y AND h bit-identical over the soak, the partial rows in the workspace tail scribbled between the launches"""
+    import ctypes
+    bits, gs, K, N = 4, 128, 11008, 4096
+    L = make_random_layer(bits, gs, K, N, seed=77)
+    pl = prepared(((dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx'])),), None, bits, gs, K, N)
+    lib = _native.lib()
+    rng = np.random.default_rng(M)
+    x = dev(rng.standard_normal((M, K)).astype(np.float16))
+    r = dev(rng.standard_normal((M, N)).astype(np.float16))
+    nw = dev((1 + 0.1 * rng.standard_normal(N)).astype(np.float16))
+    dirt = Dirt(lib.gptq_layer_decode_scratch_bytes(pl.handle, M))
+    done = ctypes.c_int(0)
+
+    def launch(yh):          # yh[0] = y, yh[1] = h
+        rc = lib.gptq_layer_decode_next_norm_f16(pl.handle, x.data_ptr(), K, yh[0].data_ptr(), N, M, None, 1e-6, r.data_ptr(), N, nw.data_ptr(), 1e-6, yh[1].data_ptr(), N,
+                                                 ctypes.byref(done), dirt.lws.data_ptr(), dirt.lws.numel(), dirt.scratch.data_ptr(), dirt.scratch.numel(), dirt.s)
+        assert rc == 0 and done.value == 1, (rc, done.value)
+    soak(launch, (2, M, N), dirt, launches=max(LAUNCHES // 4, RING))
+
+
 @pytest.mark.parametrize('B,pos', [(1, 0), (1, 100), (1, 700), (1, 2040), (4, 900), (16, 300)])
 def test_soak_attention(B, pos):
     """the attention launch of the engine: self-merging (tickets must return to zero: checked after every block) and, at batch 1, the split records

@@ -134,6 +134,26 @@ def test_layer_decode_leaves_the_next_norm_behind(bits, K, N, gs, M):
             assert done.value == 1           # LLaMA-7B's down_proj at 9 .. 16 rows: the route this entry exists for
         if K == 4096:
             assert done.value == 0           # one launch, no combine: nothing to hang the norm on
+    # a BIASED layer without a residual: the bias takes the add slot of the combine launch (ldb = 0) -- the same bits as the two launches
+    bias = rng.standard_normal(N).astype(np.float16)
+    plb, _keepb = _prepared(Ls, gs, K, N, bits, bias=bias)
+    yb0 = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV)
+    assert lib.gptq_layer_decode_f16(plb.handle, x.data_ptr(), K, yb0.data_ptr(), N, M, None, 1e-6, None, 0, ws.data_ptr(), ws.numel(), scratch.data_ptr(), scratch.numel(), s) == 0
+    hb0 = torch.empty_like(yb0)
+    assert lib.gptq_rmsnorm_f16(yb0.data_ptr(), N, nw.data_ptr(), hb0.data_ptr(), N, M, N, 1e-6, s) == 0
+    yb, hb = torch.full((M, N), float('nan'), dtype=torch.float16, device=DEV), torch.full((M, N), 7.0, dtype=torch.float16, device=DEV)
+    done = ctypes.c_int(-1)
+    rc = lib.gptq_layer_decode_next_norm_f16(plb.handle, x.data_ptr(), K, yb.data_ptr(), N, M, None, 1e-6, None, 0, nw.data_ptr(), 1e-6, hb.data_ptr(), N, ctypes.byref(done),
+                                             ws.data_ptr(), ws.numel(), scratch.data_ptr(), scratch.numel(), s)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert torch.equal(yb, yb0) and (torch.equal(hb, hb0) if done.value == 1 else bool((hb == 7.0).all()))
+    # h_written is mandatory, a missing next-norm weight / h degrades to gptq_layer_decode_f16
+    assert lib.gptq_layer_decode_next_norm_f16(plb.handle, x.data_ptr(), K, yb.data_ptr(), N, M, None, 1e-6, None, 0, nw.data_ptr(), 1e-6, hb.data_ptr(), N, None,
+                                               ws.data_ptr(), ws.numel(), scratch.data_ptr(), scratch.numel(), s) < 0
+    done = ctypes.c_int(-1)
+    assert lib.gptq_layer_decode_next_norm_f16(plb.handle, x.data_ptr(), K, yb.data_ptr(), N, M, None, 1e-6, None, 0, None, 1e-6, None, 0, ctypes.byref(done),
+                                               ws.data_ptr(), ws.numel(), scratch.data_ptr(), scratch.numel(), s) == 0 and done.value == 0
 
 
 @pytest.mark.parametrize('M', [1, 2, 3, 4, 5, 8, 9, 13, 16])          # 9 .. 16 (round 6): sixteen A rows of the 16x16x16 inner product, one deferred epilogue

@@ -1003,6 +1003,36 @@ def test_stripe_mm_vs_oracle(bits, K, N, gs, M):
         assert rel_err(yp, y[perm]) < TOL
 
 
+@pytest.mark.parametrize('M', [17, 40, 64, 77, 80, 96, 112, 113, 128])
+@pytest.mark.parametrize('K,N,gs', [(4096, 11008, 128), (1024, 6176, 128), (2048, 8192, 256), (1152, 12288, -1)])
+def test_stripe_mm_loader_consumer_route(K, N, gs, M):
+    """17 .. 128 rows on shapes whose stripes need two or three rounds of workgroups and K <= 8192 -- the home ground of the loader / consumer kernel
+    (csrc/stripe_mm.inc stripe_mmr_kernel, round 6: x through an LDS ring of (row block, 64-row pass) chunks, two passes per row block from 65 rows on):
+    a ragged stripe count (688 = 229 x 3 + 1: the last workgroup's clamped stripes), ragged batches (rows >= M are clamped loads and
+    skipped stores), groups of two row blocks and one group, a row-block count that is not a multiple of the six consumer waves / two loader waves, a
+    bias, and x as a strided view; against the oracle, bit-reproducible, every row bit-independent of its position (ONE launch, one schedule)"""
+    L = make_random_layer(4, gs, K, N, seed=K + N + M)
+    rng = np.random.default_rng(M)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    y, ref = check_forward(x, L, family='stripe_mm')
+    assert np.array_equal(hip_forward(x, L, family='stripe_mm').view(np.uint16), y.view(np.uint16))
+    perm = rng.permutation(M)
+    yp = hip_forward(np.ascontiguousarray(x[perm]), L, family='stripe_mm')
+    assert np.array_equal(yp.view(np.uint16), y[perm].view(np.uint16))
+    ya = hip_forward(x, L)                                                   # the layer ABI's own dispatch: the same launch
+    assert np.array_equal(ya.view(np.uint16), y.view(np.uint16))
+    assert _native.lib().gptq_layer_route_for_shape(M, K, N, 4, K if gs == -1 else gs, 1, 0, 1) == 2         # GPTQ_ROUTE_STRIPE_TILES
+    bias = rng.standard_normal(N).astype(np.float16)
+    xs = np.zeros((M, K + 72), dtype=np.float16)
+    xs[:, :K] = x
+    xs[:, K:] = np.float16(np.nan)          # (nothing beyond a row's K columns may be read into a sum)
+    args = (dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx']), 4, 15)
+    yb = QL.matmul248(dev(xs)[:, :K], *args, bias=dev(bias)).cpu().numpy()
+    assert rel_err(yb, exact_forward(x, L, bias)) < TOL
+    yb2 = QL.matmul248(dev(x), *args, bias=dev(bias)).cpu().numpy()
+    assert np.array_equal(yb.view(np.uint16), yb2.view(np.uint16))
+
+
 @pytest.mark.parametrize('M', [129, 200, 256, 384, 1000])
 @pytest.mark.parametrize('bits,K,N,gs', [(4, 4096, 4096, 128), (4, 4096, 11008, 128), (4, 11008, 4096, 128), (4, 1152, 288, 128), (4, 2048, 96, -1),
                                          (4, 3072, 64, 256), (8, 2048, 288, 64), (8, 1088, 96, -1), (3, 4096, 512, -1), (3, 1152, 160, 128)])

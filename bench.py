@@ -498,6 +498,24 @@ def small_batch_leg(dev):
             row['M%d' % M] = {'us': round(us, 2), 'TFLOPs': round(2.0 * M * K * N / us / 1e6, 1), 'GBps': round(alg_bytes(M, K, N) / us / 1e3, 1)}
         out['shapes']['%dx%d' % (K, N)] = row
         del sets
+    # the gate | up pair of the fused MLP (fused_mlp.py:84-168: one launch, SiLU(gate) * up on the fp32 sums): 5 .. 16 rows in the decode launch / one row
+    # tile, 17 .. 128 the loader / consumer kernel with the consumers split by set (csrc/stripe_mm.inc stripe_mmr_kernel, round 6)
+    from quant import fused_mlp as FM
+    K, N = HIDDEN, INTER
+    npairs = int(300e6 // alg_bytes(1, K, N, nsets=2)) + 1
+    pairs = [(PackedSet(K, N, dev, gen), PackedSet(K, N, dev, gen)) for _ in range(npairs)]
+    gi = (torch.arange(K, device=dev) // GS).to(torch.int32)
+    row = {}
+    for M in (1, 4, 8, 16, 32, 64, 128):
+        x = torch.randn((M, K), device=dev, generator=gen).half()
+
+        def run_pair(i):
+            a, b = pairs[i]
+            FM.fused_gate_up(x, (a.qweight, a.scales, a.qzeros, gi), (b.qweight, b.scales, b.qzeros, gi), BITS, GS)
+        us = _time_cold(run_pair, npairs, reps=3)
+        row['M%d' % M] = {'us': round(us, 2), 'TFLOPs': round(4.0 * M * K * N / us / 1e6, 1), 'GBps': round(alg_bytes(M, K, N, nsets=2) / us / 1e3, 1)}
+    out['shapes']['gate_up_silu_2x%dx%d' % (K, N)] = row
+    del pairs
     return out
 
 

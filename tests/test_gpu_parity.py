@@ -1139,6 +1139,36 @@ def test_stripe_mm_fused_mlp(bits, K, N, gs, M):
         assert_not_worse_than_reference(c2, ref, oracle.fused_mlp_exact(x, (A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']), bits))
 
 
+@pytest.mark.parametrize('M', [17, 48, 64, 77, 96, 112, 113, 128])
+@pytest.mark.parametrize('K,N,gs', [(4096, 11008, 128), (1024, 6176, 128), (1152, 8192, -1)])
+def test_stripe_mm_loader_consumer_pair(K, N, gs, M):
+    """the gate | up pair at 17 .. 128 rows on shapes with two or three rounds of column stripes: the loader / consumer kernel with the consumers
+    split by SET (csrc/stripe_mm.inc stripe_mmr_kernel<.., NS = 2, SS = 1>, round 6) -- three k lanes per set, a chunk of x released when the
+    consumers of both sets are done with it, SiLU(gate) * up on the fp32 sums; 113 .. 128 rows of three-stripe shapes run two stripes per
+    workgroup (the eight-tile instance of three spills).  Against the oracle and the float64 result, bit-reproducible, rows bit-independent
+    of their position, x as a strided view with NaN padding, the default dispatch takes the same launch"""
+    A, B = make_random_layer(4, gs, K, N, seed=K + M), make_random_layer(4, gs, K, N, seed=K + M + 1)
+    rng = np.random.default_rng(M)
+    gsz = K if gs == -1 else gs
+    x = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+    gate = tuple(dev(A[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    up = tuple(dev(B[k]) for k in ('qweight', 'scales', 'qzeros', 'g_idx'))
+    sets = ((A['qweight'], A['scales'], A['qzeros'], A['g_idx']), (B['qweight'], B['scales'], B['qzeros'], B['g_idx']))
+    c = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, gsz, family='stripe_mm').cpu().numpy()
+    ref = oracle.fused_mlp(x, sets[0], sets[1], 4)
+    assert rel_err(c, ref) < TOL
+    assert_not_worse_than_reference(c, ref, oracle.fused_mlp_exact(x, sets[0], sets[1], 4))
+    c2 = quant.fused_mlp.fused_gate_up(dev(x), gate, up, 4, gsz).cpu().numpy()
+    assert np.array_equal(c.view(np.uint16), c2.view(np.uint16))
+    perm = rng.permutation(M)
+    cp = quant.fused_mlp.fused_gate_up(dev(np.ascontiguousarray(x[perm])), gate, up, 4, gsz, family='stripe_mm').cpu().numpy()
+    assert np.array_equal(cp.view(np.uint16), c[perm].view(np.uint16))
+    xs = np.full((M, K + 72), np.nan, dtype=np.float16)
+    xs[:, :K] = x
+    cs = quant.fused_mlp.fused_gate_up(dev(xs)[:, :K], gate, up, 4, gsz).cpu().numpy()
+    assert np.array_equal(cs.view(np.uint16), c.view(np.uint16))
+
+
 def test_stripe_long_k_small_batch():
     """M rows of x must fit in LDS.  Round 5: 5 .. 8 rows on K = 11008 (LLaMA-7B down_proj) run in the decode kernel with x staged in two K
     halves (stripe_gemv2p_kernel) -- with a bias and with a per-row residual; 16 rows on that K, or 8 rows on K = 22016, are still refused by

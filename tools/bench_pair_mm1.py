@@ -10,7 +10,7 @@ from quant import _native, quant_linear as QL
 dev = 'cuda:0'; lib = _native.lib()
 gen = torch.Generator(device=dev); gen.manual_seed(0)
 mws = _native.mm_workspace(torch.device(dev))
-for K, N in [(4096, 11008), (4096, 4096)]:
+for K, N in ([(4096, 11008)] if os.environ.get('MS') else [(4096, 11008), (4096, 4096)]):
     nsets = int(300e6 // alg_bytes(1, K, N, nsets=2)) + 1
     imgs = []
     for _ in range(nsets):
@@ -18,7 +18,7 @@ for K, N in [(4096, 11008), (4096, 4096)]:
         imgs.append(QL.stripe_copy(a.qweight, a.scales, a.qzeros, BITS, GS, up=(b.qweight, b.scales, b.qzeros)))
         torch.cuda.synchronize()
         del a, b
-    for M in (9, 16):
+    for M in [int(v) for v in os.environ.get('MS', '9,16').split(',')]:
         x = torch.randn((M, K), device=dev, generator=gen).half(); y = torch.empty((M, N), dtype=torch.float16, device=dev)
 
         def run(i):
@@ -39,6 +39,6 @@ for K, N in [(4096, 11008), (4096, 4096)]:
             for _ in range(5): g.replay()
             e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) * 1e3 / (5 * nsets))
-        print('PF=%s gate/up 2x%dx%d M=%-2d: %.2f us' % (os.environ.get('GPTQ_MM1_PAIR_PF', 'default(4)'), K, N, M, best), flush=True)
+        print('MMR_PAIR=%s PF=%s gate/up 2x%dx%d M=%-2d: %.2f us' % (os.environ.get('GPTQ_MMR_PAIR', 'default(1)'), os.environ.get('GPTQ_MM1_PAIR_PF', 'default(4)'), K, N, M, best), flush=True)
     del imgs
     torch.cuda.empty_cache()

@@ -198,6 +198,110 @@ def test_default_load_path_with_warmups_then_generate(tmp_path, capsys):
     assert int(greedy.max()) < TINY['vocab_size']
 
 
+# llama_inference.py:75-128 restated (the tree is absent on the GPU box): the script's own argument names, its load / to(DEV) / tokenizer / generate /
+# decode / print sequence -- run as a PROCESS below.  `load_quant` = this file's restatement of :27-72 (or the reference's own function where the tree is).
+MAIN_FLOW = r"""
+import argparse, os, sys
+import torch
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {pkg!r}); sys.path.insert(0, {root!r})
+import test_reference_callers as T
+from transformers import AutoTokenizer
+DEV = torch.device('cuda:0')                                            # utils/modelutils.py:4
+parser = argparse.ArgumentParser()                                      # llama_inference.py:78-103
+parser.add_argument('model', type=str)
+parser.add_argument('--wbits', type=int, default=16, choices=[2, 3, 4, 8, 16])
+parser.add_argument('--groupsize', type=int, default=-1)
+parser.add_argument('--load', type=str, default='')
+parser.add_argument('--text', type=str)
+parser.add_argument('--min_length', type=int, default=10)
+parser.add_argument('--max_length', type=int, default=50)
+parser.add_argument('--top_p', type=float, default=0.95)
+parser.add_argument('--temperature', type=float, default=0.8)
+parser.add_argument('--device', type=int, default=-1)
+parser.add_argument('--fused_mlp', action='store_true')
+parser.add_argument('--no_fused_mlp', dest='fused_mlp', action='store_false')
+parser.set_defaults(fused_mlp=True)
+args = parser.parse_args()
+load_quant = T._import_reference('llama_inference').load_quant if os.path.isdir(T.REF) else T.load_quant_flow
+model = load_quant(args.model, args.load, args.wbits, args.groupsize, fused_mlp=args.fused_mlp)     # :110-111
+model.to(DEV)                                                           # :116
+tokenizer = AutoTokenizer.from_pretrained(args.model, use_fast=False)   # :117
+input_ids = tokenizer.encode(args.text, return_tensors="pt").to(DEV)    # :118
+torch.manual_seed(int(os.environ.get('SEED', '0')))
+with torch.no_grad():                                                   # :120-128
+    generated_ids = model.generate(input_ids, do_sample=True, min_length=args.min_length, max_length=args.max_length, top_p=args.top_p,
+                                   temperature=args.temperature)
+print('IDS', [el.item() for el in generated_ids[0]])
+print('TEXT', repr(tokenizer.decode([el.item() for el in generated_ids[0]])))
+import quant
+from quant import engine_hook
+print('NATIVE', quant._native.lib() is not None)
+print('ENGINE_STEPS', engine_hook.engine_steps(model))
+"""
+
+
+def _tiny_tokenizer(config_dir):
+    """a BPE tokenizer of TINY['vocab_size'] entries at most, saved next to the config (AutoTokenizer.from_pretrained(args.model), llama_inference.py:117)"""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    from transformers import PreTrainedTokenizerFast
+    tok = Tokenizer(models.BPE(unk_token='<unk>'))
+    tok.pre_tokenizer = pre_tokenizers.Metaspace()
+    tok.decoder = decoders.Metaspace()
+    corpus = ['this is a llama . the quick brown fox jumps over the lazy dog', 'hello world again and again', 'a b c d e f g h i j k l m n o p q r s t u v w x y z'] * 20
+    tok.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=TINY['vocab_size'], special_tokens=['<unk>', '<s>', '</s>']))
+    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token='<unk>', bos_token='<s>', eos_token='</s>').save_pretrained(config_dir)
+
+
+def test_tiny_tokenizer_round_trip(tmp_path):
+    """(CPU) the tokenizer leg of the process test below: AutoTokenizer on the model directory, encode / decode"""
+    from transformers import AutoTokenizer
+    cfg_dir = _tiny_config_dir(tmp_path)
+    _tiny_tokenizer(cfg_dir)
+    tok = AutoTokenizer.from_pretrained(cfg_dir, use_fast=False)
+    ids = tok.encode('this is a llama', return_tensors='pt')
+    assert ids.shape[0] == 1 and ids.shape[1] >= 2 and int(ids.max()) < TINY['vocab_size']
+    assert tok.decode([el.item() for el in ids[0]]).strip() == 'this is a llama'
+
+
+@pytest.mark.gpu
+def test_inference_main_as_a_process(tmp_path):
+    """llama_inference.py's `__main__` (:75-128) as a PROCESS with the script's own command line: load_quant with the warm-ups, model.to(DEV), the
+    tokenizer of the model directory, sampling generate with the script's arguments, decode, print.  Two runs with one seed print the same text (the
+    decode engine behind model.generate is deterministic; sampling draws from torch's seeded generator), another seed still yields a valid text."""
+    import subprocess
+    saved = (torch.nn.init.kaiming_uniform_, torch.nn.init.uniform_, torch.nn.init.normal_)
+    try:
+        cfg_dir = _tiny_config_dir(tmp_path)
+        ckpt, _ = _tiny_checkpoint(tmp_path, cfg_dir)
+    finally:
+        _restore_torch_defaults(saved)
+    _tiny_tokenizer(cfg_dir)
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    script = tmp_path / 'llama_inference_main.py'
+    script.write_text(MAIN_FLOW.format(tests=here, pkg=os.path.join(root, 'gptq-for-llama_amd'), root=root))
+    cmd = [sys.executable, str(script), cfg_dir, '--wbits', str(WBITS), '--groupsize', str(GROUPSIZE), '--load', ckpt, '--text', 'this is a llama',
+           '--min_length', '12', '--max_length', '32']
+
+    def run(seed):
+        env = dict(os.environ, SEED=str(seed))
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = r.stdout
+        assert 'Loading model ...' in out and 'Done.' in out and 'NATIVE True' in out
+        ids = eval([l for l in out.splitlines() if l.startswith('IDS ')][0][4:])
+        text = eval([l for l in out.splitlines() if l.startswith('TEXT ')][0][5:])
+        assert 12 <= len(ids) <= 32 and max(ids) < TINY['vocab_size'] and isinstance(text, str)
+        steps = int([l for l in out.splitlines() if l.startswith('ENGINE_STEPS ')][0].split()[1])
+        assert steps >= len(ids) - 6          # the decode engine answered the one-token forwards of generate (the prompt is one prefill call)
+        return ids, text
+    a, ta = run(0)
+    b, tb = run(0)
+    assert a == b and ta == tb
+    assert ta.lstrip('<s>').strip().startswith('this is a llama')
+    run(1)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('transpose', [False, True])
 def test_autotune_warmup_linear_walks_every_m(transpose, capsys):

@@ -99,6 +99,28 @@ def test_soak_decode_linears(name, K, N, NS, norm, res, M):
     soak(launch, (M, N), dirt)
 
 
+@pytest.mark.parametrize('M', [32, 64, 100, 128])
+@pytest.mark.parametrize('name,K,N,NS', [('qkv', 4096, 12288, 1), ('gate | up', 4096, 11008, 2), ('two stripes per workgroup', 1024, 8192, 1)])
+def test_soak_short_prompt_tiles(name, K, N, NS, M):
+    """round 6, second half: 17 .. 128 rows on the wide layers run the loader / consumer kernel (csrc/stripe_mm.inc stripe_mmr_kernel) -- waves of one
+    workgroup meeting through progress words in LDS, an LDS ring refilled by LDS-DMA while other waves read it.  The same soak: a race between a
+    loader's refill and a consumer's reads, a progress word read before its initialisation, or a chunk consumed before it landed shows up as a
+    differing launch (instances: two, four, seven row tiles in two passes, eight as row halves / as two launches for the pair)"""
+    bits, gs = 4, 128
+    Ls = [make_random_layer(bits, gs, K, N, seed=60 + i) for i in range(NS)]
+    sets = tuple((dev(L['qweight']), dev(L['scales']), dev(L['qzeros']), dev(L['g_idx'])) for L in Ls)
+    pl = prepared(sets, None, bits, gs, K, N)
+    lib = _native.lib()
+    x = dev(np.random.default_rng(M + N).standard_normal((M, K)).astype(np.float16))
+    dirt = Dirt(lib.gptq_layer_decode_scratch_bytes(pl.handle, M))
+
+    def launch(y):
+        rc = lib.gptq_layer_decode_f16(pl.handle, x.data_ptr(), K, y.data_ptr(), N, M, None, 1e-6, None, 0, dirt.lws.data_ptr(), dirt.lws.numel(),
+                                       dirt.scratch.data_ptr(), dirt.scratch.numel(), dirt.s)
+        assert rc == 0, rc
+    soak(launch, (M, N), dirt, launches=max(LAUNCHES // 8, RING))
+
+
 @pytest.mark.parametrize('M', [9, 16])
 def test_soak_down_proj_with_the_next_norm(M):
     """round 6: down_proj at 9 .. 16 rows -- K slices + the combine launch that also writes the next block's RMSNorm rows

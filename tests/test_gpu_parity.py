@@ -1004,13 +1004,15 @@ def test_stripe_mm_vs_oracle(bits, K, N, gs, M):
 
 
 @pytest.mark.parametrize('M', [17, 40, 64, 77, 80, 96, 112, 113, 128])
-@pytest.mark.parametrize('K,N,gs', [(4096, 11008, 128), (1024, 6176, 128), (2048, 8192, 256), (1152, 12288, -1)])
+@pytest.mark.parametrize('K,N,gs', [(4096, 11008, 128), (1024, 6176, 128), (2048, 8192, 256), (1152, 12288, -1), (11008, 4096, 128), (6272, 3584, 128)])
 def test_stripe_mm_loader_consumer_route(K, N, gs, M):
     """17 .. 128 rows on shapes whose stripes need two or three rounds of workgroups and K <= 8192 -- the home ground of the loader / consumer kernel
     (csrc/stripe_mm.inc stripe_mmr_kernel, round 6: x through an LDS ring of (row block, 64-row pass) chunks, two passes per row block from 65 rows on):
     a ragged stripe count (688 = 229 x 3 + 1: the last workgroup's clamped stripes), ragged batches (rows >= M are clamped loads and
     skipped stores), groups of two row blocks and one group, a row-block count that is not a multiple of the six consumer waves / two loader waves, a
-    bias, and x as a strided view; against the oracle, bit-reproducible, every row bit-independent of its position (ONE launch, one schedule)"""
+    bias, and x as a strided view; against the oracle, bit-reproducible, every row bit-independent of its position (ONE launch, one schedule).
+    The last two shapes (one round of stripes, long K: LLaMA-7B's down_proj; 224 stripes x 49 row blocks) take its K-SLICED form -- four stripes x four
+    slices per round of workgroups (a ragged last slice: 86 = 3 x 22 + 20, 49 = 3 x 13 + 10), fp32 rows per slice, the combine launch adds them in slice order"""
     L = make_random_layer(4, gs, K, N, seed=K + N + M)
     rng = np.random.default_rng(M)
     x = rng.standard_normal((M, K)).astype(np.float16)

@@ -100,7 +100,7 @@ def test_soak_decode_linears(name, K, N, NS, norm, res, M):
 
 
 @pytest.mark.parametrize('M', [32, 64, 100, 128])
-@pytest.mark.parametrize('name,K,N,NS', [('qkv', 4096, 12288, 1), ('gate | up', 4096, 11008, 2), ('two stripes per workgroup', 1024, 8192, 1)])
+@pytest.mark.parametrize('name,K,N,NS', [('qkv', 4096, 12288, 1), ('gate | up', 4096, 11008, 2), ('two stripes per workgroup', 1024, 8192, 1), ('down_proj: K slices + combine', 11008, 4096, 1)])
 def test_soak_short_prompt_tiles(name, K, N, NS, M):
     """round 6, second half: 17 .. 128 rows on the wide layers run the loader / consumer kernel (csrc/stripe_mm.inc stripe_mmr_kernel) -- waves of one
     workgroup meeting through progress words in LDS, an LDS ring refilled by LDS-DMA while other waves read it.  The same soak: a race between a

@@ -388,8 +388,12 @@ int gptq_stripe_matmul_partial_f32(const void *x, int64_t ldx, const void *strip
  * rowwave kernels.  129 <= M <= gptq_set_stripe_gemm_max_rows() (default 2048; groups of at least a row block, bits 3 / 4 / 8): ONE launch of
  * the 2-D tiled fused-dequantise GEMM (stripe_gemm_kernel: 128 x 128 tiles, weights stay packed, x through LDS) -- no per-call
  * dequantise pass; round 5: while the tiles cover at most half the chip (N = 4096: up to 512 rows) K is sliced over the row tiles too
- * (partial tiles in `workspace` + the reduce kernel, as below 129 rows).  Reference semantics:
- * quant/quant_linear.py:103-137, :415-419; nsets = 2: quant/fused_mlp.py:128-168 (no bias). */
+ * (partial tiles in `workspace` + the reduce kernel, as below 129 rows).  Round 6: 17 <= M <= 128 of a 4-bit layer whose stripes need two or three
+ * rounds of workgroups (N = 8192 .. 12288; K <= 8192) and of the gate | up pair of such a shape run the loader / consumer kernel (stripe_mmr_kernel:
+ * two waves per workgroup stream x into an LDS ring by LDS-DMA, six only read A fragments out of it and run the MFMAs on weights unpacked in their
+ * registers; the pair's consumers split by set) -- one launch, no workspace; a long K on one round of stripes (N <= 4096, K > 6144) runs its K-sliced
+ * form: fp32 rows per slice in `workspace` + a combine launch (slice order, one rounding).  Same arithmetic and result conventions as the tiles above.
+ * Reference semantics: quant/quant_linear.py:103-137, :415-419; nsets = 2: quant/fused_mlp.py:128-168 (no bias). */
 int gptq_stripe_matmul_f16(const void *x, int64_t ldx, const void *stripes, size_t stripes_bytes, const void *bias, void *y, int64_t ldy, int M,
                            int K, int N, int bits, int groupsize, int nsets, void *workspace, size_t workspace_bytes, gptq_stream_t stream);
 

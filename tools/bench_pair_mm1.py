@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """the single-launch gate/up pair kernel for 5..16 rows (stripe_mm1_kernel<1, 2, PF>): PF = 2 (two workgroups per CU, 128 VGPRs, 208 B of
-scratch per lane) against PF = 4 (one workgroup per CU, no spills).  Run once per setting: GPTQ_MM1_PAIR_PF=2|4 python tools/bench_pair_mm1.py"""
+scratch per lane) against PF = 4 (one workgroup per CU, no spills).  Run once per setting: GPTQ_MM1_PAIR_PF=2|4 python tools/bench_pair_mm1.py
+Round 6: MS=16,32,..,128 times 2 x 4096 x 11008 at those batches (17 .. 128 rows: the loader / consumer pair, GPTQ_MMR_PAIR=0 restores the routes before)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'gptq-for-llama_amd')); sys.path.insert(0, ROOT)

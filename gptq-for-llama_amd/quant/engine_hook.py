@@ -11,7 +11,8 @@ original forward untouched.  Beam search goes the eager way too (round 6, ADVICE
 every step (``cache.reorder_cache(beam_idx)``), which the engine's static per-row K/V cache would not follow -- ``generate(num_beams > 1)``
 switches the hook off for the call, and a tracked cache whose ``reorder_cache`` is called by anyone is completed, released and never
 tracked again.  The caller keeps its API: HF ``generate`` with its own sampling, stopping
-criteria and cache object.
+criteria and cache object.  Round 6: the one call HF's loop only slows down -- plain GREEDY ``generate`` of one prompt with nothing between the steps --
+runs the engine's self-feeding greedy graph instead (``_greedy_fast`` below: the same tokens, no host round trip per token).
 
 Cache protocol: the engine owns a static K/V cache.  The first decode step after a prefill copies the caller's cache
 into it; later steps only advance the engine (HF ``generate`` carries position_ids / attention_mask itself and never
@@ -308,6 +309,103 @@ def _engine_forward(model, st, input_ids, cache, attention_mask, position_ids, k
     return CausalLMOutputWithPast(loss=None, logits=logits.view(B, 1, -1).clone(), past_key_values=cache)
 
 
+# ---- greedy generate without a host round trip per token (round 6) ----
+# model.generate(ids[1, T], do_sample=False, max_new_tokens=N) with nothing that looks at the scores between the steps is what engine_generate
+# (quant/decode.py) does on the device: the prompt through the eager chain once, then ONE hipGraph replay per token whose argmax feeds the next
+# replay, the host looking at the stream every 16 tokens only (EOS).  HF's loop costs ~170 us of host work per token on top of the same
+# replays (bench.py: drop_in_generate 784 tok/s against 920-937 for the engine under the reference's protocol).  The tokens are the ones HF's
+# loop picks: both take the argmax of the logits the SAME engine step writes.  Anything this path does not reproduce to the letter -- sampling,
+# processors, criteria, streamers, score outputs, batches, masks with holes -- takes HF's loop as before.  GPTQ_GREEDY_FAST=0: off.
+GREEDY_FAST = os.environ.get('GPTQ_GREEDY_FAST', '1') != '0'
+_GREEDY_KW = {'input_ids', 'inputs', 'do_sample', 'max_new_tokens', 'max_length', 'min_length', 'min_new_tokens', 'eos_token_id', 'pad_token_id',
+              'attention_mask', 'use_cache', 'num_beams', 'temperature', 'top_p', 'top_k'}
+# generation_config fields that must sit at their neutral value (name, neutral values)
+_GREEDY_NEUTRAL = (('num_return_sequences', (None, 1)), ('repetition_penalty', (None, 1.0)), ('no_repeat_ngram_size', (None, 0)),
+                   ('encoder_no_repeat_ngram_size', (None, 0)), ('bad_words_ids', (None,)), ('force_words_ids', (None,)), ('renormalize_logits', (None, False)),
+                   ('constraints', (None,)), ('forced_bos_token_id', (None,)), ('forced_eos_token_id', (None,)), ('remove_invalid_values', (None, False)),
+                   ('exponential_decay_length_penalty', (None,)), ('suppress_tokens', (None,)), ('begin_suppress_tokens', (None,)), ('sequence_bias', (None,)),
+                   ('guidance_scale', (None, 1, 1.0)), ('penalty_alpha', (None,)), ('output_scores', (None, False)), ('output_logits', (None, False)),
+                   ('output_attentions', (None, False)), ('output_hidden_states', (None, False)), ('return_dict_in_generate', (None, False)),
+                   ('stop_strings', (None,)), ('prompt_lookup_num_tokens', (None,)), ('max_time', (None,)), ('cache_implementation', (None,)),
+                   ('num_beam_groups', (None, 1)), ('dola_layers', (None,)), ('assistant_early_exit', (None,)), ('watermarking_config', (None,)),
+                   ('token_healing', (None, False)), ('low_memory', (None, False)), ('compile_config', (None,)))
+
+
+def _greedy_fast(model, st, args, kwargs):
+    """the sequence [1, T + new] model.generate would return, or None when this call is not the plain greedy case (HF's loop takes it)."""
+    if not (ENABLED and GREEDY_FAST) or model.training or getattr(model, '_gptq_engine_disabled', False):
+        return None
+    if len(args) > 1 or not set(kwargs) <= _GREEDY_KW:
+        return None
+    gc = getattr(model, 'generation_config', None)
+    if gc is None:
+        return None
+    get = lambda name: kwargs[name] if kwargs.get(name) is not None else getattr(gc, name, None)
+    if get('do_sample') or int(get('num_beams') or 1) != 1 or get('use_cache') is False:
+        return None
+    for name, neutral in _GREEDY_NEUTRAL:
+        if getattr(gc, name, None) not in neutral:
+            return None
+    ids = args[0] if args else kwargs.get('input_ids', kwargs.get('inputs'))
+    dev = next(model.parameters()).device
+    if not torch.is_tensor(ids) or ids.dim() != 2 or ids.shape[0] != 1 or ids.shape[1] < 2 or ids.dtype != torch.int64 or ids.device != dev or dev.type != 'cuda':
+        return None
+    T = int(ids.shape[1])
+    mask = kwargs.get('attention_mask')
+    if mask is not None and (not torch.is_tensor(mask) or tuple(mask.shape) != (1, T) or not bool((mask != 0).all())):
+        return None
+    new = kwargs.get('max_new_tokens') or (None if kwargs.get('max_length') is not None else getattr(gc, 'max_new_tokens', None))
+    if new is None:
+        new = int(get('max_length') or 0) - T
+    new = int(new)
+    if new < 1:
+        return None
+    eos = get('eos_token_id')
+    eos = None if eos is None else [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
+    # min_length / min_new_tokens only ever change a step whose argmax is an EOS token (HF sets those logits to -inf until then): the stream is
+    # generated without the mask, and if an EOS shows up before the minimum the call is handed to HF's loop after all (nothing was returned yet)
+    min_new = max(int(get('min_new_tokens') or 0), int(get('min_length') or 0) - T, 0) if eos else 0
+    eng, _ = _engine_for(model, st, 1, _signature(model), need=T + new + 1)
+    if eng is None or eng.batch != 1 or T + new + 1 > eng.t_max:
+        return None
+    from transformers.cache_utils import DynamicCache
+    from .decode import _cache_layer_kv
+    if st.cache_ref is not None:          # a sequence some caller steps by hand: its cache is completed before the engine moves on
+        _sync_back(st)
+    st.engine, st.cache_ref = None, None
+    with torch.no_grad():
+        cache = DynamicCache(config=model.config)
+        out = model._gptq_orig_forward(input_ids=ids, past_key_values=cache, use_cache=True)
+        first = out.logits[0, -1].argmax().reshape(1)
+        for li in range(len(eng.layers)):
+            k, v = _cache_layer_kv(cache, li)
+            eng.kc[li, :T].copy_(k[0].transpose(0, 1).reshape(T, -1))
+            eng.vc[li, :T].copy_(v[0].transpose(0, 1).reshape(T, -1))
+        del out, cache
+        eng.pos.fill_(T)
+        if eng.greedy_graph is None:
+            eng.capture_greedy()
+        eng.ids.copy_(first)
+        eng.stream_out[T] = first[0]                          # stream_out[p] = the token generated after p consumed tokens
+        eos_t = torch.tensor(eos, device=dev, dtype=eng.stream_out.dtype) if eos else None
+        done = 1
+        hit_eos = lambda: eos_t is not None and bool(torch.isin(eng.stream_out[T:T + done], eos_t).any())
+        while done < new and not hit_eos():
+            burst = min(16, new - done)                       # the host looks at the stream every 16 tokens only
+            for _ in range(burst):
+                eng.greedy_graph.replay()
+            done += burst
+            st.steps += burst
+        gen = eng.stream_out[T:T + done].clone()
+        if eos_t is not None:
+            hit = torch.isin(gen, eos_t).nonzero()
+            if hit.numel():
+                if int(hit[0]) < min_new:
+                    return None                               # HF's loop would have masked this EOS: it takes the call
+                gen = gen[:int(hit[0]) + 1]
+    return torch.cat([ids[0], gen.to(ids.dtype)]).unsqueeze(0)
+
+
 def install_decode_engine(model):
     """wrap ``model.forward`` (instance level).  Idempotent; returns the model."""
     if not ENABLED or getattr(model, '_gptq_engine_state', None) is not None:
@@ -357,6 +455,10 @@ def install_decode_engine(model):
             if beams > 1:                     # beams: the cache is permuted in place after every step -- eager (see the module docstring)
                 self._gptq_engine_disabled = True
             try:
+                if beams == 1:
+                    fast = _greedy_fast(self, st, args, kwargs)
+                    if fast is not None:
+                        return fast
                 return orig_generate(*args, **kwargs)
             finally:
                 self._gptq_engine_disabled = was_off

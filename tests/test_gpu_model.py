@@ -509,6 +509,74 @@ def test_generate_goes_through_the_decode_engine_and_matches_the_module_chain():
     assert s.shape[1] <= 40 and torch.equal(s[:, :7], ids)
 
 
+def test_greedy_generate_fast_path_equals_the_hf_loop():
+    """round 6: model.generate(ids[1, T], do_sample=False, max_new_tokens=N) with nothing between the steps runs the self-feeding greedy graph
+    (quant/engine_hook.py _greedy_fast: no host round trip per token) -- the SAME tokens as HF's loop over the same engine steps, with and
+    without an EOS in the stream, with max_length instead of max_new_tokens and an all-ones mask; every call the fast path does not reproduce
+    to the letter (sampling, min_length, score outputs, batches, a prompt of one token) takes HF's loop"""
+    from quant import engine_hook as EH
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=17, fused=True, **HOOK_CFG)
+    ids = torch.randint(1, 512, (1, 9), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    calls = []
+    orig = EH._greedy_fast
+    EH._greedy_fast = lambda *a, **k: (calls.append(orig(*a, **k)) or calls[-1])
+    try:
+        def both(**kw):
+            with torch.no_grad():
+                calls.clear()
+                fast = model.generate(ids, **kw)
+                assert len(calls) == 1 and calls[0] is not None, 'the fast path declined %r' % (kw,)
+                EH.GREEDY_FAST = False
+                try:
+                    slow = model.generate(ids, **kw)
+                finally:
+                    EH.GREEDY_FAST = True
+            assert fast.dtype == slow.dtype and fast.device == slow.device
+            assert torch.equal(fast, slow), (fast.tolist(), slow.tolist())
+            return fast
+        before = EH.engine_steps(model)
+        full = both(do_sample=False, max_new_tokens=40)
+        assert full.shape == (1, 49) and torch.equal(full[:, :9], ids)
+        assert EH.engine_steps(model) == before + 2 * 39                       # both ways: every token after the prompt's is an engine step
+        both(do_sample=False, max_length=30, attention_mask=torch.ones_like(ids))
+        eos = int(full[0, 9 + 21])                                              # a token the stream contains: both stop behind its FIRST occurrence
+        cut = both(do_sample=False, max_new_tokens=40, eos_token_id=eos, pad_token_id=0)
+        first = int((full[0, 9:] == eos).nonzero()[0])
+        assert cut.shape[1] == 9 + first + 1 and int(cut[0, -1]) == eos
+        both(do_sample=False, max_new_tokens=40, eos_token_id=[eos, int(full[0, 9 + 30])])
+        both(do_sample=False, max_new_tokens=1)
+        # a minimum length only matters where an EOS would be picked before it: behind the EOS the minimum allows -> the fast path's stream stands ...
+        both(do_sample=False, max_new_tokens=40, eos_token_id=eos, min_new_tokens=first, pad_token_id=0)
+        both(do_sample=False, max_new_tokens=40, eos_token_id=eos, min_length=9 + first, pad_token_id=0)
+        # ... in front of it HF's loop masks that EOS and goes on: the fast path hands the call over (and the result is HF's)
+        with torch.no_grad():
+            calls.clear()
+            masked = model.generate(ids, do_sample=False, max_new_tokens=40, eos_token_id=eos, min_new_tokens=first + 2, pad_token_id=0)
+            assert calls == [None]
+            EH.GREEDY_FAST = False
+            try:
+                assert torch.equal(masked, model.generate(ids, do_sample=False, max_new_tokens=40, eos_token_id=eos, min_new_tokens=first + 2, pad_token_id=0))
+            finally:
+                EH.GREEDY_FAST = True
+            assert masked.shape[1] > 9 + first + 1 and int(masked[0, 9 + first]) != eos
+        # ... and what it leaves to HF's loop
+        with torch.no_grad():
+            for kw in (dict(do_sample=True, max_new_tokens=8, top_p=0.9), dict(do_sample=False, max_new_tokens=8, output_logits=True, return_dict_in_generate=True),
+                       dict(do_sample=False, max_new_tokens=8, repetition_penalty=1.2)):
+                calls.clear()
+                model.generate(ids, **kw)
+                assert calls == [None] or calls == [], kw
+            calls.clear()
+            model.generate(ids[:, :1], do_sample=False, max_new_tokens=4)     # a one-token prompt: its first step is an engine step in HF's loop
+            assert calls == [None]
+            calls.clear()
+            model.generate(torch.cat([ids, ids]), do_sample=False, max_new_tokens=4, pad_token_id=0)
+            assert calls == [None]
+    finally:
+        EH._greedy_fast = orig
+        EH.GREEDY_FAST = True
+
+
 def test_batched_generate_goes_through_the_batched_engine():
     """model.generate on a BATCH of prompts (all-ones padding mask, batch 4 and 12): since round 5 the hook answers [B, 1] steps with
     DecodeEngine(batch = B) -- the linears run at M = batch inside ONE hipGraph replay (decode kernel row groups at 4, 16-row MFMA tiles

@@ -311,7 +311,7 @@ def _engine_forward(model, st, input_ids, cache, attention_mask, position_ids, k
 
 # ---- greedy generate without a host round trip per token (round 6) ----
 # model.generate(ids[1, T], do_sample=False, max_new_tokens=N) with nothing that looks at the scores between the steps is what engine_generate
-# (quant/decode.py) does on the device: the prompt through the eager chain once, then ONE hipGraph replay per token whose argmax feeds the next
+# (quant/decode.py) does on the device: the prompt and the first token through HF's own generate (one new token), then ONE hipGraph replay per token whose argmax feeds the next
 # replay, the host looking at the stream every 16 tokens only (EOS).  HF's loop costs ~170 us of host work per token on top of the same
 # replays (bench.py: drop_in_generate 784 tok/s against 920-937 for the engine under the reference's protocol).  The tokens are the ones HF's
 # loop picks: both take the argmax of the logits the SAME engine step writes.  Anything this path does not reproduce to the letter -- sampling,
@@ -331,7 +331,7 @@ _GREEDY_NEUTRAL = (('num_return_sequences', (None, 1)), ('repetition_penalty', (
                    ('token_healing', (None, False)), ('low_memory', (None, False)), ('compile_config', (None,)))
 
 
-def _greedy_fast(model, st, args, kwargs):
+def _greedy_fast(model, st, orig_generate, args, kwargs):
     """the sequence [1, T + new] model.generate would return, or None when this call is not the plain greedy case (HF's loop takes it)."""
     if not (ENABLED and GREEDY_FAST) or model.training or getattr(model, '_gptq_engine_disabled', False):
         return None
@@ -368,15 +368,20 @@ def _greedy_fast(model, st, args, kwargs):
     eng, _ = _engine_for(model, st, 1, _signature(model), need=T + new + 1)
     if eng is None or eng.batch != 1 or T + new + 1 > eng.t_max:
         return None
-    from transformers.cache_utils import DynamicCache
     from .decode import _cache_layer_kv
     if st.cache_ref is not None:          # a sequence some caller steps by hand: its cache is completed before the engine moves on
         _sync_back(st)
     st.engine, st.cache_ref = None, None
     with torch.no_grad():
-        cache = DynamicCache(config=model.config)
-        out = model._gptq_orig_forward(input_ids=ids, past_key_values=cache, use_cache=True)
-        first = out.logits[0, -1].argmax().reshape(1)
+        # the prompt and the FIRST token are HF's own: its generate for one new token (its prefill inputs, its processors on that step)
+        kw1 = {k: v for k, v in kwargs.items() if k not in ('input_ids', 'inputs', 'max_new_tokens', 'max_length', 'min_length', 'min_new_tokens')}
+        if min_new >= 1:
+            kw1['min_new_tokens'] = 1         # (all of the caller's minimum that this one step can see; the full value would only draw HF's "unfeasible" warning)
+        out = orig_generate(ids, max_new_tokens=1, return_dict_in_generate=True, **kw1)
+        cache = getattr(out, 'past_key_values', None)
+        if cache is None or tuple(out.sequences.shape) != (1, T + 1) or _cache_len(cache) != T:
+            return None
+        first = out.sequences[0, T:].clone()
         for li in range(len(eng.layers)):
             k, v = _cache_layer_kv(cache, li)
             eng.kc[li, :T].copy_(k[0].transpose(0, 1).reshape(T, -1))
@@ -456,7 +461,7 @@ def install_decode_engine(model):
                 self._gptq_engine_disabled = True
             try:
                 if beams == 1:
-                    fast = _greedy_fast(self, st, args, kwargs)
+                    fast = _greedy_fast(self, st, orig_generate, args, kwargs)
                     if fast is not None:
                         return fast
                 return orig_generate(*args, **kwargs)

@@ -261,6 +261,7 @@ class DecodeEngine:
         self.logits = torch.zeros((B, self.lm_head.shape[0]), **f16)
         self.stream_out = torch.zeros(self.t_max + 1, dtype=torch.int64, device=dev)   # greedy mode (batch 1): token chosen after position p
         self.greedy_graph = None
+        self.greedy_rows_graph, self.stream_rows, self.stepc = None, None, None
         nl = len(self.layers)
         self.kcb = torch.zeros((nl, B, self.t_max, H), **f16)          # [layer][row][t][heads * head_dim]
         self.vcb = torch.zeros((nl, B, self.t_max, H), **f16)
@@ -600,6 +601,32 @@ class DecodeEngine:
                 self._greedy_step()
             self.greedy_graph = g
             self.pos.copy_(pos0); self.ids.copy_(ids0)
+        return self
+
+    def _greedy_rows_step(self):
+        """the self-feeding greedy step for ANY batch: every row's argmax becomes its next input token, and the choices of step n are row n of
+        stream_rows (n = stepc, a device counter the step advances itself)"""
+        self._step()
+        torch.argmax(self.logits, dim=-1, out=self.ids)
+        self.stream_rows.index_copy_(0, self.stepc, self.ids.unsqueeze(0))
+        self.stepc.add_(1)
+
+    def capture_greedy_rows(self):
+        """capture _greedy_rows_step (quant/engine_hook.py _greedy_fast: greedy model.generate without a host round trip per token)"""
+        with torch.no_grad():
+            if getattr(self, 'stream_rows', None) is None:
+                self.stream_rows = torch.zeros((self.t_max + 1, self.batch), dtype=torch.int64, device=self.dev)
+                self.stepc = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            pos0, ids0 = self.pos.clone(), self.ids.clone()
+            self.stepc.zero_()
+            self._greedy_rows_step()
+            torch.cuda.synchronize(self.dev)
+            self.pos.copy_(pos0); self.ids.copy_(ids0); self.stepc.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._greedy_rows_step()
+            self.greedy_rows_graph = g
+            self.pos.copy_(pos0); self.ids.copy_(ids0); self.stepc.zero_()
         return self
 
     def capture(self):

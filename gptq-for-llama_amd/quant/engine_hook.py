@@ -310,12 +310,13 @@ def _engine_forward(model, st, input_ids, cache, attention_mask, position_ids, k
 
 
 # ---- greedy generate without a host round trip per token (round 6) ----
-# model.generate(ids[1, T], do_sample=False, max_new_tokens=N) with nothing that looks at the scores between the steps is what engine_generate
+# model.generate(ids[B <= 16, T], do_sample=False, max_new_tokens=N) (left-padded mask allowed) with nothing that looks at the scores between the steps is what engine_generate
 # (quant/decode.py) does on the device: the prompt and the first token through HF's own generate (one new token), then ONE hipGraph replay per token whose argmax feeds the next
 # replay, the host looking at the stream every 16 tokens only (EOS).  HF's loop costs ~170 us of host work per token on top of the same
 # replays (bench.py: drop_in_generate 784 tok/s against 920-937 for the engine under the reference's protocol).  The tokens are the ones HF's
 # loop picks: both take the argmax of the logits the SAME engine step writes.  Anything this path does not reproduce to the letter -- sampling,
-# processors, criteria, streamers, score outputs, batches, masks with holes -- takes HF's loop as before.  GPTQ_GREEDY_FAST=0: off.
+# processors, criteria, streamers, score outputs, more than 16 rows, masks with holes -- takes HF's loop as before.  Batches: a row that has its EOS gets the pad
+# token from then on, the call ends when every row has one (HF's own rule); the rows never see each other, so the stream is cut and padded afterwards.  GPTQ_GREEDY_FAST=0: off.
 GREEDY_FAST = os.environ.get('GPTQ_GREEDY_FAST', '1') != '0'
 _GREEDY_KW = {'input_ids', 'inputs', 'do_sample', 'max_new_tokens', 'max_length', 'min_length', 'min_new_tokens', 'eos_token_id', 'pad_token_id',
               'attention_mask', 'use_cache', 'num_beams', 'temperature', 'top_p', 'top_k'}
@@ -332,7 +333,7 @@ _GREEDY_NEUTRAL = (('num_return_sequences', (None, 1)), ('repetition_penalty', (
 
 
 def _greedy_fast(model, st, orig_generate, args, kwargs):
-    """the sequence [1, T + new] model.generate would return, or None when this call is not the plain greedy case (HF's loop takes it)."""
+    """the sequences [B, T + n] model.generate would return, or None when this call is not the plain greedy case (HF's loop takes it)."""
     if not (ENABLED and GREEDY_FAST) or model.training or getattr(model, '_gptq_engine_disabled', False):
         return None
     if len(args) > 1 or not set(kwargs) <= _GREEDY_KW:
@@ -348,12 +349,17 @@ def _greedy_fast(model, st, orig_generate, args, kwargs):
             return None
     ids = args[0] if args else kwargs.get('input_ids', kwargs.get('inputs'))
     dev = next(model.parameters()).device
-    if not torch.is_tensor(ids) or ids.dim() != 2 or ids.shape[0] != 1 or ids.shape[1] < 2 or ids.dtype != torch.int64 or ids.device != dev or dev.type != 'cuda':
+    if not torch.is_tensor(ids) or ids.dim() != 2 or not 1 <= ids.shape[0] <= MAX_BATCH or ids.shape[1] < 2 or ids.dtype != torch.int64 or ids.device != dev or dev.type != 'cuda':
         return None
-    T = int(ids.shape[1])
+    B, T = int(ids.shape[0]), int(ids.shape[1])
     mask = kwargs.get('attention_mask')
-    if mask is not None and (not torch.is_tensor(mask) or tuple(mask.shape) != (1, T) or not bool((mask != 0).all())):
-        return None
+    npad = None
+    if mask is not None:                 # all ones, or zeros as a LEFT-padding prefix of each row (one host sync)
+        if not torch.is_tensor(mask) or tuple(mask.shape) != (B, T) or mask.device != dev:
+            return None
+        npad = _left_pads(mask, T - 1)
+        if npad is None:
+            return None
     new = kwargs.get('max_new_tokens') or (None if kwargs.get('max_length') is not None else getattr(gc, 'max_new_tokens', None))
     if new is None:
         new = int(get('max_length') or 0) - T
@@ -362,13 +368,17 @@ def _greedy_fast(model, st, orig_generate, args, kwargs):
         return None
     eos = get('eos_token_id')
     eos = None if eos is None else [int(e) for e in (eos if isinstance(eos, (list, tuple)) else [eos])]
+    pad = get('pad_token_id')
+    if mask is None and pad is not None and bool((ids == int(pad)).any()):
+        return None                       # HF derives a mask from the pad tokens it finds in the prompt: its loop
+    if B > 1 and eos and pad is None:
+        pad = eos[0]                      # (HF's own default, with a warning)
     # min_length / min_new_tokens only ever change a step whose argmax is an EOS token (HF sets those logits to -inf until then): the stream is
     # generated without the mask, and if an EOS shows up before the minimum the call is handed to HF's loop after all (nothing was returned yet)
     min_new = max(int(get('min_new_tokens') or 0), int(get('min_length') or 0) - T, 0) if eos else 0
-    eng, _ = _engine_for(model, st, 1, _signature(model), need=T + new + 1)
-    if eng is None or eng.batch != 1 or T + new + 1 > eng.t_max:
+    eng, _ = _engine_for(model, st, B, _signature(model), need=T + new + 1)
+    if eng is None or eng.batch != B or T + new + 1 > eng.t_max:
         return None
-    from .decode import _cache_layer_kv
     if st.cache_ref is not None:          # a sequence some caller steps by hand: its cache is completed before the engine moves on
         _sync_back(st)
     st.engine, st.cache_ref = None, None
@@ -379,36 +389,43 @@ def _greedy_fast(model, st, orig_generate, args, kwargs):
             kw1['min_new_tokens'] = 1         # (all of the caller's minimum that this one step can see; the full value would only draw HF's "unfeasible" warning)
         out = orig_generate(ids, max_new_tokens=1, return_dict_in_generate=True, **kw1)
         cache = getattr(out, 'past_key_values', None)
-        if cache is None or tuple(out.sequences.shape) != (1, T + 1) or _cache_len(cache) != T:
+        if cache is None or tuple(out.sequences.shape) != (B, T + 1) or _cache_len(cache) != T:
             return None
-        first = out.sequences[0, T:].clone()
-        for li in range(len(eng.layers)):
-            k, v = _cache_layer_kv(cache, li)
-            eng.kc[li, :T].copy_(k[0].transpose(0, 1).reshape(T, -1))
-            eng.vc[li, :T].copy_(v[0].transpose(0, 1).reshape(T, -1))
+        first = out.sequences[:, T].clone()
+        st.engine = eng
+        _sync_in(st, cache, T, npad)          # the rows' K / V behind their pads, per-row positions
+        st.engine, st.cache_ref = None, None  # (nobody tracks this cache: it is dropped below)
         del out, cache
-        eng.pos.fill_(T)
-        if eng.greedy_graph is None:
-            eng.capture_greedy()
+        if eng.greedy_rows_graph is None:
+            eng.capture_greedy_rows()
+        eng.stepc.zero_()
         eng.ids.copy_(first)
-        eng.stream_out[T] = first[0]                          # stream_out[p] = the token generated after p consumed tokens
-        eos_t = torch.tensor(eos, device=dev, dtype=eng.stream_out.dtype) if eos else None
-        done = 1
-        hit_eos = lambda: eos_t is not None and bool(torch.isin(eng.stream_out[T:T + done], eos_t).any())
-        while done < new and not hit_eos():
+        eos_t = torch.tensor(eos, device=dev, dtype=torch.int64) if eos else None
+        done = 1                              # tokens per row so far: `first`, then rows 0 .. done - 2 of stream_rows
+        stream = lambda: torch.cat([first[None, :], eng.stream_rows[:done - 1]], 0)           # [done, B]
+        all_hit = lambda: eos_t is not None and bool(torch.isin(stream(), eos_t).any(0).all())
+        while done < new and not all_hit():
             burst = min(16, new - done)                       # the host looks at the stream every 16 tokens only
             for _ in range(burst):
-                eng.greedy_graph.replay()
+                eng.greedy_rows_graph.replay()
             done += burst
             st.steps += burst
-        gen = eng.stream_out[T:T + done].clone()
+        gen = stream().t().contiguous()                       # [B, done]
+        length = done
         if eos_t is not None:
-            hit = torch.isin(gen, eos_t).nonzero()
-            if hit.numel():
-                if int(hit[0]) < min_new:
-                    return None                               # HF's loop would have masked this EOS: it takes the call
-                gen = gen[:int(hit[0]) + 1]
-    return torch.cat([ids[0], gen.to(ids.dtype)]).unsqueeze(0)
+            hit = torch.isin(gen, eos_t)
+            anyhit = hit.any(1)
+            firsthit = torch.where(anyhit, hit.int().argmax(1), torch.full_like(anyhit, done, dtype=torch.int64))          # per row: index of its first EOS (done: none)
+            info = torch.cat([firsthit, anyhit.to(torch.int64)]).tolist()
+            fh, ah = info[:B], info[B:]
+            if any(a and f < min_new for f, a in zip(fh, ah)):
+                return None                                   # HF's loop would have masked that EOS: it takes the call
+            length = max((f + 1 if a else done) for f, a in zip(fh, ah))          # HF stops when every row has its EOS
+            if any(ah) and B > 1:                             # behind a row's EOS HF writes the pad token while the other rows go on
+                col = torch.arange(done, device=dev)[None, :]
+                gen = torch.where(col > firsthit[:, None], torch.full_like(gen, int(pad)), gen)
+        gen = gen[:, :length]
+    return torch.cat([ids, gen.to(ids.dtype)], 1)
 
 
 def install_decode_engine(model):

@@ -510,10 +510,11 @@ def test_generate_goes_through_the_decode_engine_and_matches_the_module_chain():
 
 
 def test_greedy_generate_fast_path_equals_the_hf_loop():
-    """round 6: model.generate(ids[1, T], do_sample=False, max_new_tokens=N) with nothing between the steps runs the self-feeding greedy graph
+    """round 6: model.generate(ids[B, T], do_sample=False, max_new_tokens=N) with nothing between the steps runs the self-feeding greedy graph
     (quant/engine_hook.py _greedy_fast: no host round trip per token) -- the SAME tokens as HF's loop over the same engine steps, with and
-    without an EOS in the stream, with max_length instead of max_new_tokens and an all-ones mask; every call the fast path does not reproduce
-    to the letter (sampling, min_length, score outputs, batches, a prompt of one token) takes HF's loop"""
+    without an EOS in the stream, with max_length instead of max_new_tokens, minimum lengths, an all-ones mask, and for left-padded BATCHES whose
+    rows end at different steps (pad tokens behind a row's EOS, the call ends with the last row); every call the fast path does not reproduce
+    to the letter (sampling, score outputs, penalties, a prompt of one token) takes HF's loop"""
     from quant import engine_hook as EH
     model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=17, fused=True, **HOOK_CFG)
     ids = torch.randint(1, 512, (1, 9), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
@@ -521,14 +522,14 @@ def test_greedy_generate_fast_path_equals_the_hf_loop():
     orig = EH._greedy_fast
     EH._greedy_fast = lambda *a, **k: (calls.append(orig(*a, **k)) or calls[-1])
     try:
-        def both(**kw):
+        def both(x=ids, **kw):
             with torch.no_grad():
                 calls.clear()
-                fast = model.generate(ids, **kw)
+                fast = model.generate(x, **kw)
                 assert len(calls) == 1 and calls[0] is not None, 'the fast path declined %r' % (kw,)
                 EH.GREEDY_FAST = False
                 try:
-                    slow = model.generate(ids, **kw)
+                    slow = model.generate(x, **kw)
                 finally:
                     EH.GREEDY_FAST = True
             assert fast.dtype == slow.dtype and fast.device == slow.device
@@ -559,6 +560,29 @@ def test_greedy_generate_fast_path_equals_the_hf_loop():
             finally:
                 EH.GREEDY_FAST = True
             assert masked.shape[1] > 9 + first + 1 and int(masked[0, 9 + first]) != eos
+        # batches: left-padded rows of different lengths, rows that end at different steps
+        for Bn in (4, 9):
+            idb = torch.randint(1, 512, (Bn, 8), device=DEV, generator=torch.Generator(device=DEV).manual_seed(Bn))
+            mb = torch.ones_like(idb)
+            for r in range(Bn):
+                n = (3 * r + 2) % 6 if r < Bn - 1 else 0
+                idb[r, :n] = 0
+                mb[r, :n] = 0
+            fullb = both(idb, attention_mask=mb, do_sample=False, max_new_tokens=24, pad_token_id=0)
+            assert fullb.shape == (Bn, 32)
+            both(idb.clamp(min=1), do_sample=False, max_new_tokens=5, pad_token_id=0)                     # (no mask, no pad token in the prompts: every row full length)
+            with torch.no_grad():
+                calls.clear()
+                model.generate(idb, do_sample=False, max_new_tokens=3, pad_token_id=0)                     # no mask BUT pad tokens in the prompts: HF derives one -- its loop
+                assert calls == [None]
+            stop = [int(fullb[1, 8 + 4]), int(fullb[2, 8 + 11])]                                             # rows 1 and 2 end early, at different steps
+            cutb = both(idb, attention_mask=mb, do_sample=False, max_new_tokens=24, eos_token_id=stop, pad_token_id=0)
+            ends = [(torch.isin(fullb[r, 8:], torch.tensor(stop, device=DEV)).nonzero().flatten().tolist() + [None])[0] for r in range(Bn)]
+            if all(e is not None for e in ends):
+                assert cutb.shape[1] == 8 + max(ends) + 1
+            e1 = ends[1]
+            assert e1 is not None and e1 <= 4 and (cutb.shape[1] == 8 + e1 + 1 or bool((cutb[1, 8 + e1 + 1:] == 0).all()))       # pads behind row 1's EOS
+            both(idb, attention_mask=mb, do_sample=False, max_new_tokens=24, eos_token_id=stop)                 # pad defaults to the first EOS id
         # ... and what it leaves to HF's loop
         with torch.no_grad():
             for kw in (dict(do_sample=True, max_new_tokens=8, top_p=0.9), dict(do_sample=False, max_new_tokens=8, output_logits=True, return_dict_in_generate=True),
@@ -569,8 +593,10 @@ def test_greedy_generate_fast_path_equals_the_hf_loop():
             calls.clear()
             model.generate(ids[:, :1], do_sample=False, max_new_tokens=4)     # a one-token prompt: its first step is an engine step in HF's loop
             assert calls == [None]
+            holes = torch.ones((2, 9), dtype=torch.int64, device=DEV)
+            holes[0, 4] = 0
             calls.clear()
-            model.generate(torch.cat([ids, ids]), do_sample=False, max_new_tokens=4, pad_token_id=0)
+            model.generate(torch.cat([ids, ids]), attention_mask=holes, do_sample=False, max_new_tokens=4, pad_token_id=0)      # a mask with a hole
             assert calls == [None]
     finally:
         EH._greedy_fast = orig

@@ -261,7 +261,7 @@ class DecodeEngine:
         self.logits = torch.zeros((B, self.lm_head.shape[0]), **f16)
         self.stream_out = torch.zeros(self.t_max + 1, dtype=torch.int64, device=dev)   # greedy mode (batch 1): token chosen after position p
         self.greedy_graph = None
-        self.greedy_rows_graph, self.stream_rows, self.stepc = None, None, None
+        self.greedy_rows_graph, self.stream_rows, self.stepc, self.sample_graphs = None, None, None, {}
         nl = len(self.layers)
         self.kcb = torch.zeros((nl, B, self.t_max, H), **f16)          # [layer][row][t][heads * head_dim]
         self.vcb = torch.zeros((nl, B, self.t_max, H), **f16)
@@ -628,6 +628,39 @@ class DecodeEngine:
             self.greedy_rows_graph = g
             self.pos.copy_(pos0); self.ids.copy_(ids0); self.stepc.zero_()
         return self
+
+    def _sample_rows_step(self, warpers):
+        """the self-feeding SAMPLING step: HF's own arithmetic on the step's logits (generation/utils.py `_sample`: fp32 copy, the warpers in HF's order,
+        softmax, torch.multinomial) -- inside the graph, where the default generator's Philox offset advances per replay exactly as per eager call"""
+        self._step()
+        scores = self.logits.to(copy=True, dtype=torch.float32)
+        for w in warpers:
+            scores = w(None, scores)
+        probs = torch.nn.functional.softmax(scores, dim=-1)
+        self.ids.copy_(torch.multinomial(probs, num_samples=1).squeeze(1))
+        self.stream_rows.index_copy_(0, self.stepc, self.ids.unsqueeze(0))
+        self.stepc.add_(1)
+
+    def capture_sample_rows(self, key, warpers):
+        """capture _sample_rows_step for one (temperature, top_k, top_p) setting; the generator's state is put back behind the warm-up run"""
+        with torch.no_grad():
+            if getattr(self, 'stream_rows', None) is None:
+                self.stream_rows = torch.zeros((self.t_max + 1, self.batch), dtype=torch.int64, device=self.dev)
+                self.stepc = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            rng = torch.cuda.get_rng_state(self.dev)
+            pos0, ids0 = self.pos.clone(), self.ids.clone()
+            self.stepc.zero_()
+            self._sample_rows_step(warpers)
+            torch.cuda.synchronize(self.dev)
+            self.pos.copy_(pos0); self.ids.copy_(ids0); self.stepc.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._sample_rows_step(warpers)
+            self.pos.copy_(pos0); self.ids.copy_(ids0); self.stepc.zero_()
+            torch.cuda.synchronize(self.dev)
+            torch.cuda.set_rng_state(rng, self.dev)
+            self.sample_graphs = {key: g}          # (one setting at a time: a graph holds the temporaries of a vocabulary-sized sort per row)
+        return g
 
     def capture(self):
         """warm up once (module loads, workspace), then capture one decode step into a hipGraph."""

@@ -314,10 +314,13 @@ def _engine_forward(model, st, input_ids, cache, attention_mask, position_ids, k
 # (quant/decode.py) does on the device: the prompt and the first token through HF's own generate (one new token), then ONE hipGraph replay per token whose argmax feeds the next
 # replay, the host looking at the stream every 16 tokens only (EOS).  HF's loop costs ~170 us of host work per token on top of the same
 # replays (bench.py: drop_in_generate 784 tok/s against 920-937 for the engine under the reference's protocol).  The tokens are the ones HF's
-# loop picks: both take the argmax of the logits the SAME engine step writes.  Anything this path does not reproduce to the letter -- sampling,
-# processors, criteria, streamers, score outputs, more than 16 rows, masks with holes -- takes HF's loop as before.  Batches: a row that has its EOS gets the pad
+# loop picks: both take the argmax of the logits the SAME engine step writes.  SAMPLING (llama_inference.py:119-127's own call) the same way: HF's warpers and
+# torch.multinomial captured behind the step -- the same draws for a seed, the generator left where HF's loop leaves it (GPTQ_SAMPLE_FAST=0: off).  Anything this
+# path does not reproduce to the letter --
+# warpers other than temperature / top-k / top-p, processors, criteria, streamers, score outputs, more than 16 rows, masks with holes -- takes HF's loop as before.  Batches: a row that has its EOS gets the pad
 # token from then on, the call ends when every row has one (HF's own rule); the rows never see each other, so the stream is cut and padded afterwards.  GPTQ_GREEDY_FAST=0: off.
 GREEDY_FAST = os.environ.get('GPTQ_GREEDY_FAST', '1') != '0'
+SAMPLE_FAST = os.environ.get('GPTQ_SAMPLE_FAST', '1') != '0'
 _GREEDY_KW = {'input_ids', 'inputs', 'do_sample', 'max_new_tokens', 'max_length', 'min_length', 'min_new_tokens', 'eos_token_id', 'pad_token_id',
               'attention_mask', 'use_cache', 'num_beams', 'temperature', 'top_p', 'top_k'}
 # generation_config fields that must sit at their neutral value (name, neutral values)
@@ -338,15 +341,42 @@ def _greedy_fast(model, st, orig_generate, args, kwargs):
         return None
     if len(args) > 1 or not set(kwargs) <= _GREEDY_KW:
         return None
-    gc = getattr(model, 'generation_config', None)
-    if gc is None:
+    if getattr(model, 'generation_config', None) is None:
         return None
-    get = lambda name: kwargs[name] if kwargs.get(name) is not None else getattr(gc, name, None)
-    if get('do_sample') or int(get('num_beams') or 1) != 1 or get('use_cache') is False:
+    # the generation config of THIS call as HF resolves it (kwargs over the model's config over the library's defaults -- an unset field of
+    # model.generation_config reads None, and e.g. top_k = 50 only appears here)
+    try:
+        gc, _ = model._prepare_generation_config(None, **{k: v for k, v in kwargs.items() if k not in ('input_ids', 'inputs')})
+    except Exception:
+        return None
+    get = lambda name: getattr(gc, name, None)
+    if int(get('num_beams') or 1) != 1 or get('use_cache') is False:
         return None
     for name, neutral in _GREEDY_NEUTRAL:
         if getattr(gc, name, None) not in neutral:
             return None
+    sample = bool(get('do_sample'))
+    warpers, wkey = [], None
+    if sample:
+        # HF's warper chain for this call (generation/utils.py _get_logits_processor, the do_sample branch, in its order): temperature, top-k, top-p; any
+        # other warper configured -> HF's loop.  GPTQ_SAMPLE_FAST=0: sampling always takes HF's loop.
+        if not SAMPLE_FAST:
+            return None
+        for name, neutral in (('min_p', (None,)), ('typical_p', (None, 1.0)), ('epsilon_cutoff', (None, 0.0)), ('eta_cutoff', (None, 0.0)), ('top_h', (None,))):
+            if getattr(gc, name, None) not in neutral:
+                return None
+        from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+        temp, top_k, top_p = get('temperature'), get('top_k'), get('top_p')
+        try:
+            if temp is not None and temp != 1.0:
+                warpers.append(TemperatureLogitsWarper(temp))
+            if top_k is not None and top_k != 0:
+                warpers.append(TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=1))
+            if top_p is not None and top_p < 1.0:
+                warpers.append(TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=1))
+        except (ValueError, TypeError):
+            return None                   # (values HF itself rejects: let it say so)
+        wkey = (temp, top_k, top_p)
     ids = args[0] if args else kwargs.get('input_ids', kwargs.get('inputs'))
     dev = next(model.parameters()).device
     if not torch.is_tensor(ids) or ids.dim() != 2 or not 1 <= ids.shape[0] <= MAX_BATCH or ids.shape[1] < 2 or ids.dtype != torch.int64 or ids.device != dev or dev.type != 'cuda':
@@ -360,7 +390,7 @@ def _greedy_fast(model, st, orig_generate, args, kwargs):
         npad = _left_pads(mask, T - 1)
         if npad is None:
             return None
-    new = kwargs.get('max_new_tokens') or (None if kwargs.get('max_length') is not None else getattr(gc, 'max_new_tokens', None))
+    new = get('max_new_tokens')          # (wins over max_length, as in HF)
     if new is None:
         new = int(get('max_length') or 0) - T
     new = int(new)
@@ -382,6 +412,7 @@ def _greedy_fast(model, st, orig_generate, args, kwargs):
     if st.cache_ref is not None:          # a sequence some caller steps by hand: its cache is completed before the engine moves on
         _sync_back(st)
     st.engine, st.cache_ref = None, None
+    rng0 = torch.cuda.get_rng_state(dev) if sample else None          # (a call handed back to HF's loop must draw what it would have drawn)
     with torch.no_grad():
         # the prompt and the FIRST token are HF's own: its generate for one new token (its prefill inputs, its processors on that step)
         kw1 = {k: v for k, v in kwargs.items() if k not in ('input_ids', 'inputs', 'max_new_tokens', 'max_length', 'min_length', 'min_new_tokens')}
@@ -390,14 +421,22 @@ def _greedy_fast(model, st, orig_generate, args, kwargs):
         out = orig_generate(ids, max_new_tokens=1, return_dict_in_generate=True, **kw1)
         cache = getattr(out, 'past_key_values', None)
         if cache is None or tuple(out.sequences.shape) != (B, T + 1) or _cache_len(cache) != T:
+            if sample:
+                torch.cuda.set_rng_state(rng0, dev)
             return None
         first = out.sequences[:, T].clone()
         st.engine = eng
         _sync_in(st, cache, T, npad)          # the rows' K / V behind their pads, per-row positions
         st.engine, st.cache_ref = None, None  # (nobody tracks this cache: it is dropped below)
         del out, cache
-        if eng.greedy_rows_graph is None:
-            eng.capture_greedy_rows()
+        if sample:
+            graph = eng.sample_graphs.get(wkey) or eng.capture_sample_rows(wkey, warpers)
+            gen_state = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+            off0 = gen_state.get_offset()
+        else:
+            if eng.greedy_rows_graph is None:
+                eng.capture_greedy_rows()
+            graph = eng.greedy_rows_graph
         eng.stepc.zero_()
         eng.ids.copy_(first)
         eos_t = torch.tensor(eos, device=dev, dtype=torch.int64) if eos else None
@@ -407,7 +446,7 @@ def _greedy_fast(model, st, orig_generate, args, kwargs):
         while done < new and not all_hit():
             burst = min(16, new - done)                       # the host looks at the stream every 16 tokens only
             for _ in range(burst):
-                eng.greedy_rows_graph.replay()
+                graph.replay()
             done += burst
             st.steps += burst
         gen = stream().t().contiguous()                       # [B, done]
@@ -419,12 +458,18 @@ def _greedy_fast(model, st, orig_generate, args, kwargs):
             info = torch.cat([firsthit, anyhit.to(torch.int64)]).tolist()
             fh, ah = info[:B], info[B:]
             if any(a and f < min_new for f, a in zip(fh, ah)):
+                if sample:
+                    torch.cuda.set_rng_state(rng0, dev)
                 return None                                   # HF's loop would have masked that EOS: it takes the call
             length = max((f + 1 if a else done) for f, a in zip(fh, ah))          # HF stops when every row has its EOS
             if any(ah) and B > 1:                             # behind a row's EOS HF writes the pad token while the other rows go on
                 col = torch.arange(done, device=dev)[None, :]
                 gen = torch.where(col > firsthit[:, None], torch.full_like(gen, int(pad)), gen)
         gen = gen[:, :length]
+        if sample and done > 1:
+            # the generator stands where HF's loop would have left it: `length - 1` draws behind the first token's (the bursts may have drawn more)
+            per_step = (gen_state.get_offset() - off0) // (done - 1)
+            gen_state.set_offset(off0 + (length - 1) * per_step)
     return torch.cat([ids, gen.to(ids.dtype)], 1)
 
 

@@ -514,7 +514,7 @@ def test_greedy_generate_fast_path_equals_the_hf_loop():
     (quant/engine_hook.py _greedy_fast: no host round trip per token) -- the SAME tokens as HF's loop over the same engine steps, with and
     without an EOS in the stream, with max_length instead of max_new_tokens, minimum lengths, an all-ones mask, and for left-padded BATCHES whose
     rows end at different steps (pad tokens behind a row's EOS, the call ends with the last row); every call the fast path does not reproduce
-    to the letter (sampling, score outputs, penalties, a prompt of one token) takes HF's loop"""
+    to the letter (other warpers, score outputs, penalties, a prompt of one token) takes HF's loop"""
     from quant import engine_hook as EH
     model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=17, fused=True, **HOOK_CFG)
     ids = torch.randint(1, 512, (1, 9), device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
@@ -585,7 +585,7 @@ def test_greedy_generate_fast_path_equals_the_hf_loop():
             both(idb, attention_mask=mb, do_sample=False, max_new_tokens=24, eos_token_id=stop)                 # pad defaults to the first EOS id
         # ... and what it leaves to HF's loop
         with torch.no_grad():
-            for kw in (dict(do_sample=True, max_new_tokens=8, top_p=0.9), dict(do_sample=False, max_new_tokens=8, output_logits=True, return_dict_in_generate=True),
+            for kw in (dict(do_sample=True, max_new_tokens=8, typical_p=0.5), dict(do_sample=False, max_new_tokens=8, output_logits=True, return_dict_in_generate=True),
                        dict(do_sample=False, max_new_tokens=8, repetition_penalty=1.2)):
                 calls.clear()
                 model.generate(ids, **kw)
@@ -601,6 +601,63 @@ def test_greedy_generate_fast_path_equals_the_hf_loop():
     finally:
         EH._greedy_fast = orig
         EH.GREEDY_FAST = True
+
+
+def test_sampling_generate_fast_path_draws_what_the_hf_loop_draws():
+    """round 6: generate(do_sample=True, ...) -- llama_inference.py:119-127's own call -- runs a self-feeding SAMPLING graph: HF's warpers (temperature,
+    top-k, top-p in HF's order, built from the generation config as HF resolves it: top_k = 50 is a library default) and torch.multinomial are captured
+    behind the engine step, the default generator's Philox offset advances per replay as per eager call.  For a given seed: the SAME tokens as HF's loop,
+    and the generator left in the SAME state (the next torch.rand agrees) -- one prompt and left-padded batches, with EOS stops and a minimum length"""
+    from quant import engine_hook as EH
+    model = D.build_random_llama(DEV, bits=4, groupsize=128, seed=19, fused=True, **HOOK_CFG)
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    ids = torch.randint(1, 512, (1, 9), device=DEV, generator=gen)
+    idb = torch.randint(1, 512, (4, 8), device=DEV, generator=gen)
+    mb = torch.ones_like(idb)
+    idb[0, :3] = 0; mb[0, :3] = 0; idb[2, :1] = 0; mb[2, :1] = 0
+    calls = []
+    orig = EH._greedy_fast
+    EH._greedy_fast = lambda *a, **k: (calls.append(orig(*a, **k)) or calls[-1])
+
+    def run(fast, x, seed, **kw):
+        EH.SAMPLE_FAST = fast
+        calls.clear()
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            out = model.generate(x, **kw)
+        return out, torch.rand(4, device=DEV), (calls[0] is not None if calls else False)
+    try:
+        cases = (('the script', ids, dict(do_sample=True, min_length=10, max_length=50, top_p=0.95, temperature=0.8)),
+                 ('library defaults (top_k = 50)', ids, dict(do_sample=True, max_new_tokens=40)),
+                 ('no warper', ids, dict(do_sample=True, max_new_tokens=40, top_k=0)),
+                 ('EOS off', ids, dict(do_sample=True, max_new_tokens=40, top_p=0.9, eos_token_id=None)),
+                 ('four left-padded prompts', idb, dict(do_sample=True, attention_mask=mb, max_new_tokens=33, top_p=0.9, temperature=0.7, pad_token_id=0)))
+        taken = 0
+        for name, x, kw in cases:
+            for seed in (0, 1, 2):
+                a, ra, took = run(True, x, seed, **kw)
+                b, rb, _ = run(False, x, seed, **kw)
+                assert a.shape == b.shape and torch.equal(a, b), (name, seed, a.tolist(), b.tolist())
+                assert torch.equal(ra, rb), (name, seed, 'the generator is not where HF\'s loop leaves it')
+                taken += int(took)
+                if took:
+                    c, rc, _ = run(True, x, seed, **kw)
+                    assert torch.equal(a, c) and torch.equal(ra, rc)
+        assert taken >= 10, taken             # (a call may be handed back: an EOS drawn in front of the minimum length)
+        # a stream that stops at a sampled EOS: pick one from a long run, then ask for it as EOS (both ways stop there)
+        full, _, took = run(True, ids, 5, do_sample=True, max_new_tokens=40, top_p=0.9, eos_token_id=None)
+        assert took
+        eos = int(full[0, 9 + 17])
+        for seed in (5, 6):
+            a, ra, _ = run(True, ids, seed, do_sample=True, max_new_tokens=40, top_p=0.9, eos_token_id=eos, pad_token_id=0)
+            b, rb, _ = run(False, ids, seed, do_sample=True, max_new_tokens=40, top_p=0.9, eos_token_id=eos, pad_token_id=0)
+            assert torch.equal(a, b) and torch.equal(ra, rb), seed
+        # other warpers: HF's loop
+        _, _, took = run(True, ids, 0, do_sample=True, max_new_tokens=8, typical_p=0.5)
+        assert not took
+    finally:
+        EH._greedy_fast = orig
+        EH.SAMPLE_FAST = True
 
 
 def test_batched_generate_goes_through_the_batched_engine():

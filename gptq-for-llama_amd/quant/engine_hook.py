@@ -360,8 +360,8 @@ def _greedy_fast(model, st, orig_generate, args, kwargs):
     if sample:
         # HF's warper chain for this call (generation/utils.py _get_logits_processor, the do_sample branch, in its order): temperature, top-k, top-p; any
         # other warper configured -> HF's loop.  GPTQ_SAMPLE_FAST=0: sampling always takes HF's loop.
-        if not SAMPLE_FAST:
-            return None
+        if not SAMPLE_FAST or not hasattr(torch.Generator, 'get_offset') or not hasattr(torch.Generator, 'set_offset'):
+            return None                   # (the generator's offset is read and set below: torch >= 2.2)
         for name, neutral in (('min_p', (None,)), ('typical_p', (None, 1.0)), ('epsilon_cutoff', (None, 0.0)), ('eta_cutoff', (None, 0.0)), ('top_h', (None,))):
             if getattr(gc, name, None) not in neutral:
                 return None

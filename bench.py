@@ -736,7 +736,8 @@ def decode_tokens_per_s(dev, tokens=64):
       drop_in_generate model.generate(...) as llama_inference.py:119-127 calls it
       engine_graph     quant.decode.DecodeEngine driven directly (one hipGraph replay per token)
       engine_graph_bN  DecodeEngine(batch=N): N sequences per replay, aggregate tokens/s
-      engine_graph_[bN_]ctxT  the same engines with ~T tokens of history per row (round 6)"""
+      engine_graph_[bN_]ctxT  the same engines with ~T tokens of history per row (round 6)
+      drop_in_generate_sampling  the script's own SAMPLING call, self-feeding sampling graph against HF's loop (own process: sampling_generate_leg)"""
     from quant.decode import build_random_llama, benchmark_decode, benchmark_decode_engine, benchmark_generate, benchmark_decode_engine_context
     import quant
     model = build_random_llama(dev)
@@ -775,7 +776,59 @@ def decode_tokens_per_s(dev, tokens=64):
     torch.cuda.empty_cache()
     out['drop_in_generate_b4_left_padded'] = benchmark_generate(model, batch=4, left_pad=True, new_tokens=64)
     drop_decode_engines(model)
+    del model
+    torch.cuda.empty_cache()
+    out['drop_in_generate_sampling'] = sampling_generate_leg()
     return out
+
+
+_SAMPLING_LEG = r'''
+import json, sys, time
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+from quant import decode as D, engine_hook as EH
+fill = D.fill_random_quant_
+def small(layer, gen):
+    fill(layer, gen)
+    layer.scales.mul_(0.05)
+D.fill_random_quant_ = small
+m = D.build_random_llama('cuda:0')
+ids = torch.randint(1, 32000, (1, 16), device='cuda:0', generator=torch.Generator(device='cuda:0').manual_seed(0))
+with torch.no_grad():
+    lg = m(ids).logits[0, -1].float()
+res = {'logits_finite': bool(torch.isfinite(lg).all())}
+if res['logits_finite']:
+    def t(n):
+        torch.manual_seed(0); torch.cuda.synchronize(); t0 = time.perf_counter()
+        with torch.no_grad():
+            out = m.generate(ids, do_sample=True, max_new_tokens=n, top_p=0.95, temperature=0.8, eos_token_id=None)
+        torch.cuda.synchronize(); return time.perf_counter() - t0, out
+    toks = {}
+    for name, fast in (('sampling_graph', True), ('hf_loop', False)):
+        EH.SAMPLE_FAST = fast
+        t(4); t1, _ = t(1); tn, out = t(128)
+        res[name + '_tokens_per_s'] = round(127 / (tn - t1), 1)
+        toks[name] = out[0].tolist()
+    res['same_tokens'] = toks['sampling_graph'] == toks['hf_loop']
+print('SAMPLING_LEG ' + json.dumps(res), flush=True)
+'''
+
+
+def sampling_generate_leg():
+    """llama_inference.py:119-127's own call -- model.generate(do_sample=True, top_p=0.95, temperature=0.8) -- on a LLaMA-7B-shaped random model, tokens/s through
+    the hook's self-feeding sampling graph (HF's warpers + torch.multinomial captured behind the engine step: quant/engine_hook.py) and through HF's loop, same
+    seed, and whether both drew the same tokens.  In a PROCESS of its own, on a model whose random scales are 20 x smaller: the stock random stack overflows fp16
+    to NaN logits, on which torch.multinomial aborts the process (in HF's loop as well) -- an abort here must not take the bench line with it."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, '-c', _SAMPLING_LEG % (PKG, ROOT)], capture_output=True, text=True, timeout=600)
+        for line in r.stdout.splitlines():
+            if line.startswith('SAMPLING_LEG '):
+                return dict(json.loads(line[len('SAMPLING_LEG '):]), call='model.generate(input_ids[1, 16], do_sample=True, max_new_tokens=128, top_p=0.95, temperature=0.8) '
+                            '(llama_inference.py:119-127), 7B-shaped random model with scales x 0.05 (finite logits), own process')
+        return {'error': 'no result (rc %d): %s' % (r.returncode, r.stderr[-300:])}
+    except Exception as e:
+        return {'error': repr(e)[:200]}
 
 
 def main():
